@@ -1,0 +1,165 @@
+/*
+ * resco_sim.h -- C ABI of the MI355X-native batched traffic-signal simulator.
+ *
+ * Drop-in boundary: this library replaces the `self.sumo` connection object behind RESCO's
+ * MultiSignal (the TraCI subset listed below) for N lock-step environment instances on one GPU.
+ * One handle = one GPU = one HIP stream; handles are independent (8 GPUs = 8 handles in 8
+ * processes or threads); there is no global state.  Functions return 0 on success or a negative
+ * RS_E* code and never throw; rs_last_error() gives the message.  The library owns all device
+ * buffers; rs_get_buffer() lends device pointers that stay valid until rs_destroy().
+ *
+ * Reference interface each entry point replaces (paths relative to the RESCO repository):
+ *   rs_create    traci.start(sumo_cmd) + the probe run + Signal() program install
+ *                resco_benchmark/multi_signal.py:38-47,72-73,132-137; traffic_signal.py:93-100
+ *   rs_reset     MultiSignal.reset(): new simulation, fresh Signal objects, first observe
+ *                resco_benchmark/multi_signal.py:107-162
+ *   rs_step      MultiSignal.step(): prep_phase all -> yellow ticks -> set_phase all -> green
+ *                ticks -> observe all -> state_fn / reward_fn -> calc_metrics
+ *                resco_benchmark/multi_signal.py:164-197 (step_sim :102-105 = sumo.simulationStep()),
+ *                traffic_signal.py:172-187 (FSM), :189-247 (observe / get_vehicles),
+ *                states.py:34-127 (drq_norm, mplight, wave), rewards.py:6-41 (wait, wait_norm, pressure)
+ *   rs_get_buffer  the TraCI getters used per step: trafficlight.getPhase (traffic_signal.py:174),
+ *                lane.getLastStepVehicleIDs (:240), vehicle.getNextTLS / getWaitingTime / getSpeed /
+ *                getAcceleration / getLanePosition / getTypeID (:201-210,241), simulation.getTime
+ *                (multi_signal.py:190,212)
+ *   rs_act_*     the static agents' act(): agents/maxwave.py:18-38, maxpressure.py:13-18,
+ *                stochastic.py:17-18 (batched, on device)
+ *   rs_destroy   traci.close()  multi_signal.py:231-234
+ */
+#ifndef RESCO_SIM_H
+#define RESCO_SIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_OK 0
+#define RS_EINVAL (-1)     /* bad argument */
+#define RS_EHIP (-2)       /* HIP runtime error (see rs_last_error) */
+#define RS_ENOMEM (-3)
+#define RS_ELIMIT (-4)     /* scenario exceeds a compiled-in limit (LDS budget, id widths) */
+
+/* Flat scenario tables built by resco_amd/scenario.py (host pointers; copied to the device by
+ * rs_create).  Field order is shared with the ctypes mirror in resco_amd/_abi.py. */
+typedef struct rs_scenario {
+    int32_t n_lanes, n_links, n_edges, n_routes, n_trips, n_signals, n_obs, n_vtypes;
+    int32_t n_foes, n_route_steps, n_tls_states, n_tls_dur, n_tls_yellow;
+    int32_t n_fix_states, n_fix_dur, n_mv_in, n_mv_out, n_pr_out;
+    int32_t horizon, capacity, step_length, yellow_length;
+    /* lanes (normal + junction-internal), compact ids */
+    const float *lane_len, *lane_vmax;
+    const int32_t *lane_edge, *lane_left, *lane_right, *lane_link_start, *lane_link_cnt, *lane_obs, *lane_internal;
+    /* links (lane -> next lane) */
+    const int32_t *link_to_lane, *link_dest_lane, *link_to_edge, *link_tls, *link_tls_pos, *link_minor, *link_cont;
+    const int32_t *link_foe_start, *link_foe_cnt;
+    const float *link_via_len;
+    const int32_t *link_via1, *link_via2, *link_from_lane, *foe_link;
+    /* edges */
+    const int32_t *edge_lane0, *edge_nlanes;
+    /* routes: CSR over route steps */
+    const int32_t *route_start, *route_edge;
+    const float *route_tlsdist;
+    const uint32_t *route_mask1, *route_mask2;
+    /* demand (identical in every environment) */
+    const int32_t *trip_depart, *trip_route, *trip_vtype, *trips_cum;
+    const float *vtype_params;          /* [n_vtypes][10]: length minGap accel decel tau sigma maxSpeed sfMean sfDev emergencyDecel */
+    /* controlled signals: program installed by Signal.__init__ (greens + generated yellows) */
+    const int32_t *tls_nphase, *tls_ngreen, *tls_nlinks, *tls_state_off, *tls_dur_off, *tls_yel_off, *tls_init_phase;
+    const int32_t *tls_states, *tls_dur, *tls_yellow;
+    /* the net file's own fixed-time programs (FIXED baseline) */
+    const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_init_phase, *fix_init_left, *fix_states, *fix_dur;
+    /* observation gather tables (Signal.lanes / lane_sets / lane_sets_outbound / outbound_lanes) */
+    const int32_t *obs_lane, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx;
+    const int32_t *pr_out_start, *pr_out_idx;
+} rs_scenario;
+
+typedef struct rs_params {
+    uint32_t seed;
+    float max_distance;       /* detector range, MultiSignal(max_distance=...) */
+    float sigma;              /* <0: the vType's Krauss sigma; 0: deterministic parity mode */
+    int32_t speed_dev;        /* 1: per-vehicle speedFactor ~ clip(N(mean, dev), 0.2, 2) */
+    int32_t fixed_program;    /* 1: run the net's own tlLogic and ignore actions */
+} rs_params;
+
+typedef struct rs_sim *rs_handle;
+
+/* env_base: global index of this handle's first environment (keys the counter-based RNG so that a batch
+ * sharded over several GPUs reproduces the single-GPU batch).  block_threads: 0 = choose. */
+int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
+              int32_t block_threads, rs_handle *out);
+void rs_destroy(rs_handle h);
+const char *rs_last_error(rs_handle h);     /* h may be NULL: error of the last failed rs_create on this thread */
+
+/* Start a new episode in every environment and run the first observe.  stream: a hipStream_t, or NULL for
+ * the handle's own stream. */
+int rs_reset(rs_handle h, void *stream);
+/* One MultiSignal.step() for every environment.  actions: int32 [n_envs][n_signals] (green-phase index per
+ * signal), host pointer, or device pointer when actions_on_device != 0; NULL = use the handle's RS_BUF_ACTIONS
+ * buffer as is (e.g. filled by rs_act_*).  Asynchronous: outputs are ready after rs_sync / stream sync. */
+int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_device, void *stream);
+int rs_sync(rs_handle h);
+
+/* Batched on-device static agents writing RS_BUF_ACTIONS. */
+int rs_act_random(rs_handle h, uint32_t step_key, void *stream);       /* STOCHASTIC: U{0..G_s-1} */
+/* MAXWAVE / MAXPRESSURE: argmax over valid phase pairs of obs[pair0]+obs[pair1].
+ * phase_pairs int32 [n_pairs][2]; valid int32 [n_signals][n_pairs] = local action or -1 (host pointers,
+ * copied on first use).  use_pressure: 1 = mplight[1:] (MAXPRESSURE), 0 = wave (MAXWAVE). */
+int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n_pairs, const int32_t *valid,
+                   int32_t use_pressure, void *stream);
+
+enum rs_buffer {
+    RS_BUF_LANE_AGG = 0,   /* f32 [N][n_obs][5]  queue, approach, total_wait, max_wait, speed_sum */
+    RS_BUF_DRQ_NORM,       /* f32 [N][n_obs][5]  states.drq_norm rows (signal-major, Signal.lanes order) */
+    RS_BUF_PHASE,          /* i32 [N][S]         Signal.phase */
+    RS_BUF_MPLIGHT,        /* i32 [N][S][13]     states.mplight */
+    RS_BUF_WAVE,           /* i32 [N][S][12]     states.wave */
+    RS_BUF_WAIT,           /* f32 [N][S]         rewards.wait */
+    RS_BUF_WAIT_NORM,      /* f32 [N][S]         rewards.wait_norm */
+    RS_BUF_PRESSURE,       /* i32 [N][S]         rewards.pressure */
+    RS_BUF_QUEUE_SUM,      /* i32 [N][S]         calc_metrics queue_lengths */
+    RS_BUF_QUEUE_MAX,      /* i32 [N][S]         calc_metrics max_queues */
+    RS_BUF_ACTIONS,        /* i32 [N][S]         action staging buffer */
+    RS_BUF_ENV,            /* i32 [N][4]         ticks since begin, next_trip, high-water slot, reserved */
+    RS_BUF_TLS,            /* i32 [N][S][3]      phase, time left, next_phase */
+    RS_BUF_VEH_POS,        /* f32 [N][C] */
+    RS_BUF_VEH_SPEED,      /* f32 [N][C] */
+    RS_BUF_VEH_ACCEL,      /* f32 [N][C] */
+    RS_BUF_VEH_TLOSS,      /* f32 [N][C] */
+    RS_BUF_VEH_LANE,       /* u16 [N][C]  0xFFFF free, 0xFFFE waiting for insertion */
+    RS_BUF_VEH_TRIP,       /* u16 [N][C]  0xFFFF free */
+    RS_BUF_VEH_CURSOR,     /* u16 [N][C] */
+    RS_BUF_VEH_SWAIT,      /* u16 [N][C]  SUMO waiting time (s) */
+    RS_BUF_VEH_RWAIT,      /* u16 [N][C]  RESCO Signal.waiting_times value (s), 0 = not in the dict */
+    RS_BUF_VEH_DEPART,     /* u16 [N][C] */
+    RS_BUF_VEH_OWNER,      /* u8  [N][C]  index of the signal that observed the vehicle last, 0xFF none */
+    RS_BUF_STATS,          /* i64 [N][10] see rs_stats */
+    RS_BUF_DRQ_NORM_F16,   /* f16 [N][S][Lmax][5] zero padded states.drq_norm (IDQN rollout layout) */
+    RS_BUF_COUNT
+};
+enum rs_dtype { RS_F32 = 0, RS_I32 = 1, RS_U16 = 2, RS_U8 = 3, RS_F16 = 4, RS_I64 = 5 };
+
+int rs_get_buffer(rs_handle h, int32_t which, void **dev_ptr, int64_t shape[4], int32_t *ndim, int32_t *dtype);
+/* convenience: synchronous device->host copy of a whole buffer */
+int rs_read_buffer(rs_handle h, int32_t which, void *host_dst, int64_t nbytes);
+
+/* per env: [0] inserted [1] arrived [2] sum duration(s) [3] sum departDelay(s) [4] sum waiting(s)
+ * [5] sum timeLoss (1/1024 s) [6] active now [7] pending now [8] sum over ticks of active vehicles [9] ticks */
+int rs_stats(rs_handle h, int64_t *host_out /* [n_envs][10] */);
+
+/* environment snapshots (device-resident copies of the SoA state) */
+int rs_snapshot(rs_handle h, void **snap);
+int rs_restore(rs_handle h, const void *snap);
+void rs_snapshot_free(rs_handle h, void *snap);
+
+/* kernel timing on the launch stream (hipEvent pairs around every step kernel while enabled) */
+int rs_timing(rs_handle h, int32_t enable);
+int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches);   /* syncs; resets the accumulators */
+
+/* static facts */
+int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int32_t *lds_bytes, int32_t *max_lanes_per_signal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,708 @@
+/*
+ * resco_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).  See resco_oracle.h.
+ *
+ * Phase-synchronous restatement: every phase reads the state left by the previous phase and
+ * writes new state, with no dependence on iteration order, so that a data-parallel
+ * implementation (one GPU lane per vehicle) must reproduce it bit-for-bit.  All kinematics
+ * are IEEE fp32 with no fused contraction (compile with -ffp-contract=off).
+ *
+ * Per tick (SUMO MSNet::simulationStep order [SUMO-K]):
+ *   P0 TLS switch events   P1 lane lists   P2 insertion   P3 link approach registration
+ *   P4 plan (Krauss)       P5 move         P6 lane lists  P7 lane change
+ */
+#include "resco_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LANE_NONE 0xFFFFu
+#define LANE_PENDING 0xFFFEu
+#define OWNER_NONE 0xFFu
+#define NIL (-1)
+#define HALT_SPEED 0.1f
+#define STOP_OFFSET 1.0f
+#define ARR_NONE 65535
+#define FOE_GAP_Q 40 /* a foe arriving within 4.0 s blocks a minor link */
+#define MAX_HOPS 6
+#define BIGF 1.0e30f
+#define SG_ADVANTAGE 10.0f
+#define URGENT_DIST 50.0f
+
+enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
+enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
+
+struct orc_env {
+    const orc_scenario *sc;
+    orc_params p;
+    int32_t env_index;
+    int32_t t;              /* ticks since begin */
+    int32_t next_trip;      /* trips [0,next_trip) have been given a slot */
+    int32_t hw;             /* high-water mark: slots >= hw are free */
+    int32_t *trip;          /* slot -> trip index, -1 free */
+    /* vehicles */
+    uint16_t *lane, *cursor, *sumo_wait, *resco_wait, *depart;
+    uint8_t *owner;
+    float *pos, *speed, *accel, *time_loss, *vnext;
+    int32_t *lc_target;
+    int32_t *dbg_reason, *dbg_block;   /* why the last plan() limited each vehicle (debug aid) */
+    /* lane lists */
+    int32_t *lane_head, *next_in_lane;
+    int32_t *link_arr;
+    int32_t *lane_ins;
+    /* signals */
+    int32_t *phase, *left, *next_phase;
+    /* outputs */
+    float *lane_agg, *drq_norm, *wait, *wait_norm;
+    int32_t *agg_q, *agg_a, *agg_w, *agg_m;
+    uint32_t *agg_s;
+    int32_t *out_phase, *mplight, *wave, *pressure, *queue_sum, *queue_max;
+    int64_t stats[10];
+};
+
+/* ------------------------------------------------------------------ counter-based RNG (murmur3_32) */
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+uint32_t orc_hash(uint32_t seed, uint32_t env, uint32_t trip, uint32_t tick, uint32_t stream) {
+    uint32_t h = seed;
+    uint32_t w[4] = {env, trip, tick, stream};
+    for (int i = 0; i < 4; ++i) {
+        uint32_t k = w[i];
+        k *= 0xcc9e2d51u; k = rotl32(k, 15); k *= 0x1b873593u;
+        h ^= k; h = rotl32(h, 13); h = h * 5u + 0xe6546b64u;
+    }
+    h ^= 16u;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+static inline float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+/* ------------------------------------------------------------------ Krauss arithmetic [SUMO-K]
+ * MSCFModel::brakeGapEuler / maximumSafeStopSpeedEuler / maximumSafeFollowSpeed, dt = 1 s. */
+float orc_brake_gap(float v, float b) {
+    int steps = (int)(v / b);
+    float fs = (float)steps;
+    return fs * v - b * fs * (fs + 1.0f) * 0.5f;
+}
+float orc_stop_speed(float gap, float b, float tau) {
+    float g = gap - 0.001f;
+    if (g < 0.0f) return 0.0f;
+    float q = 1.0f + 4.0f * ((2.0f * g / b - tau) + tau * tau);
+    float n = floorf(0.5f - (tau + sqrtf(q) * -0.5f));
+    float h = 0.5f * n * (n - 1.0f) * b + n * b * tau;
+    float r = (g - h) / (n + tau);
+    return n * b + r;
+}
+float orc_follow_speed(float gap, float vl, float b, float bl, float tau) {
+    float bm = b > bl ? b : bl;
+    return orc_stop_speed(gap + orc_brake_gap(vl, bm), b, tau);
+}
+
+/* ------------------------------------------------------------------ helpers */
+static inline const float *vt_of(const orc_env *e, int32_t trip) {
+    return e->sc->vtype_params + (size_t)e->sc->trip_vtype[trip] * VT_COLS;
+}
+static inline int32_t trip_of_slot(const orc_env *e, int32_t slot) { return e->trip[slot]; }
+static float speed_factor(const orc_env *e, int32_t trip) {
+    const float *vt = vt_of(e, trip);
+    if (!e->p.speed_dev) return vt[VT_SF_MEAN];
+    /* Irwin-Hall(4) normal surrogate: basic arithmetic only, identical on CPU and GPU */
+    float s = 0.0f;
+    for (uint32_t i = 0; i < 4; ++i) s += u01(orc_hash(e->p.seed, (uint32_t)e->env_index, (uint32_t)trip, 0xFFFFFFFFu, i));
+    float z = (s - 2.0f) * 1.7320508f;
+    float f = vt[VT_SF_MEAN] + vt[VT_SF_DEV] * z;
+    if (f < 0.2f) f = 0.2f;
+    if (f > 2.0f) f = 2.0f;
+    return f;
+}
+static inline int ahead_of(float pj, int32_t kj, float pi, int32_t ki) { /* j strictly ahead of i */
+    return pj > pi || (pj == pi && kj < ki);
+}
+static int32_t choose_link(const orc_env *e, int32_t lane, int32_t route, int32_t cursor) {
+    const orc_scenario *sc = e->sc;
+    int32_t ls = sc->lane_link_start[lane], lc = sc->lane_link_cnt[lane];
+    if (lc == 0) return -1;
+    if (sc->lane_internal[lane]) return ls;
+    int32_t rs = sc->route_start[route], rn = sc->route_start[route + 1] - rs;
+    if (cursor + 1 >= rn) return -1;
+    int32_t ne = sc->route_edge[rs + cursor + 1];
+    uint32_t pref = sc->route_mask2[rs + cursor + 1], okm = sc->route_mask1[rs + cursor + 1];
+    int32_t best = -1, any = -1;
+    for (int32_t l = ls; l < ls + lc; ++l) {
+        if (sc->link_to_edge[l] != ne) continue;
+        int32_t k = sc->link_dest_lane[l] - sc->edge_lane0[ne];
+        if ((pref >> k) & 1u) return l;                 /* lands on a lane that continues the route */
+        if (best < 0 && ((okm >> k) & 1u)) best = l;    /* lands where a lane change can still fix it */
+        if (any < 0) any = l;
+    }
+    return best >= 0 ? best : any;
+}
+static inline int32_t tls_state(const orc_env *e, int32_t link) {
+    const orc_scenario *sc = e->sc;
+    int32_t s = sc->link_tls[link];
+    if (s < 0) return TLS_G;
+    if (e->p.fixed_program)
+        return sc->fix_states[sc->fix_state_off[s] + e->phase[s] * sc->tls_nlinks[s] + sc->link_tls_pos[link]];
+    return sc->tls_states[sc->tls_state_off[s] + e->phase[s] * sc->tls_nlinks[s] + sc->link_tls_pos[link]];
+}
+/* departure lane: lowest-index lane of the first edge that continues the route ("best"; SUMO's default
+ * "first" would force a lane change on the departure edge) */
+static inline int32_t depart_lane(const orc_scenario *sc, int32_t route) {
+    int32_t rs = sc->route_start[route];
+    uint32_t m = sc->route_mask2[rs];
+    int32_t k = 0;
+    while (k < 31 && !((m >> k) & 1u)) k += 1;
+    if (k >= sc->edge_nlanes[sc->route_edge[rs]]) k = 0;
+    return sc->edge_lane0[sc->route_edge[rs]] + k;
+}
+static void build_lists(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    for (int32_t l = 0; l < sc->n_lanes; ++l) e->lane_head[l] = NIL;
+    for (int32_t s = 0; s < e->hw; ++s) {
+        if (e->lane[s] >= LANE_PENDING) continue;
+        e->next_in_lane[s] = e->lane_head[e->lane[s]];
+        e->lane_head[e->lane[s]] = s;
+    }
+}
+/* rear-most vehicle on a lane: min pos, ties -> larger trip index */
+static int32_t rearmost(const orc_env *e, int32_t lane) {
+    int32_t best = NIL, bk = 0;
+    for (int32_t s = e->lane_head[lane]; s != NIL; s = e->next_in_lane[s]) {
+        int32_t k = trip_of_slot(e, s);
+        if (best == NIL || e->pos[s] < e->pos[best] || (e->pos[s] == e->pos[best] && k > bk)) { best = s; bk = k; }
+    }
+    return best;
+}
+/* nearest vehicle ahead / behind of (pos,k) on a lane */
+static void neighbours(const orc_env *e, int32_t lane, float pos, int32_t k, int32_t self, int32_t *lead, int32_t *foll) {
+    int32_t L = NIL, F = NIL, Lk = 0, Fk = 0;
+    for (int32_t s = e->lane_head[lane]; s != NIL; s = e->next_in_lane[s]) {
+        if (s == self) continue;
+        int32_t ks = trip_of_slot(e, s);
+        if (ahead_of(e->pos[s], ks, pos, k)) {
+            if (L == NIL || ahead_of(e->pos[L], Lk, e->pos[s], ks)) { L = s; Lk = ks; }
+        } else {
+            if (F == NIL || ahead_of(e->pos[s], ks, e->pos[F], Fk)) { F = s; Fk = ks; }
+        }
+    }
+    *lead = L; *foll = F;
+}
+
+/* ------------------------------------------------------------------ lifecycle */
+#define ALLOC(p, n) p = calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(*(p)))
+orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_index) {
+    orc_env *e = calloc(1, sizeof(orc_env));
+    e->sc = sc; e->p = *p; e->env_index = env_index;
+    int32_t C = sc->capacity, S = sc->n_signals, O = sc->n_obs;
+    ALLOC(e->lane, C); ALLOC(e->cursor, C); ALLOC(e->sumo_wait, C); ALLOC(e->resco_wait, C); ALLOC(e->depart, C);
+    ALLOC(e->owner, C); ALLOC(e->pos, C); ALLOC(e->speed, C); ALLOC(e->accel, C); ALLOC(e->time_loss, C);
+    ALLOC(e->vnext, C); ALLOC(e->lc_target, C); ALLOC(e->trip, C); ALLOC(e->dbg_reason, C); ALLOC(e->dbg_block, C);
+    ALLOC(e->lane_head, sc->n_lanes); ALLOC(e->next_in_lane, C); ALLOC(e->link_arr, sc->n_links);
+    ALLOC(e->lane_ins, sc->n_lanes);
+    ALLOC(e->phase, S); ALLOC(e->left, S); ALLOC(e->next_phase, S);
+    ALLOC(e->lane_agg, O * 5); ALLOC(e->drq_norm, O * 5); ALLOC(e->wait, S); ALLOC(e->wait_norm, S);
+    ALLOC(e->agg_q, O); ALLOC(e->agg_a, O); ALLOC(e->agg_w, O); ALLOC(e->agg_m, O); ALLOC(e->agg_s, O);
+    ALLOC(e->out_phase, S); ALLOC(e->mplight, S * 13); ALLOC(e->wave, S * 12); ALLOC(e->pressure, S);
+    ALLOC(e->queue_sum, S); ALLOC(e->queue_max, S);
+    orc_reset(e);
+    return e;
+}
+void orc_destroy(orc_env *e) {
+    if (!e) return;
+    free(e->lane); free(e->cursor); free(e->sumo_wait); free(e->resco_wait); free(e->depart); free(e->owner);
+    free(e->pos); free(e->speed); free(e->accel); free(e->time_loss); free(e->vnext); free(e->lc_target); free(e->trip); free(e->dbg_reason); free(e->dbg_block);
+    free(e->lane_head); free(e->next_in_lane); free(e->link_arr); free(e->lane_ins);
+    free(e->phase); free(e->left); free(e->next_phase);
+    free(e->lane_agg); free(e->drq_norm); free(e->wait); free(e->wait_norm);
+    free(e->agg_q); free(e->agg_a); free(e->agg_w); free(e->agg_m); free(e->agg_s);
+    free(e->out_phase); free(e->mplight); free(e->wave); free(e->pressure); free(e->queue_sum); free(e->queue_max);
+    free(e);
+}
+void orc_reset(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    e->t = 0; e->next_trip = 0; e->hw = 0;
+    for (int32_t s = 0; s < sc->capacity; ++s) {
+        e->lane[s] = LANE_NONE; e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; e->sumo_wait[s] = 0; e->trip[s] = -1;
+        e->pos[s] = 0; e->speed[s] = 0; e->accel[s] = 0; e->time_loss[s] = 0; e->cursor[s] = 0; e->depart[s] = 0;
+    }
+    for (int32_t l = 0; l < sc->n_links; ++l) e->link_arr[l] = ARR_NONE;
+    for (int32_t l = 0; l < sc->n_lanes; ++l) e->lane_ins[l] = 0x7FFFFFFF;
+    for (int32_t s = 0; s < sc->n_signals; ++s) {
+        if (e->p.fixed_program) {
+            e->phase[s] = sc->fix_init_phase[s];
+            e->left[s] = sc->fix_init_left[s];
+        } else {
+            /* [SUMO-K] setProgramLogic (traffic_signal.py:96-100) restarts the current index with its full duration */
+            e->phase[s] = sc->tls_init_phase[s];
+            e->left[s] = sc->tls_dur[sc->tls_dur_off[s] + e->phase[s]];
+        }
+        e->next_phase[s] = 0;       /* Signal.__init__: self.next_phase = 0 (traffic_signal.py:32) */
+    }
+    memset(e->stats, 0, sizeof(e->stats));
+    build_lists(e);
+}
+int32_t orc_time(const orc_env *e) { return e->t; }
+int32_t orc_get_phase(const orc_env *e, int32_t sig) { return e->phase[sig]; }
+void orc_set_phase(orc_env *e, int32_t sig, int32_t ph) {
+    const orc_scenario *sc = e->sc;
+    if (ph < 0 || ph >= sc->tls_nphase[sig]) return;
+    e->phase[sig] = ph;
+    e->left[sig] = sc->tls_dur[sc->tls_dur_off[sig] + ph];
+}
+
+/* ------------------------------------------------------------------ the tick */
+static void tls_events(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    for (int32_t s = 0; s < sc->n_signals; ++s) {
+        const int32_t *dur = e->p.fixed_program ? sc->fix_dur + sc->fix_dur_off[s] : sc->tls_dur + sc->tls_dur_off[s];
+        int32_t P = e->p.fixed_program ? sc->fix_nphase[s] : sc->tls_nphase[s];
+        if (e->left[s] == 0) {
+            e->phase[s] = (e->phase[s] + 1) % P;
+            e->left[s] = dur[e->phase[s]];
+        }
+        e->left[s] -= 1;
+    }
+}
+
+static void insertion(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    int32_t C = sc->capacity;
+    /* trips that departed before this tick take the lowest free slots, in trip order */
+    int32_t due = e->t >= 1 ? sc->trips_cum[e->t - 1 <= sc->horizon ? e->t - 1 : sc->horizon] : 0;
+    for (int32_t s = 0; s < C && e->next_trip < due; ++s) {
+        if (e->lane[s] != LANE_NONE) continue;
+        e->trip[s] = e->next_trip++;
+        e->lane[s] = LANE_PENDING;
+        e->pos[s] = 0; e->speed[s] = 0; e->accel[s] = 0; e->time_loss[s] = 0; e->cursor[s] = 0;
+        e->sumo_wait[s] = 0; e->resco_wait[s] = 0; e->owner[s] = OWNER_NONE; e->depart[s] = 0;
+        if (s + 1 > e->hw) e->hw = s + 1;
+    }
+    /* lowest pending trip per departure lane is the candidate */
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] != LANE_PENDING) continue;
+        int32_t r = sc->trip_route[k];
+        int32_t dl = depart_lane(sc, r);
+        if (k < e->lane_ins[dl]) e->lane_ins[dl] = k;
+    }
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] != LANE_PENDING) continue;
+        int32_t r = sc->trip_route[k];
+        int32_t dl = depart_lane(sc, r);
+        if (e->lane_ins[dl] != k) continue;
+        const float *vt = vt_of(e, k);
+        float mypos = vt[VT_LENGTH] < sc->lane_len[dl] ? vt[VT_LENGTH] : sc->lane_len[dl];
+        int ok = 1;
+        for (int32_t o = e->lane_head[dl]; o != NIL; o = e->next_in_lane[o]) {
+            const float *vo = vt_of(e, trip_of_slot(e, o));
+            float back = e->pos[o] - vo[VT_LENGTH];
+            if (back - mypos - vt[VT_MINGAP] < 0.0f) ok = 0;
+        }
+        if (!ok) continue;
+        e->lc_target[s] = dl;        /* staged; applied after every candidate has been checked */
+        e->vnext[s] = mypos;
+        e->lane[s] = LANE_PENDING;   /* unchanged until the apply loop */
+        e->cursor[s] = 0xFFFF;       /* marker: insert me */
+    }
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] != LANE_PENDING) continue;
+        int32_t r = sc->trip_route[k];
+        int32_t dl = depart_lane(sc, r);
+        e->lane_ins[dl] = 0x7FFFFFFF;
+        if (e->cursor[s] != 0xFFFF) continue;
+        e->lane[s] = (uint16_t)dl;
+        e->pos[s] = e->vnext[s];
+        e->speed[s] = 0; e->cursor[s] = 0; e->depart[s] = (uint16_t)e->t;
+        e->next_in_lane[s] = e->lane_head[dl];
+        e->lane_head[dl] = s;
+        e->stats[0] += 1;
+        e->stats[3] += e->t - 1 - sc->trip_depart[k];
+    }
+}
+
+static void register_approaches(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] >= LANE_PENDING) continue;
+        int32_t lane = e->lane[s];
+        int32_t link = choose_link(e, lane, sc->trip_route[k], e->cursor[s]);
+        if (link < 0) continue;
+        const float *vt = vt_of(e, k);
+        float dist = sc->lane_len[lane] - e->pos[s];
+        float v = e->speed[s];
+        int32_t st = tls_state(e, link);
+        if (v <= HALT_SPEED) continue;          /* a standing vehicle is not "approaching" (SUMO willPass=false) */
+        if (st == TLS_R) continue;
+        if (st == TLS_Y && dist >= orc_brake_gap(v, vt[VT_DECEL])) continue;
+        float ta = dist / (v > 1.0f ? v : 1.0f);
+        int32_t q = ta * 10.0f >= 65000.0f ? 65000 : (int32_t)(ta * 10.0f);
+        if (q < e->link_arr[link]) e->link_arr[link] = q;
+    }
+}
+
+/* a vehicle moving on a foe's junction lane blocks; a standing one (spill-back) is driven around */
+static int lane_has_mover(const orc_env *e, int32_t lane) {
+    for (int32_t s = e->lane_head[lane]; s != NIL; s = e->next_in_lane[s])
+        if (e->speed[s] > HALT_SPEED) return 1;
+    return 0;
+}
+static int foe_blocked(const orc_env *e, int32_t link) {
+    const orc_scenario *sc = e->sc;
+    int32_t fs = sc->link_foe_start[link], fc = sc->link_foe_cnt[link];
+    for (int32_t i = fs; i < fs + fc; ++i) {
+        int32_t f = sc->foe_link[i];
+        if (sc->link_tls[f] >= 0 && tls_state(e, f) == TLS_R) continue;
+        if (e->link_arr[f] < FOE_GAP_Q) return 1;
+        if (sc->link_via1[f] >= 0 && lane_has_mover(e, sc->link_via1[f])) return 1;
+        if (sc->link_via2[f] >= 0 && lane_has_mover(e, sc->link_via2[f])) return 1;
+    }
+    return 0;
+}
+
+static void plan(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] >= LANE_PENDING) continue;
+        const float *vt = vt_of(e, k);
+        float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
+        int32_t lane = e->lane[s], route = sc->trip_route[k];
+        int32_t cursor = e->cursor[s];
+        float v = e->speed[s], x = e->pos[s];
+        float sf = speed_factor(e, k);
+        float vfree = v + a;
+        float vl = sc->lane_vmax[lane] * sf;
+        if (vl < vfree) vfree = vl;
+        if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
+        float vsafe = BIGF;
+        e->dbg_reason[s] = 0; e->dbg_block[s] = -1;
+        /* leader on my own lane */
+        int32_t lead, foll;
+        neighbours(e, lane, x, k, s, &lead, &foll);
+        int found = 0;
+        if (lead != NIL) {
+            const float *vo = vt_of(e, trip_of_slot(e, lead));
+            float gap = e->pos[lead] - vo[VT_LENGTH] - x - mingap;
+            vsafe = orc_follow_speed(gap, e->speed[lead], b, vo[VT_DECEL], tau);
+            found = 1;
+            e->dbg_reason[s] = 1; e->dbg_block[s] = lead;
+        }
+        /* look ahead along my path */
+        float look = orc_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
+        float seen = sc->lane_len[lane] - x;
+        int32_t cur = lane, cur_cursor = cursor;
+        int32_t rn = sc->route_start[route + 1] - sc->route_start[route];
+        for (int hop = 0; hop < MAX_HOPS && !found && seen < look; ++hop) {
+            if (!sc->lane_internal[cur] && cur_cursor + 1 >= rn) break;     /* my last edge: free run to its end */
+            int32_t link = choose_link(e, cur, route, cur_cursor);
+            if (link < 0) {     /* wrong lane for my route: wait at the end for a lane change */
+                float g = seen - STOP_OFFSET;
+                float vs = orc_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
+                if (vs < vsafe) { vsafe = vs; e->dbg_reason[s] = 2; e->dbg_block[s] = cur; }
+                break;
+            }
+            int32_t st = tls_state(e, link);
+            int stop_here = 0;
+            if (sc->link_tls[link] >= 0 && (st == TLS_R || st == TLS_Y)) {
+                if (seen >= orc_brake_gap(v, b)) { stop_here = 1; e->dbg_reason[s] = 3; e->dbg_block[s] = link; }
+            }
+            if (!stop_here && !sc->link_cont[link] && sc->link_foe_cnt[link] > 0 &&
+                (sc->link_minor[link] || (sc->link_tls[link] >= 0 && st == TLS_g))) {
+                if (foe_blocked(e, link)) { stop_here = 1; e->dbg_reason[s] = 4; e->dbg_block[s] = link; }
+            }
+            if (stop_here) {
+                float g = seen - STOP_OFFSET;
+                float vs = orc_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
+                if (vs < vsafe) vsafe = vs;
+                break;
+            }
+            int32_t nl = sc->link_to_lane[link];
+            int32_t o = rearmost(e, nl);
+            if (o != NIL) {
+                const float *vo = vt_of(e, trip_of_slot(e, o));
+                float gap = seen + e->pos[o] - vo[VT_LENGTH] - mingap;
+                float vs = orc_follow_speed(gap, e->speed[o], b, vo[VT_DECEL], tau);
+                if (vs < vsafe) { vsafe = vs; e->dbg_reason[s] = 5; e->dbg_block[s] = o; }
+                found = 1;
+                break;
+            }
+            if (!sc->lane_internal[cur]) cur_cursor += 1;
+            seen += sc->lane_len[nl];
+            cur = nl;
+        }
+        /* MSCFModel::finalizeSpeed + Krauss dawdle2 [SUMO-K] */
+        float vmin_n = v - b; if (vmin_n < 0.0f) vmin_n = 0.0f;
+        float vmin_e = v - vt[VT_EMERGENCY]; if (vmin_e < 0.0f) vmin_e = 0.0f;
+        float lo = vsafe > vmin_e ? vsafe : vmin_e;
+        float vmin = vmin_n < lo ? vmin_n : lo;
+        float vmax = vfree < vsafe ? vfree : vsafe;
+        if (vmax < vmin) vmax = vmin;
+        float sigma = e->p.sigma >= 0.0f ? e->p.sigma : vt[VT_SIGMA];
+        float vd = vmax;
+        if (sigma > 0.0f) {
+            float r = u01(orc_hash(e->p.seed, (uint32_t)e->env_index, (uint32_t)k, (uint32_t)e->t, 0u));
+            if (vd < a) vd -= sigma * vd * r; else vd -= sigma * a * r;
+            if (vd < 0.0f) vd = 0.0f;
+        }
+        e->vnext[s] = vd > vmin ? vd : vmin;
+    }
+}
+
+static void move(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] >= LANE_PENDING) continue;
+        /* clear my approach registration (the table is all-ARR_NONE between ticks) */
+        int32_t lk = choose_link(e, e->lane[s], sc->trip_route[k], e->cursor[s]);
+        if (lk >= 0) e->link_arr[lk] = ARR_NONE;
+    }
+    int32_t active = 0;
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] >= LANE_PENDING) continue;
+        int32_t route = sc->trip_route[k];
+        int32_t rn = sc->route_start[route + 1] - sc->route_start[route];
+        float vn = e->vnext[s];
+        float sf = speed_factor(e, k);
+        float vref = sc->lane_vmax[e->lane[s]] * sf;
+        e->accel[s] = vn - e->speed[s];
+        e->speed[s] = vn;
+        if (vn <= HALT_SPEED) { if (e->sumo_wait[s] < 65535) e->sumo_wait[s] += 1; e->stats[4] += 1; }
+        else e->sumo_wait[s] = 0;
+        if (vref > 0.0f && vn < vref) e->time_loss[s] += (vref - vn) / vref;
+        float x = e->pos[s] + vn;
+        int32_t lane = e->lane[s], cursor = e->cursor[s];
+        int arrived = 0;
+        for (int it = 0; it < 16; ++it) {
+            float len = sc->lane_len[lane];
+            if (!(x > len)) break;
+            if (!sc->lane_internal[lane] && cursor + 1 >= rn) { arrived = 1; break; }
+            int32_t link = choose_link(e, lane, route, cursor);
+            if (link < 0) { x = len; break; }
+            x -= len;
+            if (!sc->lane_internal[lane]) cursor += 1;
+            lane = sc->link_to_lane[link];
+        }
+        if (arrived) {
+            e->lane[s] = LANE_NONE; e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; e->trip[s] = -1;
+            e->stats[1] += 1;
+            e->stats[2] += e->t + 1 - e->depart[s];
+            e->stats[5] += (int64_t)(e->time_loss[s] * 1024.0f + 0.5f);
+        } else {
+            e->lane[s] = (uint16_t)lane; e->cursor[s] = (uint16_t)cursor; e->pos[s] = x;
+            active += 1;
+        }
+    }
+    e->stats[8] += active;
+    while (e->hw > 0 && e->lane[e->hw - 1] == LANE_NONE) e->hw -= 1;
+}
+
+static void lane_change(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    int32_t dir_allowed = (e->t & 1) ? -1 : +1;
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        e->lc_target[s] = -1;
+        if (e->lane[s] >= LANE_PENDING) continue;
+        int32_t lane = e->lane[s];
+        if (sc->lane_internal[lane]) continue;
+        int32_t ed = sc->lane_edge[lane];
+        int32_t n = sc->edge_nlanes[ed];
+        if (n < 2) continue;
+        int32_t kk = lane - sc->edge_lane0[ed];
+        int32_t route = sc->trip_route[k];
+        uint32_t m2 = sc->route_mask2[sc->route_start[route] + e->cursor[s]];
+        int32_t tk = kk + dir_allowed;
+        if (tk < 0 || tk >= n) continue;
+        const float *vt = vt_of(e, k);
+        float x = e->pos[s], v = e->speed[s];
+        int32_t tl = sc->edge_lane0[ed] + tk;
+        int want = 0;
+        int32_t lead_c, foll_c, lead_t, foll_t;
+        neighbours(e, tl, x, k, s, &lead_t, &foll_t);
+        if (!((m2 >> kk) & 1u)) {
+            /* strategic: head for the nearest lane that continues my route */
+            int32_t dl = 1000, dr = 1000;
+            for (int32_t j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
+            for (int32_t j = kk - 1; j >= 0; --j) if ((m2 >> j) & 1u) { dr = kk - j; break; }
+            int32_t dir = 0;
+            if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
+            want = (dir == dir_allowed) ? 2 : 0;
+        } else if ((m2 >> tk) & 1u) {
+            /* speed gain between equally good lanes: more room ahead on the neighbour */
+            neighbours(e, lane, x, k, s, &lead_c, &foll_c);
+            if (lead_c != NIL) {
+                const float *vo = vt_of(e, trip_of_slot(e, lead_c));
+                float gcur = e->pos[lead_c] - vo[VT_LENGTH] - x;
+                float gtgt = BIGF;
+                if (lead_t != NIL) {
+                    const float *vq = vt_of(e, trip_of_slot(e, lead_t));
+                    gtgt = e->pos[lead_t] - vq[VT_LENGTH] - x;
+                }
+                if (gcur < v * 3.0f + 15.0f && gtgt > gcur + SG_ADVANTAGE) want = 1;
+            }
+        }
+        if (!want) continue;
+        /* urgent = strategic change close to the end of the lane: accept tighter gaps (followers may have to
+         * brake with their emergency deceleration), otherwise dense queues would never let anybody in */
+        int urgent = want == 2 && (sc->lane_len[lane] - x) <= URGENT_DIST;
+        int safe = 1;
+        if (lead_t != NIL) {
+            const float *vo = vt_of(e, trip_of_slot(e, lead_t));
+            float gap = e->pos[lead_t] - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
+            float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
+            float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
+            if (gap < 0.0f || vb > orc_follow_speed(gap, e->speed[lead_t], vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = 0;
+        }
+        if (safe && foll_t != NIL) {
+            const float *vo = vt_of(e, trip_of_slot(e, foll_t));
+            float gap = x - vt[VT_LENGTH] - e->pos[foll_t] - (urgent ? 0.0f : vo[VT_MINGAP]);
+            float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
+            float vb = e->speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
+            if (gap < 0.0f || vb > orc_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = 0;
+        }
+        if (safe) e->lc_target[s] = tl;
+    }
+    for (int32_t s = 0; s < e->hw; ++s) {
+        if (e->lane[s] >= LANE_PENDING) continue;
+        if (e->lc_target[s] >= 0) e->lane[s] = (uint16_t)e->lc_target[s];
+    }
+}
+
+void orc_tick(orc_env *e) {
+    tls_events(e);
+    build_lists(e);
+    insertion(e);
+    register_approaches(e);
+    plan(e);
+    move(e);
+    build_lists(e);
+    lane_change(e);
+    e->t += 1;
+    e->stats[9] += 1;
+}
+
+/* ------------------------------------------------------------------ observe + state/reward */
+void orc_observe(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    int32_t O = sc->n_obs, S = sc->n_signals;
+    for (int32_t i = 0; i < O; ++i) { e->agg_q[i] = e->agg_a[i] = e->agg_w[i] = e->agg_m[i] = 0; e->agg_s[i] = 0; }
+    /* obs-lane -> signal */
+    for (int32_t s = 0; s < e->hw; ++s) {
+        int32_t k = e->trip[s];
+        if (e->lane[s] >= LANE_PENDING) continue;
+        int32_t lane = e->lane[s];
+        int32_t oi = sc->lane_obs[lane];
+        int detect = 0;
+        if (oi >= 0) {
+            int32_t route = sc->trip_route[k];
+            float d = (sc->lane_len[lane] - e->pos[s]) + sc->route_tlsdist[sc->route_start[route] + e->cursor[s]];
+            detect = d <= e->p.max_distance;
+        }
+        if (!detect) { e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; continue; }
+        int32_t sig = 0;
+        while (sc->sig_obs_start[sig + 1] <= oi) sig += 1;
+        /* RESCO waiting-time rule (traffic_signal.py:198-202, 222-232) */
+        if (e->owner[s] != (uint8_t)sig) e->resco_wait[s] = 0;
+        if (e->resco_wait[s] > 0) {
+            uint32_t w = (uint32_t)e->resco_wait[s] + (uint32_t)sc->step_length;
+            e->resco_wait[s] = (uint16_t)(w > 65535u ? 65535u : w);
+        } else if (e->sumo_wait[s] > 0) {
+            e->resco_wait[s] = e->sumo_wait[s];
+        }
+        e->owner[s] = (uint8_t)sig;
+        int32_t w = e->resco_wait[s];
+        if (w > 0) { e->agg_q[oi] += 1; e->agg_w[oi] += w; if (w > e->agg_m[oi]) e->agg_m[oi] = w; }
+        else e->agg_a[oi] += 1;
+        e->agg_s[oi] += (uint32_t)(e->speed[s] * 65536.0f + 0.5f);      /* Q16 fixed point: order-independent */
+    }
+    for (int32_t sg = 0; sg < S; ++sg) {
+        int32_t ph = e->phase[sg];
+        e->out_phase[sg] = ph;
+        int32_t o0 = sc->sig_obs_start[sg], o1 = sc->sig_obs_start[sg + 1];
+        int32_t tw = 0, tq = 0, mq = 0;
+        for (int32_t oi = o0; oi < o1; ++oi) {
+            float sp = (float)e->agg_s[oi] * (1.0f / 65536.0f);
+            float *la = e->lane_agg + oi * 5, *dn = e->drq_norm + oi * 5;
+            la[0] = (float)e->agg_q[oi]; la[1] = (float)e->agg_a[oi]; la[2] = (float)e->agg_w[oi];
+            la[3] = (float)e->agg_m[oi]; la[4] = sp;
+            /* states.drq_norm (states.py:34-59): one-hot compares LANE POSITION with PHASE INDEX */
+            dn[0] = (oi - o0) == ph ? 1.0f : 0.0f;
+            dn[1] = (float)e->agg_a[oi] / 28.0f;
+            dn[2] = (float)e->agg_w[oi] / 28.0f;
+            dn[3] = (float)e->agg_q[oi] / 28.0f;
+            dn[4] = sp / 20.0f / 28.0f;
+            tw += e->agg_w[oi]; tq += e->agg_q[oi];
+            if (e->agg_q[oi] > mq) mq = e->agg_q[oi];
+        }
+        e->queue_sum[sg] = tq; e->queue_max[sg] = mq;
+        e->wait[sg] = -(float)tw;                                         /* rewards.wait (rewards.py:6-14) */
+        float wn = -(float)tw / 224.0f;                                   /* rewards.wait_norm (rewards.py:17-25) */
+        e->wait_norm[sg] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
+        int32_t pr = tq;                                                  /* rewards.pressure (rewards.py:28-41) */
+        for (int32_t i = sc->pr_out_start[sg]; i < sc->pr_out_start[sg + 1]; ++i) pr -= e->agg_q[sc->pr_out_idx[i]];
+        e->pressure[sg] = -pr;
+        e->mplight[sg * 13] = ph;                                         /* states.mplight (states.py:62-80) */
+        for (int32_t m = 0; m < 12; ++m) {
+            int32_t q = 0, wv = 0;
+            for (int32_t i = sc->mv_in_start[sg * 12 + m]; i < sc->mv_in_start[sg * 12 + m + 1]; ++i) {
+                q += e->agg_q[sc->mv_in_idx[i]];
+                wv += e->agg_q[sc->mv_in_idx[i]] + e->agg_a[sc->mv_in_idx[i]];
+            }
+            for (int32_t i = sc->mv_out_start[sg * 12 + m]; i < sc->mv_out_start[sg * 12 + m + 1]; ++i)
+                q -= e->agg_q[sc->mv_out_idx[i]];
+            e->mplight[sg * 13 + 1 + m] = q;
+            e->wave[sg * 12 + m] = wv;                                    /* states.wave (states.py:116-127) */
+        }
+    }
+}
+
+void orc_step(orc_env *e, const int32_t *actions) {
+    const orc_scenario *sc = e->sc;
+    int32_t S = sc->n_signals;
+    if (!e->p.fixed_program) {
+        for (int32_t s = 0; s < S; ++s) {                    /* Signal.prep_phase (traffic_signal.py:176-184) */
+            int32_t a = actions[s], cur = e->phase[s], G = sc->tls_ngreen[s];
+            if (a < 0 || a >= sc->tls_nphase[s]) { e->next_phase[s] = cur; continue; }
+            e->next_phase[s] = a;
+            if (cur != a && cur < G && a < G) {
+                int32_t y = sc->tls_yellow[sc->tls_yel_off[s] + cur * G + a];
+                if (y >= 0) orc_set_phase(e, s, y);
+            }
+        }
+    }
+    for (int32_t i = 0; i < sc->yellow_length; ++i) orc_tick(e);
+    if (!e->p.fixed_program)
+        for (int32_t s = 0; s < S; ++s) orc_set_phase(e, s, e->next_phase[s]);   /* Signal.set_phase (:186-187) */
+    for (int32_t i = 0; i < sc->step_length - sc->yellow_length; ++i) orc_tick(e);
+    orc_observe(e);
+}
+
+/* ------------------------------------------------------------------ getters */
+const float *orc_lane_agg(const orc_env *e) { return e->lane_agg; }
+const float *orc_drq_norm(const orc_env *e) { return e->drq_norm; }
+const int32_t *orc_phase(const orc_env *e) { return e->out_phase; }
+const int32_t *orc_mplight(const orc_env *e) { return e->mplight; }
+const int32_t *orc_wave(const orc_env *e) { return e->wave; }
+const float *orc_wait(const orc_env *e) { return e->wait; }
+const float *orc_wait_norm(const orc_env *e) { return e->wait_norm; }
+const int32_t *orc_pressure(const orc_env *e) { return e->pressure; }
+const int32_t *orc_queue_sum(const orc_env *e) { return e->queue_sum; }
+const int32_t *orc_queue_max(const orc_env *e) { return e->queue_max; }
+void orc_get_vehicles(const orc_env *e, orc_vehicles *o) {
+    o->hw = e->hw; o->next_trip = e->next_trip; o->trip = e->trip; o->lane = e->lane; o->pos = e->pos; o->speed = e->speed;
+    o->accel = e->accel; o->time_loss = e->time_loss; o->cursor = e->cursor; o->sumo_wait = e->sumo_wait;
+    o->resco_wait = e->resco_wait; o->depart = e->depart; o->owner = e->owner;
+}
+void orc_debug(const orc_env *e, const int32_t **reason, const int32_t **block) { *reason = e->dbg_reason; *block = e->dbg_block; }
+void orc_stats(const orc_env *e, int64_t out[10]) {
+    memcpy(out, e->stats, sizeof(e->stats));
+    int64_t act = 0, pend = 0;
+    for (int32_t s = 0; s < e->hw; ++s) {
+        uint16_t l = e->lane[s];
+        if (l == LANE_PENDING) pend += 1; else if (l != LANE_NONE) act += 1;
+    }
+    out[6] = act; out[7] = pend;
+}

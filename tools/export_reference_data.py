@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Build-container tool: turn the reference's scenario DATA into the files this package ships.
+
+Runs only where /root/reference exists (never on the GPU box).  Produces
+  resco_amd/config/signal_configs.json   the per-map signal_configs dict (data; hot maps)
+  resco_amd/scenarios/<map>.npz          compiled flat tables (resco_amd.scenario.compile_scenario)
+
+No reference source text is copied: signal_config.py is *executed* as data and its dict is
+re-serialised; net.xml / rou.xml are parsed and compiled to index tables.
+"""
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get('RESCO_REFERENCE', '/root/reference')
+MAPS = ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21']
+
+
+def load_ref_module(rel, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    from resco_amd.scenario import compile_from_sumocfg
+    sc_mod = load_ref_module('resco_benchmark/config/signal_config.py', '_ref_signal_config')
+    mc_mod = load_ref_module('resco_benchmark/config/map_config.py', '_ref_map_config')
+    out = {}
+    for m in MAPS:
+        cfg = sc_mod.signal_configs[m]
+        enc = {}
+        for k, v in cfg.items():
+            if k == 'valid_acts':
+                enc[k] = None if v is None else {sid: [[int(a), int(b)] for a, b in d.items()] for sid, d in v.items()}
+            else:
+                enc[k] = v
+        out[m] = enc
+    with open(os.path.join(ROOT, 'resco_amd', 'config', 'signal_configs.json'), 'w') as f:
+        json.dump(out, f, separators=(',', ':'))
+    for m in MAPS:
+        mc = mc_mod.map_configs[m]
+        cfgpath = os.path.join(REF, 'resco_benchmark', mc['net'])
+        sc = compile_from_sumocfg(m, cfgpath, sc_mod.signal_configs[m], lights=mc['lights'],
+                                  yellow_length=mc['yellow_length'])
+        sc.save(os.path.join(ROOT, 'resco_amd', 'scenarios', m + '.npz'))
+        print(m, 'lanes', sc.n_lanes, 'links', sc.n_links, 'edges', sc.n_edges, 'routes', sc.n_routes,
+              'trips', sc.n_trips, 'dropped', sc.dropped_trips, 'signals', sc.n_signals, 'obs', sc.n_obs,
+              'capacity', sc.capacity, 'unmapped obs lanes', int((sc.obs_lane < 0).sum()))
+
+
+if __name__ == '__main__':
+    main()
