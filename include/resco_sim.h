@@ -102,11 +102,13 @@ int rs_sync(rs_handle h);
 
 /* Batched on-device static agents writing RS_BUF_ACTIONS. */
 int rs_act_random(rs_handle h, uint32_t step_key, void *stream);       /* STOCHASTIC: U{0..G_s-1} */
-/* MAXWAVE / MAXPRESSURE: argmax over valid phase pairs of obs[pair0]+obs[pair1].
- * phase_pairs int32 [n_pairs][2]; valid int32 [n_signals][n_pairs] = local action or -1 (host pointers,
- * copied on first use).  use_pressure: 1 = mplight[1:] (MAXPRESSURE), 0 = wave (MAXWAVE). */
+/* MAXWAVE / MAXPRESSURE: first maximum over the valid phase pairs of obs[pair0]+obs[pair1].
+ * phase_pairs int32 [n_pairs][2]; valid int32 [n_signals][n_pairs] = local action of a pair or -1;
+ * order int32 [n_signals][n_pairs] = pair indices in the reference's iteration order, -1 terminated
+ * (host pointers, copied on first use, may be NULL afterwards).
+ * use_pressure: 1 = mplight[1:] (MAXPRESSURE), 0 = wave (MAXWAVE). */
 int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n_pairs, const int32_t *valid,
-                   int32_t use_pressure, void *stream);
+                   const int32_t *order, int32_t use_pressure, void *stream);
 
 enum rs_buffer {
     RS_BUF_LANE_AGG = 0,   /* f32 [N][n_obs][5]  queue, approach, total_wait, max_wait, speed_sum */

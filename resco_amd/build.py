@@ -1,0 +1,27 @@
+"""Build the HIP shared library in-tree (resco_amd/csrc/libresco_sim.so) for gfx950."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, 'csrc', 'resco_sim.hip')
+LIB = os.path.join(HERE, 'csrc', 'libresco_sim.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# -ffp-contract=off: fp32 results must equal the CPU oracle bit-for-bit (no FMA fusion)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+         '-I' + os.path.join(ROOT, 'include')]
+
+
+def build_library(force=False, verbose=False):
+    deps = [SRC, os.path.join(ROOT, 'include', 'resco_sim.h')]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return LIB
+    cmd = [HIPCC] + FLAGS + [SRC, '-o', LIB]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_library(force=True, verbose=True))

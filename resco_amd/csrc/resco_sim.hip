@@ -1,0 +1,1175 @@
+// resco_sim.hip -- MI355X (gfx950 / CDNA4) batched traffic-signal microsimulator behind the C ABI of
+// include/resco_sim.h.  Written for gfx950 only: wave64, LDS-resident environment state, one workgroup
+// per environment instance, every tick of an env-step fused into ONE kernel launch.
+//
+// Hot path replaced (RESCO, paths relative to its repository):
+//   MultiSignal.step                 resco_benchmark/multi_signal.py:164-197
+//   Signal.prep_phase / set_phase    resco_benchmark/traffic_signal.py:176-187
+//   sumo.simulationStep() x 10       resco_benchmark/multi_signal.py:102-105   (SUMO itself: [SUMO-K])
+//   Signal.observe / get_vehicles    resco_benchmark/traffic_signal.py:189-247
+//   states.drq_norm / mplight / wave resco_benchmark/states.py:34-127
+//   rewards.wait / wait_norm / pressure  resco_benchmark/rewards.py:6-41
+//
+// Layout
+//   HBM  : env-major SoA, field[env][slot]; a workgroup streams its env's slab in once per env-step
+//          (coalesced, slot-contiguous), keeps it in LDS for all ticks, and streams it out once.
+//   LDS  : per-vehicle arrays + per-lane list heads + per-link approach registers + per-lane aggregates.
+//   L2/IC: read-only scenario tables shared by all environments (< 1 MB).
+// There is no dense contraction on this path: no MFMA.  Arithmetic is IEEE fp32 with contraction off so the
+// CPU oracle (oracle/resco_oracle.c, test-only) reproduces every value bit-for-bit.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "resco_sim.h"
+
+#define LANE_NONE 0xFFFFu
+#define LANE_PENDING 0xFFFEu
+#define OWNER_NONE 0xFFu
+#define NIL 0xFFFF
+#define HALT_SPEED 0.1f
+#define STOP_OFFSET 1.0f
+#define ARR_NONE 65535
+#define FOE_GAP_Q 40
+#define MAX_HOPS 6
+#define BIGF 1.0e30f
+#define SG_ADVANTAGE 10.0f
+#define URGENT_DIST 50.0f
+
+enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
+enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
+enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, ST_ACTIVE, ST_PENDING, ST_ACTIVE_TICKS, ST_TICKS, ST_N };
+
+// ------------------------------------------------------------------------------------------------ tables
+// X(name, ctype, count)
+#define RS_TABLES(X)                                                                                              \
+    X(lane_len, float, n_lanes) X(lane_vmax, float, n_lanes) X(lane_edge, int32_t, n_lanes)                       \
+    X(lane_left, int32_t, n_lanes) X(lane_right, int32_t, n_lanes) X(lane_link_start, int32_t, n_lanes)           \
+    X(lane_link_cnt, int32_t, n_lanes) X(lane_obs, int32_t, n_lanes) X(lane_internal, int32_t, n_lanes)           \
+    X(link_to_lane, int32_t, n_links) X(link_dest_lane, int32_t, n_links) X(link_to_edge, int32_t, n_links)       \
+    X(link_tls, int32_t, n_links) X(link_tls_pos, int32_t, n_links) X(link_minor, int32_t, n_links)               \
+    X(link_cont, int32_t, n_links) X(link_foe_start, int32_t, n_links) X(link_foe_cnt, int32_t, n_links)          \
+    X(link_via_len, float, n_links) X(link_via1, int32_t, n_links) X(link_via2, int32_t, n_links)                 \
+    X(link_from_lane, int32_t, n_links) X(foe_link, int32_t, n_foes) X(edge_lane0, int32_t, n_edges)              \
+    X(edge_nlanes, int32_t, n_edges) X(route_start, int32_t, n_routes + 1) X(route_edge, int32_t, n_route_steps)  \
+    X(route_tlsdist, float, n_route_steps) X(route_mask1, uint32_t, n_route_steps)                                \
+    X(route_mask2, uint32_t, n_route_steps) X(trip_depart, int32_t, n_trips) X(trip_route, int32_t, n_trips)      \
+    X(trip_vtype, int32_t, n_trips) X(trips_cum, int32_t, horizon + 2) X(vtype_params, float, n_vtypes * VT_COLS) \
+    X(tls_nphase, int32_t, n_signals) X(tls_ngreen, int32_t, n_signals) X(tls_nlinks, int32_t, n_signals)         \
+    X(tls_state_off, int32_t, n_signals) X(tls_dur_off, int32_t, n_signals) X(tls_yel_off, int32_t, n_signals)    \
+    X(tls_init_phase, int32_t, n_signals) X(tls_states, int32_t, n_tls_states) X(tls_dur, int32_t, n_tls_dur)     \
+    X(tls_yellow, int32_t, n_tls_yellow) X(fix_nphase, int32_t, n_signals) X(fix_state_off, int32_t, n_signals)   \
+    X(fix_dur_off, int32_t, n_signals) X(fix_init_phase, int32_t, n_signals) X(fix_init_left, int32_t, n_signals) \
+    X(fix_states, int32_t, n_fix_states) X(fix_dur, int32_t, n_fix_dur) X(obs_lane, int32_t, n_obs)               \
+    X(sig_obs_start, int32_t, n_signals + 1) X(mv_in_start, int32_t, n_signals * 12 + 1)                          \
+    X(mv_in_idx, int32_t, n_mv_in) X(mv_out_start, int32_t, n_signals * 12 + 1) X(mv_out_idx, int32_t, n_mv_out)  \
+    X(pr_out_start, int32_t, n_signals + 1) X(pr_out_idx, int32_t, n_pr_out)
+
+struct Tab {
+#define X(name, type, count) const type *name;
+    RS_TABLES(X)
+#undef X
+    const int32_t *obs_sig;     // observed lane -> signal index (derived)
+    int32_t n_lanes, n_links, n_edges, n_routes, n_trips, n_signals, n_obs, n_vtypes;
+    int32_t horizon, capacity, step_length, yellow_length, lmax, n_arr;
+};
+
+struct State {      // env-major SoA in HBM
+    float *pos, *speed, *accel, *tloss;
+    uint16_t *lane, *trip, *cursor, *swait, *rwait, *depart;
+    uint8_t *owner;
+    int32_t *env;       // [N][4] t, next_trip, hw, reserved
+    int32_t *tls;       // [N][S][3] phase, left, next_phase
+    long long *stats;   // [N][10]
+};
+
+struct Out {
+    float *lane_agg, *drq_norm, *wait, *wait_norm;
+    int32_t *phase, *mplight, *wave, *pressure, *queue_sum, *queue_max;
+    __half *drq_f16;
+};
+
+struct KParams {
+    uint32_t seed;
+    int32_t env_base;
+    float max_distance, sigma;
+    int32_t speed_dev, fixed_program;
+    int32_t n_ticks;        // ticks to simulate in this launch (0: observe only)
+    int32_t do_fsm;         // apply prep_phase / set_phase around the ticks
+    int32_t n_envs;
+};
+
+// ------------------------------------------------------------------------------------------------ device math
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t d_hash(uint32_t seed, uint32_t env, uint32_t trip, uint32_t tick, uint32_t stream) {
+    uint32_t h = seed;
+    uint32_t w[4] = {env, trip, tick, stream};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t k = w[i];
+        k *= 0xcc9e2d51u; k = rotl32(k, 15); k *= 0x1b873593u;
+        h ^= k; h = rotl32(h, 13); h = h * 5u + 0xe6546b64u;
+    }
+    h ^= 16u;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float d_u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+// Krauss (SUMO MSCFModel, Euler update, dt = 1 s) [SUMO-K]
+__device__ __forceinline__ float d_brake_gap(float v, float b) {
+    int steps = (int)(v / b);
+    float fs = (float)steps;
+    return fs * v - b * fs * (fs + 1.0f) * 0.5f;
+}
+__device__ __forceinline__ float d_stop_speed(float gap, float b, float tau) {
+    float g = gap - 0.001f;
+    if (g < 0.0f) return 0.0f;
+    float q = 1.0f + 4.0f * ((2.0f * g / b - tau) + tau * tau);
+    float n = floorf(0.5f - (tau + sqrtf(q) * -0.5f));
+    float h = 0.5f * n * (n - 1.0f) * b + n * b * tau;
+    float r = (g - h) / (n + tau);
+    return n * b + r;
+}
+__device__ __forceinline__ float d_follow_speed(float gap, float vl, float b, float bl, float tau) {
+    float bm = b > bl ? b : bl;
+    return d_stop_speed(gap + d_brake_gap(vl, bm), b, tau);
+}
+
+// ------------------------------------------------------------------------------------------------ LDS view
+struct Lds {
+    float *pos, *speed, *vnx, *sf, *tloss, *vtp;
+    uint16_t *lane, *nxt, *trip, *cursor, *swait, *route;
+    uint8_t *vt;
+    int32_t *head, *arr;
+    int32_t *agg_q, *agg_a, *agg_w, *agg_m;
+    uint32_t *agg_s;
+    int32_t *phase, *left, *nextp;
+    int32_t *sc;        // scalars: 0 t, 1 next_trip, 2 hw, 3 hw_new, 4.. stats
+};
+#define SC_T 0
+#define SC_NEXT 1
+#define SC_HW 2
+#define SC_HWNEW 3
+#define SC_STATS 4
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t lds_bytes_for(int C, int n_lanes, int n_arr, int n_obs, int S, int n_vt) {
+    size_t o = 0;
+    o += align16((size_t)C * 4) * 5;                 // pos speed vnx sf tloss
+    o += align16((size_t)n_vt * VT_COLS * 4);        // vtype table
+    o += align16((size_t)C * 2) * 6;                 // lane nxt trip cursor swait route
+    o += align16((size_t)C);                         // vt
+    o += align16((size_t)n_lanes * 4);               // head
+    o += align16((size_t)n_arr * 4);                 // arr
+    o += align16((size_t)n_obs * 4) * 5;             // aggregates
+    o += align16((size_t)S * 4) * 3;                 // tls
+    o += align16((size_t)(SC_STATS + ST_N) * 4);
+    return o;
+}
+__device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_lanes, int n_arr, int n_obs, int S, int n_vt) {
+    size_t o = 0;
+#define CARVE(field, type, bytes) L.field = (type *)(base + o); o += align16(bytes);
+    CARVE(pos, float, (size_t)C * 4) CARVE(speed, float, (size_t)C * 4) CARVE(vnx, float, (size_t)C * 4)
+    CARVE(sf, float, (size_t)C * 4) CARVE(tloss, float, (size_t)C * 4)
+    CARVE(vtp, float, (size_t)n_vt * VT_COLS * 4)
+    CARVE(lane, uint16_t, (size_t)C * 2) CARVE(nxt, uint16_t, (size_t)C * 2) CARVE(trip, uint16_t, (size_t)C * 2)
+    CARVE(cursor, uint16_t, (size_t)C * 2) CARVE(swait, uint16_t, (size_t)C * 2) CARVE(route, uint16_t, (size_t)C * 2)
+    CARVE(vt, uint8_t, (size_t)C)
+    CARVE(head, int32_t, (size_t)n_lanes * 4) CARVE(arr, int32_t, (size_t)n_arr * 4)
+    CARVE(agg_q, int32_t, (size_t)n_obs * 4) CARVE(agg_a, int32_t, (size_t)n_obs * 4)
+    CARVE(agg_w, int32_t, (size_t)n_obs * 4) CARVE(agg_m, int32_t, (size_t)n_obs * 4)
+    CARVE(agg_s, uint32_t, (size_t)n_obs * 4)
+    CARVE(phase, int32_t, (size_t)S * 4) CARVE(left, int32_t, (size_t)S * 4) CARVE(nextp, int32_t, (size_t)S * 4)
+    CARVE(sc, int32_t, (size_t)(SC_STATS + ST_N) * 4)
+#undef CARVE
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
+
+__device__ __forceinline__ float speed_factor(const Tab &T, const KParams &P, int env, int trip, const float *vt) {
+    if (!P.speed_dev) return vt[VT_SF_MEAN];
+    float s = 0.0f;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) s += d_u01(d_hash(P.seed, (uint32_t)env, (uint32_t)trip, 0xFFFFFFFFu, i));
+    float z = (s - 2.0f) * 1.7320508f;
+    float f = vt[VT_SF_MEAN] + vt[VT_SF_DEV] * z;
+    if (f < 0.2f) f = 0.2f;
+    if (f > 2.0f) f = 2.0f;
+    return f;
+}
+
+__device__ __forceinline__ int choose_link(const Tab &T, int lane, int route, int cursor) {
+    int ls = T.lane_link_start[lane], lc = T.lane_link_cnt[lane];
+    if (lc == 0) return -1;
+    if (T.lane_internal[lane]) return ls;
+    int rs = T.route_start[route], rn = T.route_start[route + 1] - rs;
+    if (cursor + 1 >= rn) return -1;
+    int ne = T.route_edge[rs + cursor + 1];
+    uint32_t pref = T.route_mask2[rs + cursor + 1], okm = T.route_mask1[rs + cursor + 1];
+    int l0 = T.edge_lane0[ne];
+    int best = -1, any = -1;
+    for (int l = ls; l < ls + lc; ++l) {
+        if (T.link_to_edge[l] != ne) continue;
+        int k = T.link_dest_lane[l] - l0;
+        if ((pref >> k) & 1u) return l;
+        if (best < 0 && ((okm >> k) & 1u)) best = l;
+        if (any < 0) any = l;
+    }
+    return best >= 0 ? best : any;
+}
+
+__device__ __forceinline__ int tls_state(const Tab &T, const Lds &L, const KParams &P, int link) {
+    int s = T.link_tls[link];
+    if (s < 0) return TLS_G;
+    if (P.fixed_program) return T.fix_states[T.fix_state_off[s] + L.phase[s] * T.tls_nlinks[s] + T.link_tls_pos[link]];
+    return T.tls_states[T.tls_state_off[s] + L.phase[s] * T.tls_nlinks[s] + T.link_tls_pos[link]];
+}
+
+__device__ __forceinline__ int depart_lane(const Tab &T, int route) {
+    int rs = T.route_start[route];
+    uint32_t m = T.route_mask2[rs];
+    int e = T.route_edge[rs];
+    int k = 0;
+    while (k < 31 && !((m >> k) & 1u)) k += 1;
+    if (k >= T.edge_nlanes[e]) k = 0;
+    return T.edge_lane0[e] + k;
+}
+
+__device__ __forceinline__ int rearmost(const Lds &L, int lane) {
+    int best = NIL, bk = 0;
+    float bp = 0.0f;
+    for (int s = L.head[lane]; s != NIL; s = L.nxt[s]) {
+        int k = L.trip[s];
+        float p = L.pos[s];
+        if (best == NIL || p < bp || (p == bp && k > bk)) { best = s; bk = k; bp = p; }
+    }
+    return best;
+}
+
+__device__ __forceinline__ void neighbours(const Lds &L, int lane, float pos, int k, int self, int &lead, int &foll) {
+    int Ld = NIL, Fd = NIL, Lk = 0, Fk = 0;
+    float Lp = 0.0f, Fp = 0.0f;
+    for (int s = L.head[lane]; s != NIL; s = L.nxt[s]) {
+        if (s == self) continue;
+        int ks = L.trip[s];
+        float ps = L.pos[s];
+        if (ahead_of(ps, ks, pos, k)) {
+            if (Ld == NIL || ahead_of(Lp, Lk, ps, ks)) { Ld = s; Lk = ks; Lp = ps; }
+        } else {
+            if (Fd == NIL || ahead_of(ps, ks, Fp, Fk)) { Fd = s; Fk = ks; Fp = ps; }
+        }
+    }
+    lead = Ld; foll = Fd;
+}
+
+__device__ __forceinline__ bool lane_has_mover(const Lds &L, int lane) {
+    for (int s = L.head[lane]; s != NIL; s = L.nxt[s])
+        if (L.speed[s] > HALT_SPEED) return true;
+    return false;
+}
+
+__device__ __forceinline__ bool foe_blocked(const Tab &T, const Lds &L, const KParams &P, int link) {
+    int fs = T.link_foe_start[link], fc = T.link_foe_cnt[link];
+    for (int i = fs; i < fs + fc; ++i) {
+        int f = T.foe_link[i];
+        if (T.link_tls[f] >= 0 && tls_state(T, L, P, f) == TLS_R) continue;
+        if (L.arr[f] < FOE_GAP_Q) return true;
+        int v1 = T.link_via1[f], v2 = T.link_via2[f];
+        if (v1 >= 0 && lane_has_mover(L, v1)) return true;
+        if (v2 >= 0 && lane_has_mover(L, v2)) return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void set_phase(const Tab &T, Lds &L, int s, int ph) {
+    if (ph < 0 || ph >= T.tls_nphase[s]) return;
+    L.phase[s] = ph;
+    L.left[s] = T.tls_dur[T.tls_dur_off[s] + ph];
+}
+
+// ------------------------------------------------------------------------------------------------ the step kernel
+// grid = n_envs workgroups; blockDim.x = 64 * waves.  Dynamic LDS = lds_bytes_for(...).
+extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int env = blockIdx.x;
+    if (env >= P.n_envs) return;
+    const int tid = threadIdx.x, B = blockDim.x;
+    const int C = T.capacity, S = T.n_signals, NO = T.n_obs;
+    const int genv = P.env_base + env;
+    Lds L;
+    lds_carve(L, smem, C, T.n_lanes, T.n_arr, NO, S, T.n_vtypes);
+    const size_t eo = (size_t)env * C;
+
+    // ---- load the environment slab (once per env-step)
+    if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 3 ? G.env[env * 4 + tid] : 0;
+    for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.vtype_params[i];
+    for (int i = tid; i < T.n_lanes; i += B) L.head[i] = NIL;
+    for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
+    for (int i = tid; i < S; i += B) {
+        L.phase[i] = G.tls[(env * S + i) * 3 + 0];
+        L.left[i] = G.tls[(env * S + i) * 3 + 1];
+        L.nextp[i] = G.tls[(env * S + i) * 3 + 2];
+    }
+    __syncthreads();
+    {
+        const int hw0 = L.sc[SC_HW];
+        for (int s = tid; s < C; s += B) {
+            uint16_t ln = LANE_NONE, tr = 0xFFFF;
+            if (s < hw0) { ln = G.lane[eo + s]; tr = G.trip[eo + s]; }
+            L.lane[s] = ln; L.trip[s] = tr;
+            if (ln != LANE_NONE) {
+                L.pos[s] = G.pos[eo + s]; L.speed[s] = G.speed[eo + s]; L.tloss[s] = G.tloss[eo + s];
+                L.cursor[s] = G.cursor[eo + s]; L.swait[s] = G.swait[eo + s];
+                int v = T.trip_vtype[tr];
+                L.vt[s] = (uint8_t)v; L.route[s] = (uint16_t)T.trip_route[tr];
+                L.sf[s] = speed_factor(T, P, genv, tr, T.vtype_params + v * VT_COLS);
+            }
+        }
+    }
+    // ---- Signal.prep_phase for every signal (traffic_signal.py:176-184)
+    if (P.do_fsm && !P.fixed_program) {
+        for (int s = tid; s < S; s += B) {
+            int a = actions[env * S + s], cur = L.phase[s], Gn = T.tls_ngreen[s];
+            if (a < 0 || a >= T.tls_nphase[s]) { L.nextp[s] = cur; continue; }
+            L.nextp[s] = a;
+            if (cur != a && cur < Gn && a < Gn) {
+                int y = T.tls_yellow[T.tls_yel_off[s] + cur * Gn + a];
+                if (y >= 0) set_phase(T, L, s, y);
+            }
+        }
+    }
+    __syncthreads();
+    // lists for the state we loaded
+    for (int s = tid; s < L.sc[SC_HW]; s += B) {
+        int ln = L.lane[s];
+        if (ln < LANE_PENDING) L.nxt[s] = (uint16_t)atomicExch(&L.head[ln], s);
+    }
+    __syncthreads();
+
+    for (int tick = 0; tick < P.n_ticks; ++tick) {
+        const int t = L.sc[SC_T];
+        // ---- Signal.set_phase after the yellow ticks (traffic_signal.py:186-187)
+        if (P.do_fsm && !P.fixed_program && tick == T.yellow_length) {
+            for (int s = tid; s < S; s += B) set_phase(T, L, s, L.nextp[s]);
+            __syncthreads();
+        }
+        // ---- P0: TLS switch events at the beginning of the tick
+        for (int s = tid; s < S; s += B) {
+            const int32_t *dur = P.fixed_program ? T.fix_dur + T.fix_dur_off[s] : T.tls_dur + T.tls_dur_off[s];
+            int Pn = P.fixed_program ? T.fix_nphase[s] : T.tls_nphase[s];
+            int left = L.left[s], ph = L.phase[s];
+            if (left == 0) { ph = (ph + 1) % Pn; left = dur[ph]; L.phase[s] = ph; }
+            L.left[s] = left - 1;
+        }
+        // ---- P2a: departed trips take the lowest free slots in trip order (wave 0 only)
+        {
+            int hz = t - 1 <= T.horizon ? t - 1 : T.horizon;
+            int due = t >= 1 ? T.trips_cum[hz] : 0;
+            int nt = L.sc[SC_NEXT];
+            int m = due - nt;
+            if (m > 0 && tid < 64) {
+                int base = 0;
+                for (int c0 = 0; c0 < C && base < m; c0 += 64) {
+                    int s = c0 + tid;
+                    bool fr = L.lane[s] == LANE_NONE;
+                    unsigned long long mask = __ballot(fr);
+                    int rank = __popcll(mask & ((1ull << tid) - 1ull));
+                    if (fr && base + rank < m) {
+                        int k = nt + base + rank;
+                        int v = T.trip_vtype[k];
+                        L.trip[s] = (uint16_t)k; L.lane[s] = LANE_PENDING;
+                        L.pos[s] = 0.0f; L.speed[s] = 0.0f; L.tloss[s] = 0.0f; L.cursor[s] = 0; L.swait[s] = 0;
+                        L.vt[s] = (uint8_t)v; L.route[s] = (uint16_t)T.trip_route[k];
+                        L.sf[s] = speed_factor(T, P, genv, k, T.vtype_params + v * VT_COLS);
+                        G.rwait[eo + s] = 0; G.owner[eo + s] = OWNER_NONE; G.depart[eo + s] = 0; G.accel[eo + s] = 0.0f;
+                        atomicMax(&L.sc[SC_HW], s + 1);
+                    }
+                    base += __popcll(mask);
+                }
+                if (tid == 0) L.sc[SC_NEXT] = nt + (base < m ? base : m);
+            }
+        }
+        __syncthreads();
+        const int hw = L.sc[SC_HW];
+        // ---- P2b: lowest pending trip per departure lane is the insertion candidate
+        for (int s = tid; s < hw; s += B)
+            if (L.lane[s] == LANE_PENDING) atomicMin(&L.arr[depart_lane(T, L.route[s])], (int)L.trip[s]);
+        __syncthreads();
+        // ---- P2c: candidates check the space on their lane
+        for (int s = tid; s < hw; s += B) {
+            if (L.lane[s] != LANE_PENDING) continue;
+            int k = L.trip[s];
+            int dl = depart_lane(T, L.route[s]);
+            bool ins = false;
+            float mypos = 0.0f;
+            if (L.arr[dl] == k) {
+                const float *vt = L.vtp + L.vt[s] * VT_COLS;
+                float ll = T.lane_len[dl];
+                mypos = vt[VT_LENGTH] < ll ? vt[VT_LENGTH] : ll;
+                ins = true;
+                for (int o = L.head[dl]; o != NIL; o = L.nxt[o]) {
+                    float back = L.pos[o] - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
+                    if (back - mypos - vt[VT_MINGAP] < 0.0f) ins = false;
+                }
+            }
+            L.vnx[s] = ins ? mypos : -1.0f;
+        }
+        __syncthreads();
+        // ---- P2d: apply insertions, reset the candidate table
+        for (int s = tid; s < hw; s += B) {
+            if (L.lane[s] != LANE_PENDING) continue;
+            int dl = depart_lane(T, L.route[s]);
+            L.arr[dl] = ARR_NONE;
+            if (L.vnx[s] < 0.0f) continue;
+            L.lane[s] = (uint16_t)dl; L.pos[s] = L.vnx[s]; L.speed[s] = 0.0f; L.cursor[s] = 0;
+            G.depart[eo + s] = (uint16_t)t;
+            L.nxt[s] = (uint16_t)atomicExch(&L.head[dl], s);
+            atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
+            atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.trip_depart[L.trip[s]]);
+        }
+        __syncthreads();
+        // ---- P3: vehicles that will pass their next link register an arrival-time estimate on it
+        for (int s = tid; s < hw; s += B) {
+            int lane = L.lane[s];
+            if (lane >= LANE_PENDING) continue;
+            int link = choose_link(T, lane, L.route[s], L.cursor[s]);
+            if (link < 0) continue;
+            float v = L.speed[s];
+            if (v <= HALT_SPEED) continue;
+            int st = tls_state(T, L, P, link);
+            if (st == TLS_R) continue;
+            float dist = T.lane_len[lane] - L.pos[s];
+            if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) continue;
+            float ta = dist / (v > 1.0f ? v : 1.0f);
+            int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
+            atomicMin(&L.arr[link], q);
+        }
+        __syncthreads();
+        // ---- P4: plan (Krauss car-following + links)
+        for (int s = tid; s < hw; s += B) {
+            int lane = L.lane[s];
+            if (lane >= LANE_PENDING) continue;
+            const int k = L.trip[s];
+            const float *vt = L.vtp + L.vt[s] * VT_COLS;
+            const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
+            const int route = L.route[s], cursor = L.cursor[s];
+            const float v = L.speed[s], x = L.pos[s];
+            float vfree = v + a;
+            float vl = T.lane_vmax[lane] * L.sf[s];
+            if (vl < vfree) vfree = vl;
+            if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
+            float vsafe = BIGF;
+            int lead, foll;
+            neighbours(L, lane, x, k, s, lead, foll);
+            bool found = false;
+            if (lead != NIL) {
+                const float *vo = L.vtp + L.vt[lead] * VT_COLS;
+                float gap = L.pos[lead] - vo[VT_LENGTH] - x - mingap;
+                vsafe = d_follow_speed(gap, L.speed[lead], b, vo[VT_DECEL], tau);
+                found = true;
+            }
+            float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
+            float seen = T.lane_len[lane] - x;
+            int cur = lane, cur_cursor = cursor;
+            const int rn = T.route_start[route + 1] - T.route_start[route];
+            for (int hop = 0; hop < MAX_HOPS && !found && seen < look; ++hop) {
+                const bool cur_int = T.lane_internal[cur] != 0;
+                if (!cur_int && cur_cursor + 1 >= rn) break;
+                int link = choose_link(T, cur, route, cur_cursor);
+                if (link < 0) {
+                    float g = seen - STOP_OFFSET;
+                    float vs = d_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
+                    if (vs < vsafe) vsafe = vs;
+                    break;
+                }
+                int st = tls_state(T, L, P, link);
+                const int ltls = T.link_tls[link];
+                bool stop_here = false;
+                if (ltls >= 0 && (st == TLS_R || st == TLS_Y)) {
+                    if (seen >= d_brake_gap(v, b)) stop_here = true;
+                }
+                if (!stop_here && !T.link_cont[link] && T.link_foe_cnt[link] > 0 &&
+                    (T.link_minor[link] || (ltls >= 0 && st == TLS_g))) {
+                    if (foe_blocked(T, L, P, link)) stop_here = true;
+                }
+                if (stop_here) {
+                    float g = seen - STOP_OFFSET;
+                    float vs = d_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
+                    if (vs < vsafe) vsafe = vs;
+                    break;
+                }
+                int nl = T.link_to_lane[link];
+                int o = rearmost(L, nl);
+                if (o != NIL) {
+                    const float *vo = L.vtp + L.vt[o] * VT_COLS;
+                    float gap = seen + L.pos[o] - vo[VT_LENGTH] - mingap;
+                    float vs = d_follow_speed(gap, L.speed[o], b, vo[VT_DECEL], tau);
+                    if (vs < vsafe) vsafe = vs;
+                    found = true;
+                    break;
+                }
+                if (!cur_int) cur_cursor += 1;
+                seen += T.lane_len[nl];
+                cur = nl;
+            }
+            float vmin_n = v - b; if (vmin_n < 0.0f) vmin_n = 0.0f;
+            float vmin_e = v - vt[VT_EMERGENCY]; if (vmin_e < 0.0f) vmin_e = 0.0f;
+            float lo = vsafe > vmin_e ? vsafe : vmin_e;
+            float vmin = vmin_n < lo ? vmin_n : lo;
+            float vmax = vfree < vsafe ? vfree : vsafe;
+            if (vmax < vmin) vmax = vmin;
+            float sigma = P.sigma >= 0.0f ? P.sigma : vt[VT_SIGMA];
+            float vd = vmax;
+            if (sigma > 0.0f) {
+                float r = d_u01(d_hash(P.seed, (uint32_t)genv, (uint32_t)k, (uint32_t)t, 0u));
+                if (vd < a) vd -= sigma * vd * r; else vd -= sigma * a * r;
+                if (vd < 0.0f) vd = 0.0f;
+            }
+            L.vnx[s] = vd > vmin ? vd : vmin;
+        }
+        __syncthreads();
+        // ---- P5: move (and drop this tick's approach registrations, clear the list heads)
+        if (tid == 0) L.sc[SC_HWNEW] = 0;
+        for (int s = tid; s < hw; s += B) {
+            int lane = L.lane[s];
+            if (lane >= LANE_PENDING) continue;
+            int lk = choose_link(T, lane, L.route[s], L.cursor[s]);
+            if (lk >= 0) L.arr[lk] = ARR_NONE;
+        }
+        for (int i = tid; i < T.n_lanes; i += B) L.head[i] = NIL;
+        __syncthreads();
+        {
+            int active = 0, halted = 0;
+            for (int s = tid; s < hw; s += B) {
+                int lane = L.lane[s];
+                if (lane == LANE_NONE) continue;
+                if (lane == LANE_PENDING) { atomicMax(&L.sc[SC_HWNEW], s + 1); continue; }
+                const int route = L.route[s];
+                const int rn = T.route_start[route + 1] - T.route_start[route];
+                const float vn = L.vnx[s];
+                const float vref = T.lane_vmax[lane] * L.sf[s];
+                if (tick == P.n_ticks - 1) G.accel[eo + s] = vn - L.speed[s];
+                L.speed[s] = vn;
+                if (vn <= HALT_SPEED) { int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1); halted += 1; }
+                else L.swait[s] = 0;
+                if (vref > 0.0f && vn < vref) L.tloss[s] += (vref - vn) / vref;
+                float x = L.pos[s] + vn;
+                int cursor = L.cursor[s];
+                bool arrived = false;
+                for (int it = 0; it < 16; ++it) {
+                    float len = T.lane_len[lane];
+                    if (!(x > len)) break;
+                    const bool li = T.lane_internal[lane] != 0;
+                    if (!li && cursor + 1 >= rn) { arrived = true; break; }
+                    int link = choose_link(T, lane, route, cursor);
+                    if (link < 0) { x = len; break; }
+                    x -= len;
+                    if (!li) cursor += 1;
+                    lane = T.link_to_lane[link];
+                }
+                if (arrived) {
+                    L.lane[s] = LANE_NONE; L.trip[s] = 0xFFFF;
+                    G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0;
+                    atomicAdd(&L.sc[SC_STATS + ST_ARRIVED], 1);
+                    atomicAdd(&L.sc[SC_STATS + ST_DURATION], t + 1 - (int)G.depart[eo + s]);
+                    atomicAdd(&L.sc[SC_STATS + ST_TLOSS], (int)(L.tloss[s] * 1024.0f + 0.5f));
+                } else {
+                    L.lane[s] = (uint16_t)lane; L.cursor[s] = (uint16_t)cursor; L.pos[s] = x;
+                    active += 1;
+                    atomicMax(&L.sc[SC_HWNEW], s + 1);
+                }
+            }
+            if (active) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
+            if (halted) atomicAdd(&L.sc[SC_STATS + ST_WAITING], halted);
+        }
+        __syncthreads();
+        // ---- P6: lists of the moved state
+        const int hw2 = L.sc[SC_HWNEW];
+        for (int s = tid; s < hw2; s += B) {
+            int ln = L.lane[s];
+            if (ln < LANE_PENDING) L.nxt[s] = (uint16_t)atomicExch(&L.head[ln], s);
+        }
+        __syncthreads();
+        // ---- P7a: lane-change decisions (all changes of a tick go the same way: left on even ticks)
+        const int dir_allowed = (t & 1) ? -1 : +1;
+        for (int s = tid; s < hw2; s += B) {
+            int target = -1;
+            int lane = L.lane[s];
+            if (lane < LANE_PENDING && !T.lane_internal[lane]) {
+                const int ed = T.lane_edge[lane];
+                const int n = T.edge_nlanes[ed];
+                const int l0 = T.edge_lane0[ed];
+                const int kk = lane - l0;
+                const int tk = kk + dir_allowed;
+                if (n >= 2 && tk >= 0 && tk < n) {
+                    const int k = L.trip[s];
+                    const uint32_t m2 = T.route_mask2[T.route_start[L.route[s]] + L.cursor[s]];
+                    const float *vt = L.vtp + L.vt[s] * VT_COLS;
+                    const float x = L.pos[s], v = L.speed[s];
+                    const int tl = l0 + tk;
+                    int want = 0;
+                    int lead_t, foll_t;
+                    neighbours(L, tl, x, k, s, lead_t, foll_t);
+                    if (!((m2 >> kk) & 1u)) {
+                        int dl = 1000, dr = 1000;
+                        for (int j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
+                        for (int j = kk - 1; j >= 0; --j) if ((m2 >> j) & 1u) { dr = kk - j; break; }
+                        int dir = 0;
+                        if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
+                        want = (dir == dir_allowed) ? 2 : 0;
+                    } else if ((m2 >> tk) & 1u) {
+                        int lead_c, foll_c;
+                        neighbours(L, lane, x, k, s, lead_c, foll_c);
+                        if (lead_c != NIL) {
+                            float gcur = L.pos[lead_c] - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
+                            float gtgt = BIGF;
+                            if (lead_t != NIL) gtgt = L.pos[lead_t] - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
+                            if (gcur < v * 3.0f + 15.0f && gtgt > gcur + SG_ADVANTAGE) want = 1;
+                        }
+                    }
+                    if (want) {
+                        const bool urgent = want == 2 && (T.lane_len[lane] - x) <= URGENT_DIST;
+                        bool safe = true;
+                        if (lead_t != NIL) {
+                            const float *vo = L.vtp + L.vt[lead_t] * VT_COLS;
+                            float gap = L.pos[lead_t] - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
+                            float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
+                            float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
+                            if (gap < 0.0f || vb > d_follow_speed(gap, L.speed[lead_t], vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
+                        }
+                        if (safe && foll_t != NIL) {
+                            const float *vo = L.vtp + L.vt[foll_t] * VT_COLS;
+                            float gap = x - vt[VT_LENGTH] - L.pos[foll_t] - (urgent ? 0.0f : vo[VT_MINGAP]);
+                            float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
+                            float vb = L.speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
+                            if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
+                        }
+                        if (safe) target = tl;
+                    }
+                }
+            }
+            L.vnx[s] = __int_as_float(target);
+        }
+        __syncthreads();
+        // ---- P7b: apply the lane changes, rebuild the lists for the next tick
+        for (int i = tid; i < T.n_lanes; i += B) L.head[i] = NIL;
+        for (int s = tid; s < hw2; s += B) {
+            int target = __float_as_int(L.vnx[s]);
+            if (L.lane[s] < LANE_PENDING && target >= 0) L.lane[s] = (uint16_t)target;
+        }
+        if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
+        __syncthreads();
+        for (int s = tid; s < hw2; s += B) {
+            int ln = L.lane[s];
+            if (ln < LANE_PENDING) L.nxt[s] = (uint16_t)atomicExch(&L.head[ln], s);
+        }
+        __syncthreads();
+    }
+
+    // ---- Signal.observe for every signal (traffic_signal.py:189-247)
+    for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
+    __syncthreads();
+    const int hwf = L.sc[SC_HW];
+    for (int s = tid; s < hwf; s += B) {
+        int lane = L.lane[s];
+        if (lane >= LANE_PENDING) continue;
+        int oi = T.lane_obs[lane];
+        bool detect = false;
+        if (oi >= 0) {
+            float d = (T.lane_len[lane] - L.pos[s]) + T.route_tlsdist[T.route_start[L.route[s]] + L.cursor[s]];
+            detect = d <= P.max_distance;
+        }
+        if (!detect) { G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0; continue; }
+        int sig = T.obs_sig[oi];
+        int rw = G.rwait[eo + s];
+        if (G.owner[eo + s] != (uint8_t)sig) rw = 0;
+        if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
+        else if (L.swait[s] > 0) rw = L.swait[s];
+        G.rwait[eo + s] = (uint16_t)rw;
+        G.owner[eo + s] = (uint8_t)sig;
+        if (rw > 0) { atomicAdd(&L.agg_q[oi], 1); atomicAdd(&L.agg_w[oi], rw); atomicMax(&L.agg_m[oi], rw); }
+        else atomicAdd(&L.agg_a[oi], 1);
+        atomicAdd(&L.agg_s[oi], (uint32_t)(L.speed[s] * 65536.0f + 0.5f));
+    }
+    __syncthreads();
+    // per observed lane rows
+    for (int oi = tid; oi < NO; oi += B) {
+        int sg = T.obs_sig[oi];
+        int o0 = T.sig_obs_start[sg];
+        int ph = L.phase[sg];
+        float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
+        float q = (float)L.agg_q[oi], ap = (float)L.agg_a[oi], w = (float)L.agg_w[oi];
+        float *la = O.lane_agg + ((size_t)env * NO + oi) * 5;
+        la[0] = q; la[1] = ap; la[2] = w; la[3] = (float)L.agg_m[oi]; la[4] = sp;
+        float d0 = (oi - o0) == ph ? 1.0f : 0.0f, d1 = ap / 28.0f, d2 = w / 28.0f, d3 = q / 28.0f, d4 = sp / 20.0f / 28.0f;
+        float *dn = O.drq_norm + ((size_t)env * NO + oi) * 5;
+        dn[0] = d0; dn[1] = d1; dn[2] = d2; dn[3] = d3; dn[4] = d4;
+        __half *dh = O.drq_f16 + (((size_t)env * S + sg) * T.lmax + (oi - o0)) * 5;
+        dh[0] = __float2half(d0); dh[1] = __float2half(d1); dh[2] = __float2half(d2); dh[3] = __float2half(d3); dh[4] = __float2half(d4);
+    }
+    // per signal: state vectors and rewards
+    for (int sg = tid; sg < S; sg += B) {
+        int ph = L.phase[sg];
+        int o0 = T.sig_obs_start[sg], o1 = T.sig_obs_start[sg + 1];
+        int tw = 0, tq = 0, mq = 0;
+        for (int oi = o0; oi < o1; ++oi) { tw += L.agg_w[oi]; int qq = L.agg_q[oi]; tq += qq; if (qq > mq) mq = qq; }
+        size_t so = (size_t)env * S + sg;
+        O.phase[so] = ph; O.queue_sum[so] = tq; O.queue_max[so] = mq;
+        O.wait[so] = -(float)tw;
+        float wn = -(float)tw / 224.0f;
+        O.wait_norm[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
+        int pr = tq;
+        for (int i = T.pr_out_start[sg]; i < T.pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.pr_out_idx[i]];
+        O.pressure[so] = -pr;
+        O.mplight[so * 13] = ph;
+        for (int m = 0; m < 12; ++m) {
+            int q = 0, wv = 0;
+            for (int i = T.mv_in_start[sg * 12 + m]; i < T.mv_in_start[sg * 12 + m + 1]; ++i) {
+                int oi = T.mv_in_idx[i];
+                q += L.agg_q[oi]; wv += L.agg_q[oi] + L.agg_a[oi];
+            }
+            for (int i = T.mv_out_start[sg * 12 + m]; i < T.mv_out_start[sg * 12 + m + 1]; ++i) q -= L.agg_q[T.mv_out_idx[i]];
+            O.mplight[so * 13 + 1 + m] = q;
+            O.wave[so * 12 + m] = wv;
+        }
+        G.tls[(env * S + sg) * 3 + 0] = ph;
+        G.tls[(env * S + sg) * 3 + 1] = L.left[sg];
+        G.tls[(env * S + sg) * 3 + 2] = L.nextp[sg];
+    }
+    // ---- store the slab back
+    {
+        const int hw0 = G.env[env * 4 + 2];
+        const int top = hwf > hw0 ? hwf : hw0;
+        int act = 0, pend = 0;
+        for (int s = tid; s < top; s += B) {
+            uint16_t ln = L.lane[s];
+            G.lane[eo + s] = ln; G.trip[eo + s] = L.trip[s];
+            if (ln != LANE_NONE) {
+                G.pos[eo + s] = L.pos[s]; G.speed[eo + s] = L.speed[s]; G.tloss[eo + s] = L.tloss[s];
+                G.cursor[eo + s] = L.cursor[s]; G.swait[eo + s] = L.swait[s];
+                if (ln == LANE_PENDING) pend += 1; else act += 1;
+            }
+        }
+        if (act) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE], act);
+        if (pend) atomicAdd(&L.sc[SC_STATS + ST_PENDING], pend);
+    }
+    __syncthreads();
+    if (tid < 3) G.env[env * 4 + tid] = L.sc[tid];
+    if (tid < ST_N) {
+        long long *st = G.stats + (size_t)env * ST_N;
+        if (tid == ST_ACTIVE || tid == ST_PENDING) st[tid] = L.sc[SC_STATS + tid];
+        else st[tid] += L.sc[SC_STATS + tid];
+    }
+}
+
+// reset every environment: no vehicles, TLS programs freshly installed (Signal.__init__, traffic_signal.py:93-100)
+extern "C" __global__ void rs_reset_kernel(Tab T, State G, KParams P) {
+    const int env = blockIdx.x;
+    const int C = T.capacity, S = T.n_signals;
+    const size_t eo = (size_t)env * C;
+    for (int s = threadIdx.x; s < C; s += blockDim.x) {
+        G.lane[eo + s] = LANE_NONE; G.trip[eo + s] = 0xFFFF; G.owner[eo + s] = OWNER_NONE;
+        G.rwait[eo + s] = 0; G.swait[eo + s] = 0; G.cursor[eo + s] = 0; G.depart[eo + s] = 0;
+        G.pos[eo + s] = 0.0f; G.speed[eo + s] = 0.0f; G.accel[eo + s] = 0.0f; G.tloss[eo + s] = 0.0f;
+    }
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        int ph, left;
+        if (P.fixed_program) { ph = T.fix_init_phase[s]; left = T.fix_init_left[s]; }
+        else { ph = T.tls_init_phase[s]; left = T.tls_dur[T.tls_dur_off[s] + ph]; }
+        G.tls[(env * S + s) * 3 + 0] = ph; G.tls[(env * S + s) * 3 + 1] = left; G.tls[(env * S + s) * 3 + 2] = 0;
+    }
+    if (threadIdx.x < 4) G.env[env * 4 + threadIdx.x] = 0;
+    if (threadIdx.x < ST_N) G.stats[(size_t)env * ST_N + threadIdx.x] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ static agents
+// STOCHASTIC (agents/stochastic.py:17-18): uniform green index per (env, signal, step)
+extern "C" __global__ void rs_act_random_kernel(Tab T, KParams P, uint32_t step_key, int32_t *actions) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int S = T.n_signals;
+    if (i >= P.n_envs * S) return;
+    int env = i / S, s = i - env * S;
+    uint32_t h = d_hash(P.seed ^ 0xA5A5A5A5u, (uint32_t)(P.env_base + env), (uint32_t)s, step_key, 7u);
+    actions[i] = (int32_t)(h % (uint32_t)T.tls_ngreen[s]);
+}
+// MAXWAVE / MAXPRESSURE (agents/maxwave.py:18-38, maxpressure.py:13-18): first maximum over the valid
+// phase pairs (in the reference's iteration order) of obs[pair0] + obs[pair1]
+extern "C" __global__ void rs_act_maxwave_kernel(Tab T, KParams P, const int32_t *pairs, int n_pairs,
+                                                 const int32_t *valid, const int32_t *order, int use_pressure,
+                                                 const int32_t *mplight, const int32_t *wave, int32_t *actions) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int S = T.n_signals;
+    if (i >= P.n_envs * S) return;
+    int s = i % S;
+    const int32_t *obs = use_pressure ? mplight + (size_t)i * 13 + 1 : wave + (size_t)i * 12;
+    bool have = false;
+    int best = 0, best_act = 0;
+    for (int j = 0; j < n_pairs; ++j) {
+        int p = order[s * n_pairs + j];     // the reference walks valid_acts in dict order; ties keep the first
+        if (p < 0) break;
+        int act = valid[s * n_pairs + p];
+        if (act < 0) continue;
+        int press = obs[pairs[p * 2]] + obs[pairs[p * 2 + 1]];
+        if (!have || press > best) { have = true; best = press; best_act = act; }
+    }
+    actions[i] = best_act;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct rs_sim {
+    int device = 0;
+    int n_envs = 0, env_base = 0, block = 256;
+    size_t lds = 0;
+    Tab T{};
+    State G{};
+    Out O{};
+    KParams P{};
+    int32_t *actions = nullptr;
+    int32_t *pairs = nullptr, *valid = nullptr, *order = nullptr;
+    int n_pairs = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    std::vector<int32_t> tls_ngreen;
+    struct Buf { void *ptr; int64_t shape[4]; int ndim; int dtype; size_t bytes; };
+    Buf bufs[RS_BUF_COUNT]{};
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_used = 0;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return RS_EHIP;                                                                        \
+        }                                                                                          \
+    } while (0)
+
+template <typename Tp>
+static int dev_alloc(rs_sim *h, Tp **p, size_t count, bool zero = true) {
+    void *d = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(Tp);
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return RS_ENOMEM; }
+    if (zero) (void)hipMemset(d, 0, bytes);
+    h->allocs.push_back(d);
+    *p = (Tp *)d;
+    return RS_OK;
+}
+template <typename Tp>
+static int dev_upload(rs_sim *h, const Tp **dst, const Tp *src, size_t count) {
+    Tp *d = nullptr;
+    int rc = dev_alloc(h, &d, count, false);
+    if (rc) return rc;
+    if (count) HIPCHK(h, hipMemcpy(d, src, count * sizeof(Tp), hipMemcpyHostToDevice));
+    *dst = d;
+    return RS_OK;
+}
+
+static const size_t kDtypeSize[] = {4, 4, 2, 1, 2, 8};
+static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_t a, int64_t b = 1, int64_t c = 1, int64_t d = 1) {
+    auto &B = h->bufs[which];
+    B.ptr = ptr; B.dtype = dtype; B.ndim = ndim;
+    B.shape[0] = a; B.shape[1] = b; B.shape[2] = c; B.shape[3] = d;
+    B.bytes = (size_t)(a * b * c * d) * kDtypeSize[dtype];
+}
+
+extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
+                         int32_t block_threads, rs_handle *out) {
+    if (!sc || !p || !out || n_envs <= 0) { g_create_err = "rs_create: bad argument"; return RS_EINVAL; }
+    rs_sim *h = new (std::nothrow) rs_sim();
+    if (!h) return RS_ENOMEM;
+    auto fail = [&](int rc) { g_create_err = h->err; rs_destroy(h); return rc; };
+    h->device = device_id; h->n_envs = n_envs; h->env_base = env_base;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { h->err = "no HIP device visible (this library has no CPU fallback)"; return fail(RS_EHIP); }
+    if (hipSetDevice(device_id) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(RS_EHIP); }
+    const int C = sc->capacity;
+    if (C < 64 || (C & (C - 1)) || C > 32768) { h->err = "capacity must be a power of two in [64, 32768]"; return fail(RS_ELIMIT); }
+    if (sc->n_lanes >= 0xFFFE || sc->n_trips >= 0xFFFF || sc->n_routes > 0xFFFF || sc->n_vtypes > 255 || sc->n_signals > 254) {
+        h->err = "scenario exceeds id widths (lanes/trips/routes u16, vtypes/signals u8)"; return fail(RS_ELIMIT);
+    }
+    Tab &T = h->T;
+    int rc;
+#define X(name, type, count)                                                                  \
+    if ((rc = dev_upload<type>(h, &T.name, sc->name, (size_t)(sc->count)))) return fail(rc);
+    RS_TABLES(X)
+#undef X
+    T.n_lanes = sc->n_lanes; T.n_links = sc->n_links; T.n_edges = sc->n_edges; T.n_routes = sc->n_routes;
+    T.n_trips = sc->n_trips; T.n_signals = sc->n_signals; T.n_obs = sc->n_obs; T.n_vtypes = sc->n_vtypes;
+    T.horizon = sc->horizon; T.capacity = C; T.step_length = sc->step_length; T.yellow_length = sc->yellow_length;
+    T.n_arr = sc->n_lanes > sc->n_links ? sc->n_lanes : sc->n_links;
+    std::vector<int32_t> obs_sig((size_t)sc->n_obs > 0 ? sc->n_obs : 1, 0);
+    int lmax = 1;
+    for (int s = 0; s < sc->n_signals; ++s) {
+        for (int oi = sc->sig_obs_start[s]; oi < sc->sig_obs_start[s + 1]; ++oi) obs_sig[oi] = s;
+        int n = sc->sig_obs_start[s + 1] - sc->sig_obs_start[s];
+        if (n > lmax) lmax = n;
+    }
+    T.lmax = lmax;
+    if ((rc = dev_upload<int32_t>(h, &T.obs_sig, obs_sig.data(), obs_sig.size()))) return fail(rc);
+    h->tls_ngreen.assign(sc->tls_ngreen, sc->tls_ngreen + sc->n_signals);
+
+    h->P.seed = p->seed; h->P.env_base = env_base; h->P.max_distance = p->max_distance; h->P.sigma = p->sigma;
+    h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.n_envs = n_envs;
+
+    const size_t N = (size_t)n_envs, NC = N * C, S = (size_t)sc->n_signals, NO = (size_t)sc->n_obs;
+    State &G = h->G;
+    Out &O = h->O;
+    if ((rc = dev_alloc(h, &G.pos, NC)) || (rc = dev_alloc(h, &G.speed, NC)) || (rc = dev_alloc(h, &G.accel, NC)) ||
+        (rc = dev_alloc(h, &G.tloss, NC)) || (rc = dev_alloc(h, &G.lane, NC)) || (rc = dev_alloc(h, &G.trip, NC)) ||
+        (rc = dev_alloc(h, &G.cursor, NC)) || (rc = dev_alloc(h, &G.swait, NC)) || (rc = dev_alloc(h, &G.rwait, NC)) ||
+        (rc = dev_alloc(h, &G.depart, NC)) || (rc = dev_alloc(h, &G.owner, NC)) || (rc = dev_alloc(h, &G.env, N * 4)) ||
+        (rc = dev_alloc(h, &G.tls, N * S * 3)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
+        (rc = dev_alloc(h, &O.lane_agg, N * NO * 5)) || (rc = dev_alloc(h, &O.drq_norm, N * NO * 5)) ||
+        (rc = dev_alloc(h, &O.wait, N * S)) || (rc = dev_alloc(h, &O.wait_norm, N * S)) ||
+        (rc = dev_alloc(h, &O.phase, N * S)) || (rc = dev_alloc(h, &O.mplight, N * S * 13)) ||
+        (rc = dev_alloc(h, &O.wave, N * S * 12)) || (rc = dev_alloc(h, &O.pressure, N * S)) ||
+        (rc = dev_alloc(h, &O.queue_sum, N * S)) || (rc = dev_alloc(h, &O.queue_max, N * S)) ||
+        (rc = dev_alloc(h, &O.drq_f16, N * S * lmax * 5)) || (rc = dev_alloc(h, &h->actions, N * S)))
+        return fail(rc);
+    const int64_t n = n_envs, c = C, s = sc->n_signals, o = sc->n_obs;
+    set_buf(h, RS_BUF_LANE_AGG, O.lane_agg, RS_F32, 3, n, o, 5);
+    set_buf(h, RS_BUF_DRQ_NORM, O.drq_norm, RS_F32, 3, n, o, 5);
+    set_buf(h, RS_BUF_PHASE, O.phase, RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_MPLIGHT, O.mplight, RS_I32, 3, n, s, 13);
+    set_buf(h, RS_BUF_WAVE, O.wave, RS_I32, 3, n, s, 12);
+    set_buf(h, RS_BUF_WAIT, O.wait, RS_F32, 2, n, s);
+    set_buf(h, RS_BUF_WAIT_NORM, O.wait_norm, RS_F32, 2, n, s);
+    set_buf(h, RS_BUF_PRESSURE, O.pressure, RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_QUEUE_SUM, O.queue_sum, RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_QUEUE_MAX, O.queue_max, RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_ACTIONS, h->actions, RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_ENV, G.env, RS_I32, 2, n, 4);
+    set_buf(h, RS_BUF_TLS, G.tls, RS_I32, 3, n, s, 3);
+    set_buf(h, RS_BUF_VEH_POS, G.pos, RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_SPEED, G.speed, RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_ACCEL, G.accel, RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_TLOSS, G.tloss, RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_LANE, G.lane, RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_TRIP, G.trip, RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_CURSOR, G.cursor, RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_SWAIT, G.swait, RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_RWAIT, G.rwait, RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_DEPART, G.depart, RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_OWNER, G.owner, RS_U8, 2, n, c);
+    set_buf(h, RS_BUF_STATS, G.stats, RS_I64, 2, n, ST_N);
+    set_buf(h, RS_BUF_DRQ_NORM_F16, O.drq_f16, RS_F16, 4, n, s, lmax, 5);
+
+    h->lds = lds_bytes_for(C, sc->n_lanes, T.n_arr, sc->n_obs, sc->n_signals, sc->n_vtypes);
+    if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
+    if (block_threads <= 0) {
+        block_threads = C >= 512 ? 256 : (C >= 128 ? 128 : 64);
+    }
+    if (block_threads % 64 || block_threads > 1024 || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024]"; return fail(RS_EINVAL); }
+    h->block = block_threads;
+    if (hipFuncSetAttribute((const void *)rs_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+        h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(RS_EHIP); }
+    *out = h;
+    int r2 = rs_reset(h, nullptr);
+    if (r2) { g_create_err = h->err; *out = nullptr; rs_destroy(h); return r2; }
+    return RS_OK;
+}
+
+extern "C" void rs_destroy(rs_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (auto &e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (void *p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" const char *rs_last_error(rs_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
+    KParams P = h->P;
+    P.n_ticks = n_ticks; P.do_fsm = do_fsm;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        if (h->ev_used == h->events.size()) {
+            hipEvent_t a, b;
+            HIPCHK(h, hipEventCreate(&a));
+            HIPCHK(h, hipEventCreate(&b));
+            h->events.emplace_back(a, b);
+        }
+        e0 = h->events[h->ev_used].first; e1 = h->events[h->ev_used].second;
+        h->ev_used += 1;
+        HIPCHK(h, hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL(rs_step_kernel, dim3(h->n_envs), dim3(h->block), h->lds, st, h->T, h->G, h->O, P, (const int32_t *)h->actions);
+    HIPCHK(h, hipGetLastError());
+    if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
+    return RS_OK;
+}
+
+extern "C" int rs_reset(rs_handle h, void *stream) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipLaunchKernelGGL(rs_reset_kernel, dim3(h->n_envs), dim3(256), 0, st, h->T, h->G, h->P);
+    HIPCHK(h, hipGetLastError());
+    bool tm = h->timing;
+    h->timing = false;
+    int rc = launch_step(h, st, 0, 0);
+    h->timing = tm;
+    return rc;
+}
+
+extern "C" int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_device, void *stream) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (actions) {
+        size_t bytes = (size_t)h->n_envs * h->T.n_signals * sizeof(int32_t);
+        HIPCHK(h, hipMemcpyAsync(h->actions, actions, bytes, actions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        // a pageable host source may be read after the call returns: make the caller's buffer reusable
+        if (!actions_on_device) HIPCHK(h, hipStreamSynchronize(st));
+    }
+    return launch_step(h, st, h->T.step_length, 1);
+}
+
+extern "C" int rs_sync(rs_handle h) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RS_OK;
+}
+
+extern "C" int rs_act_random(rs_handle h, uint32_t step_key, void *stream) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    int total = h->n_envs * h->T.n_signals;
+    hipLaunchKernelGGL(rs_act_random_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->T, h->P, step_key, h->actions);
+    HIPCHK(h, hipGetLastError());
+    return RS_OK;
+}
+
+extern "C" int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n_pairs, const int32_t *valid,
+                              const int32_t *order, int32_t use_pressure, void *stream) {
+    if (!h || n_pairs <= 0) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (!h->pairs) {
+        if (!phase_pairs || !valid || !order) { h->err = "rs_act_maxwave: tables required on first use"; return RS_EINVAL; }
+        int rc;
+        if ((rc = dev_alloc(h, &h->pairs, (size_t)n_pairs * 2, false)) || (rc = dev_alloc(h, &h->valid, (size_t)h->T.n_signals * n_pairs, false)) ||
+            (rc = dev_alloc(h, &h->order, (size_t)h->T.n_signals * n_pairs, false))) return rc;
+        HIPCHK(h, hipMemcpy(h->order, order, (size_t)h->T.n_signals * n_pairs * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->pairs, phase_pairs, (size_t)n_pairs * 2 * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->valid, valid, (size_t)h->T.n_signals * n_pairs * 4, hipMemcpyHostToDevice));
+        h->n_pairs = n_pairs;
+    }
+    int total = h->n_envs * h->T.n_signals;
+    hipLaunchKernelGGL(rs_act_maxwave_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->T, h->P, (const int32_t *)h->pairs,
+                       h->n_pairs, (const int32_t *)h->valid, (const int32_t *)h->order, (int)use_pressure, (const int32_t *)h->O.mplight,
+                       (const int32_t *)h->O.wave, h->actions);
+    HIPCHK(h, hipGetLastError());
+    return RS_OK;
+}
+
+extern "C" int rs_get_buffer(rs_handle h, int32_t which, void **dev_ptr, int64_t shape[4], int32_t *ndim, int32_t *dtype) {
+    if (!h || which < 0 || which >= RS_BUF_COUNT) return RS_EINVAL;
+    auto &B = h->bufs[which];
+    if (dev_ptr) *dev_ptr = B.ptr;
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = B.shape[i];
+    if (ndim) *ndim = B.ndim;
+    if (dtype) *dtype = B.dtype;
+    return RS_OK;
+}
+
+extern "C" int rs_read_buffer(rs_handle h, int32_t which, void *host_dst, int64_t nbytes) {
+    if (!h || which < 0 || which >= RS_BUF_COUNT || !host_dst) return RS_EINVAL;
+    auto &B = h->bufs[which];
+    if ((size_t)nbytes != B.bytes) { h->err = "rs_read_buffer: size mismatch"; return RS_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(host_dst, B.ptr, B.bytes, hipMemcpyDeviceToHost));
+    return RS_OK;
+}
+
+extern "C" int rs_stats(rs_handle h, int64_t *host_out) {
+    if (!h) return RS_EINVAL;
+    return rs_read_buffer(h, RS_BUF_STATS, host_out, (int64_t)h->n_envs * ST_N * 8);
+}
+
+struct Snapshot { std::vector<void *> ptrs; };
+// state AND the observation buffers: re-running observe would advance Signal.waiting_times
+static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, RS_BUF_MPLIGHT, RS_BUF_WAVE, RS_BUF_WAIT,
+                                RS_BUF_WAIT_NORM, RS_BUF_PRESSURE, RS_BUF_QUEUE_SUM, RS_BUF_QUEUE_MAX, RS_BUF_DRQ_NORM_F16,
+                                RS_BUF_ENV, RS_BUF_TLS, RS_BUF_VEH_POS, RS_BUF_VEH_SPEED, RS_BUF_VEH_ACCEL, RS_BUF_VEH_TLOSS,
+                                RS_BUF_VEH_LANE, RS_BUF_VEH_TRIP, RS_BUF_VEH_CURSOR, RS_BUF_VEH_SWAIT, RS_BUF_VEH_RWAIT,
+                                RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_STATS};
+extern "C" int rs_snapshot(rs_handle h, void **snap) {
+    if (!h || !snap) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    Snapshot *S = new Snapshot();
+    for (int b : kSnapBufs) {
+        void *d = nullptr;
+        if (hipMalloc(&d, h->bufs[b].bytes) != hipSuccess) { h->err = "rs_snapshot: hipMalloc failed"; rs_snapshot_free(h, S); return RS_ENOMEM; }
+        S->ptrs.push_back(d);
+        HIPCHK(h, hipMemcpy(d, h->bufs[b].ptr, h->bufs[b].bytes, hipMemcpyDeviceToDevice));
+    }
+    *snap = S;
+    return RS_OK;
+}
+extern "C" int rs_restore(rs_handle h, const void *snap) {
+    if (!h || !snap) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const Snapshot *S = (const Snapshot *)snap;
+    size_t i = 0;
+    for (int b : kSnapBufs) { HIPCHK(h, hipMemcpy(h->bufs[b].ptr, S->ptrs[i], h->bufs[b].bytes, hipMemcpyDeviceToDevice)); ++i; }
+    return RS_OK;
+}
+extern "C" void rs_snapshot_free(rs_handle h, void *snap) {
+    if (!snap) return;
+    Snapshot *S = (Snapshot *)snap;
+    for (void *p : S->ptrs) (void)hipFree(p);
+    delete S;
+}
+
+extern "C" int rs_timing(rs_handle h, int32_t enable) {
+    if (!h) return RS_EINVAL;
+    h->timing = enable != 0;
+    return RS_OK;
+}
+extern "C" int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    float tot = 0.0f;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.0f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int32_t)h->ev_used;
+    h->ev_used = 0;
+    return RS_OK;
+}
+
+extern "C" int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int32_t *lds_bytes, int32_t *max_lanes_per_signal) {
+    if (!h) return RS_EINVAL;
+    if (n_envs) *n_envs = h->n_envs;
+    if (block_threads) *block_threads = h->block;
+    if (lds_bytes) *lds_bytes = (int32_t)h->lds;
+    if (max_lanes_per_signal) *max_lanes_per_signal = h->T.lmax;
+    return RS_OK;
+}

@@ -1,0 +1,226 @@
+"""ctypes binding of the C ABI in include/resco_sim.h (resco_amd/csrc/libresco_sim.so).
+
+This is the only gateway to the simulator: there is NO CPU fallback.  If the HIP library is
+missing or no MI355X is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import ParamsStruct, pack_scenario
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libresco_sim.so')
+
+BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure', 'queue_sum',
+           'queue_max', 'actions', 'env', 'tls', 'veh_pos', 'veh_speed', 'veh_accel', 'veh_tloss', 'veh_lane',
+           'veh_trip', 'veh_cursor', 'veh_swait', 'veh_rwait', 'veh_depart', 'veh_owner', 'stats', 'drq_norm_f16']
+BUF_ID = {n: i for i, n in enumerate(BUFFERS)}
+_NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64]
+_TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8']
+STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10',
+             'active', 'pending', 'active_ticks', 'ticks']
+
+# every symbol include/resco_sim.h declares
+ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_act_random',
+               'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
+               'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_info']
+
+_lib = None
+
+
+def load_library():
+    """Load libresco_sim.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('HIP extension %s is missing: build it with `python -m resco_amd.build` '
+                           '(there is no CPU fallback)' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.rs_create.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(vp)]
+    L.rs_destroy.argtypes = [vp]
+    L.rs_destroy.restype = None
+    L.rs_last_error.argtypes = [vp]
+    L.rs_last_error.restype = C.c_char_p
+    L.rs_reset.argtypes = [vp, vp]
+    L.rs_step.argtypes = [vp, vp, i32, vp]
+    L.rs_sync.argtypes = [vp]
+    L.rs_act_random.argtypes = [vp, C.c_uint32, vp]
+    L.rs_act_maxwave.argtypes = [vp, vp, i32, vp, vp, i32, vp]
+    L.rs_get_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32)]
+    L.rs_read_buffer.argtypes = [vp, i32, vp, C.c_int64]
+    L.rs_stats.argtypes = [vp, vp]
+    L.rs_snapshot.argtypes = [vp, C.POINTER(vp)]
+    L.rs_restore.argtypes = [vp, vp]
+    L.rs_snapshot_free.argtypes = [vp, vp]
+    L.rs_snapshot_free.restype = None
+    L.rs_timing.argtypes = [vp, i32]
+    L.rs_timing_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+    L.rs_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+class _DevArray:
+    """Zero-copy view of a library-owned device buffer (__cuda_array_interface__, also honoured on ROCm)."""
+
+    def __init__(self, ptr, shape, dtype_code, owner):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=_TYPESTR[dtype_code],
+                                             data=(int(ptr), False), version=2, strides=None)
+        self._owner = owner
+
+
+class BatchedSim:
+    """N lock-step environments of one scenario on one GPU (one rs_handle)."""
+
+    def __init__(self, scenario, n_envs, device=0, seed=0, max_distance=200.0, sigma=-1.0, speed_dev=1,
+                 fixed_program=0, env_base=0, step_length=10, yellow_length=None, block_threads=0):
+        self.sc = scenario
+        self.n_envs = int(n_envs)
+        self.device = int(device)
+        self._lib = load_library()
+        self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
+        self._p = ParamsStruct(int(seed) & 0xFFFFFFFF, float(max_distance), float(sigma), int(speed_dev),
+                               int(fixed_program))
+        self._h = C.c_void_p()
+        rc = self._lib.rs_create(C.byref(self._st), C.byref(self._p), self.n_envs, int(env_base), self.device,
+                                 int(block_threads), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.rs_last_error(None)
+            self._h = None
+            raise RuntimeError('rs_create failed (%d): %s' % (rc, msg.decode() if msg else '?'))
+        self.S, self.O, self.C = scenario.n_signals, scenario.n_obs, scenario.capacity
+        self._maxwave_ready = False
+        self._meta = {}
+        for name, bid in BUF_ID.items():
+            ptr, shape, nd, dt = C.c_void_p(), (C.c_int64 * 4)(), C.c_int32(), C.c_int32()
+            self._check(self._lib.rs_get_buffer(self._h, bid, C.byref(ptr), shape, C.byref(nd), C.byref(dt)))
+            self._meta[name] = (ptr.value, tuple(shape[:nd.value]), dt.value)
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.rs_last_error(self._h)
+            raise RuntimeError('resco_sim error %d: %s' % (rc, msg.decode() if msg else '?'))
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.rs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.rs_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(n_envs=a.value, block_threads=b.value, lds_bytes=c.value, max_lanes_per_signal=d.value)
+
+    # ------------------------------------------------------------------ stepping
+    def reset(self, stream=None):
+        self._check(self._lib.rs_reset(self._h, stream))
+
+    def step(self, actions=None, stream=None):
+        """actions: None (use the on-device action buffer), a numpy int32 [N,S] array, or a torch
+        CUDA int32 tensor [N,S]."""
+        if actions is None:
+            self._check(self._lib.rs_step(self._h, None, 0, stream))
+            return
+        if hasattr(actions, 'data_ptr'):        # torch tensor
+            assert tuple(actions.shape) == (self.n_envs, self.S) and actions.is_contiguous()
+            assert str(actions.dtype) == 'torch.int32'
+            self._check(self._lib.rs_step(self._h, actions.data_ptr(), 1 if actions.is_cuda else 0, stream))
+            return
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.shape == (self.n_envs, self.S), a.shape
+        self._check(self._lib.rs_step(self._h, a.ctypes.data, 0, stream))
+
+    def sync(self):
+        self._check(self._lib.rs_sync(self._h))
+
+    def act_random(self, step_key, stream=None):
+        self._check(self._lib.rs_act_random(self._h, int(step_key) & 0xFFFFFFFF, stream))
+
+    def act_maxwave(self, use_pressure, stream=None):
+        if not self._maxwave_ready:
+            pairs, valid, order = maxwave_tables(self.sc)
+            self._pairs, self._valid, self._order = pairs, valid, order
+            self._check(self._lib.rs_act_maxwave(self._h, pairs.ctypes.data, len(pairs), valid.ctypes.data,
+                                                 order.ctypes.data, int(use_pressure), stream))
+            self._maxwave_ready = True
+            return
+        self._check(self._lib.rs_act_maxwave(self._h, None, len(self._pairs), None, None, int(use_pressure), stream))
+
+    # ------------------------------------------------------------------ buffers
+    def read(self, name):
+        """Synchronous host copy of a buffer as a numpy array."""
+        ptr, shape, dt = self._meta[name]
+        out = np.empty(shape, _NP_DTYPES[dt])
+        self._check(self._lib.rs_read_buffer(self._h, BUF_ID[name], out.ctypes.data, out.nbytes))
+        return out
+
+    def tensor(self, name):
+        """Zero-copy torch tensor over the library-owned device buffer (agent boundary)."""
+        import torch
+        ptr, shape, dt = self._meta[name]
+        return torch.as_tensor(_DevArray(ptr, shape, dt, self), device='cuda:%d' % self.device)
+
+    def device_pointer(self, name):
+        return self._meta[name]
+
+    def outputs(self, names=('lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure',
+                             'queue_sum', 'queue_max')):
+        return {n: self.read(n) for n in names}
+
+    def stats(self):
+        st = self.read('stats')
+        return {k: st[:, i].copy() for i, k in enumerate(STAT_KEYS)}
+
+    def time(self):
+        return self.read('env')[:, 0]
+
+    # ------------------------------------------------------------------ snapshots / timing
+    def snapshot(self):
+        snap = C.c_void_p()
+        self._check(self._lib.rs_snapshot(self._h, C.byref(snap)))
+        return snap
+
+    def restore(self, snap):
+        self._check(self._lib.rs_restore(self._h, snap))
+
+    def free_snapshot(self, snap):
+        self._lib.rs_snapshot_free(self._h, snap)
+
+    def timing(self, enable):
+        self._check(self._lib.rs_timing(self._h, 1 if enable else 0))
+
+    def timing_read(self):
+        ms, n = C.c_float(), C.c_int32()
+        self._check(self._lib.rs_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def maxwave_tables(sc):
+    """phase_pairs [P][2], valid [S][P] (local action of pair p or -1) and order [S][P] (pair indices in
+    the reference's iteration order, -1 padded) for the batched MAXWAVE / MAXPRESSURE agent
+    (agents/maxwave.py:18-38).  Without valid_acts every pair k maps to action k (np.argmax branch)."""
+    pairs = np.asarray(sc.phase_pairs, np.int32).reshape(-1, 2)
+    S, P = sc.n_signals, len(pairs)
+    valid = np.full((S, P), -1, np.int32)
+    order = np.full((S, P), -1, np.int32)
+    for si, sid in enumerate(sc.signal_ids):
+        va = None if sc.valid_acts is None else sc.valid_acts.get(sid)
+        if va is None:
+            valid[si, :] = np.arange(P)
+            order[si, :] = np.arange(P)
+        else:
+            for j, (gidx, act) in enumerate(va.items()):        # dict order = the reference's iteration order
+                valid[si, int(gidx)] = int(act)
+                order[si, j] = int(gidx)
+    return np.ascontiguousarray(pairs), np.ascontiguousarray(valid), np.ascontiguousarray(order)
