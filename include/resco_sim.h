@@ -158,6 +158,10 @@ void rs_snapshot_free(rs_handle h, void *snap);
 int rs_timing(rs_handle h, int32_t enable);
 int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches);   /* syncs; resets the accumulators */
 
+/* new RNG seed for subsequent launches (the reference restarts SUMO with --random every episode,
+ * multi_signal.py:127); call between rs_reset()s */
+int rs_set_seed(rs_handle h, uint32_t seed);
+
 /* static facts */
 int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int32_t *lds_bytes, int32_t *max_lanes_per_signal);
 

@@ -61,6 +61,8 @@ def lib():
         L.orc_brake_gap.argtypes = [C.c_float] * 2
         L.orc_follow_speed.restype = C.c_float
         L.orc_follow_speed.argtypes = [C.c_float] * 5
+        L.orc_free_speed.restype = C.c_float
+        L.orc_free_speed.argtypes = [C.c_float] * 3
         L.orc_hash.restype = C.c_uint32
         L.orc_hash.argtypes = [C.c_uint32] * 5
         _lib = L

@@ -91,6 +91,19 @@ float orc_stop_speed(float gap, float b, float tau) {
     float r = (g - h) / (n + tau);
     return n * b + r;
 }
+/* MSCFModel::freeSpeed (Euler): highest speed now that still allows reaching `target` after `dist` metres
+ * when decelerating with b per step [SUMO-K] */
+float orc_free_speed(float dist, float target, float b) {
+    if (dist < target) return target;
+    float t2 = b + 2.0f * target;
+    float y = ((sqrtf(t2 * t2 + 8.0f * b * dist) - b) * 0.5f - target) / b;
+    if (y < 0.0f) y = 0.0f;
+    float yf = floorf(y);
+    float exact = (yf * yf + yf) * 0.5f * b + yf * target + (y > yf ? target : 0.0f);
+    float rest = dist - exact;
+    if (rest < 0.0f) rest = 0.0f;
+    return rest / (yf + 1.0f) + yf * b + target;
+}
 float orc_follow_speed(float gap, float vl, float b, float bl, float tau) {
     float bm = b > bl ? b : bl;
     return orc_stop_speed(gap + orc_brake_gap(vl, bm), b, tau);
@@ -418,6 +431,13 @@ static void plan(orc_env *e) {
                 break;
             }
             int32_t nl = sc->link_to_lane[link];
+            {   /* slow down in time for a lower speed limit on the next lane */
+                float vnl = sc->lane_vmax[nl] * sf;
+                if (vnl < vfree) {
+                    float vs = orc_free_speed(seen, vnl, b);
+                    if (vs < vsafe) { vsafe = vs; e->dbg_reason[s] = 6; e->dbg_block[s] = nl; }
+                }
+            }
             int32_t o = rearmost(e, nl);
             if (o != NIL) {
                 const float *vo = vt_of(e, trip_of_slot(e, o));

@@ -136,6 +136,17 @@ __device__ __forceinline__ float d_stop_speed(float gap, float b, float tau) {
     float r = (g - h) / (n + tau);
     return n * b + r;
 }
+__device__ __forceinline__ float d_free_speed(float dist, float target, float b) {
+    if (dist < target) return target;
+    float t2 = b + 2.0f * target;
+    float y = ((sqrtf(t2 * t2 + 8.0f * b * dist) - b) * 0.5f - target) / b;
+    if (y < 0.0f) y = 0.0f;
+    float yf = floorf(y);
+    float exact = (yf * yf + yf) * 0.5f * b + yf * target + (y > yf ? target : 0.0f);
+    float rest = dist - exact;
+    if (rest < 0.0f) rest = 0.0f;
+    return rest / (yf + 1.0f) + yf * b + target;
+}
 __device__ __forceinline__ float d_follow_speed(float gap, float vl, float b, float bl, float tau) {
     float bm = b > bl ? b : bl;
     return d_stop_speed(gap + d_brake_gap(vl, bm), b, tau);
@@ -506,6 +517,13 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
                     break;
                 }
                 int nl = T.link_to_lane[link];
+                {   // slow down in time for a lower speed limit on the next lane
+                    float vnl = T.lane_vmax[nl] * L.sf[s];
+                    if (vnl < vfree) {
+                        float vs = d_free_speed(seen, vnl, b);
+                        if (vs < vsafe) vsafe = vs;
+                    }
+                }
                 int o = rearmost(L, nl);
                 if (o != NIL) {
                     const float *vo = L.vtp + L.vt[o] * VT_COLS;
@@ -1162,6 +1180,12 @@ extern "C" int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches) {
     if (total_ms) *total_ms = tot;
     if (launches) *launches = (int32_t)h->ev_used;
     h->ev_used = 0;
+    return RS_OK;
+}
+
+extern "C" int rs_set_seed(rs_handle h, uint32_t seed) {
+    if (!h) return RS_EINVAL;
+    h->P.seed = seed;
     return RS_OK;
 }
 

@@ -1,0 +1,292 @@
+"""MultiSignal: the gym-style multi-agent traffic-signal environment, backed by the HIP simulator.
+
+Drop-in for the reference's resco_benchmark/multi_signal.py:9-234 — same constructor arguments
+(multi_signal.py:10-12, as main.py:81-89 passes them), reset() / step(act) / close() / render(), and the
+attributes callers read (obs_shape, phases, all_ts_ids, ts_order, signals, signal_ids, observation_space,
+action_space, n_agents, connection_name, run).  The `self.sumo` TraCI connection does not exist: every
+sumo.* call of the reference (simulationStep, trafficlight.setPhase/getPhase, lane/vehicle getters) happens
+inside one HIP kernel launch per step (resco_amd/csrc/resco_sim.hip) through the C ABI of
+include/resco_sim.h.
+
+MultiSignal is the single-environment dict API existing agents plug into unchanged;
+VecMultiSignal is the batched tensor API (N lock-step environments on one GPU).
+"""
+import os
+
+import numpy as np
+
+from . import rewards as _rewards
+from . import states as _states
+from .config.map_config import map_configs
+from .config.signal_config import signal_configs
+from .scenario import Scenario, compile_from_sumocfg
+from .sim import BatchedSim
+from .traffic_signal import Phase, Signal
+
+try:  # gym is optional: only observation_space / action_space use it
+    import gym as _gym
+    _Box, _Discrete = _gym.spaces.Box, _gym.spaces.Discrete
+    _EnvBase = _gym.Env
+except Exception:  # pragma: no cover - gym is not installed in the build image
+    _EnvBase = object
+
+    class _Box:
+        def __init__(self, low, high, shape, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+    class _Discrete:
+        def __init__(self, n):
+            self.n = int(n)
+
+_SCEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scenarios')
+
+
+def load_scenario(map_name, net=None, lights=(), yellow_length=3):
+    """Scenario tables for a map: compiled from the SUMO files when `net` names an existing .sumocfg,
+    otherwise the pre-compiled tables shipped in resco_amd/scenarios/."""
+    if net is not None and os.path.isfile(net) and net.endswith('.sumocfg'):
+        return compile_from_sumocfg(map_name, net, signal_configs[map_name], lights=lights,
+                                    yellow_length=yellow_length)
+    path = os.path.join(_SCEN_DIR, map_name + '.npz')
+    if not os.path.exists(path):
+        raise EnvironmentError('no scenario for map %r: %r is not a .sumocfg and %s does not exist'
+                               % (map_name, net, path))
+    sc = Scenario.load(path)
+    if sc.yellow_length != yellow_length:
+        raise EnvironmentError('packaged scenario %s was compiled with yellow_length=%d (asked %d); pass the '
+                               '.sumocfg path to recompile' % (map_name, sc.yellow_length, yellow_length))
+    if len(lights) > 0 and list(lights) != list(sc.signal_ids):
+        raise EnvironmentError('packaged scenario %s controls %s' % (map_name, sc.signal_ids))
+    return sc
+
+
+class MultiSignal(_EnvBase):
+    def __init__(self, run_name, map_name, net, state_fn, reward_fn, route=None, gui=False, end_time=3600,
+                 step_length=10, yellow_length=4, step_ratio=1, max_distance=200, lights=(), log_dir='/',
+                 libsumo=False, warmup=0, gymma=False, *, device=0, seed=None, sigma=-1.0, speed_dev=1,
+                 fixed_program=False, scenario=None, use_fast_path=True):
+        if step_ratio != 1:
+            raise NotImplementedError('step_ratio != 1 (sub-second SUMO steps) is not supported')
+        self.libsumo, self.gymma, self.gui = libsumo, gymma, gui
+        self.log_dir, self.net, self.route = log_dir, net, route
+        self.state_fn, self.reward_fn = state_fn, reward_fn
+        self.max_distance, self.warmup = max_distance, warmup
+        self.end_time, self.step_length = end_time, step_length
+        self.yellow_length, self.step_ratio = yellow_length, step_ratio
+        self.map_name = map_name
+        self.use_fast_path = use_fast_path
+        self.connection_name = run_name + '-' + map_name + '---' + state_fn.__name__ + '-' + reward_fn.__name__
+
+        self.scenario = scenario if scenario is not None else load_scenario(map_name, net, lights, yellow_length)
+        sc = self.scenario
+        self._base_seed = int.from_bytes(os.urandom(4), 'little') if seed is None else int(seed)
+        self.sim = BatchedSim(sc, 1, device=device, seed=self._base_seed, max_distance=max_distance, sigma=sigma,
+                              speed_dev=speed_dev, fixed_program=1 if fixed_program else 0,
+                              step_length=step_length, yellow_length=yellow_length)
+        self.view_env = 0
+        self._version = 0
+        self._cache = {}
+
+        # multi_signal.py:48-59: all TLS ids, green phases per signal
+        self.signal_ids = list(sc.signal_ids)
+        self.phases = {sid: [Phase(d, s) for d, s in sc.signal_meta[sid]['phases'][:sc.signal_meta[sid]['n_green']]]
+                       for sid in sc.signal_ids}
+        self.all_ts_ids = list(lights) if len(lights) > 0 else list(sc.signal_ids)
+        self.ts_starter = len(self.all_ts_ids)
+        self.signals = {}
+        for i, ts in enumerate(self.all_ts_ids):
+            self.signals[ts] = Signal(self, i, ts)
+        for ts in self.all_ts_ids:
+            self.signals[ts].signals = self.signals
+
+        # multi_signal.py:67-86: observation shapes from one evaluation of the state function
+        self.obs_shape, self.observation_space, self.action_space, self.ts_order = {}, [], [], []
+        observations = self._evaluate(self.state_fn)
+        for ts in observations:
+            shape = observations[ts].shape
+            self.obs_shape[ts] = shape
+            self.ts_order.append(ts)
+            self.observation_space.append(_Box(low=-np.inf, high=np.inf, shape=shape))
+            if ts == 'top_mgr' or ts == 'bot_mgr':
+                continue
+            self.action_space.append(_Discrete(len(self.phases[ts])))
+        self.n_agents = self.ts_starter
+        self.run = 0
+        self.metrics = []
+        self.wait_metric = {}
+        self.connection_name = (run_name + '-' + map_name + '-' + str(len(lights)) + '-' + state_fn.__name__ + '-' +
+                                reward_fn.__name__)
+        try:
+            os.makedirs(log_dir + self.connection_name, exist_ok=True)
+        except OSError:
+            pass
+
+    # ------------------------------------------------------------------ device buffer access
+    def _host(self, name):
+        hit = self._cache.get(name)
+        if hit is None or hit[0] != self._version:
+            hit = (self._version, self.sim.read(name))
+            self._cache[name] = hit
+        return hit[1]
+
+    def _evaluate(self, fn):
+        """fn(signals) through the kernel-produced buffer when the registry knows one, else on the host."""
+        fast = getattr(fn, 'fast_buffer', None) if self.use_fast_path else None
+        registry = _states.REGISTRY.get(fn.__name__) is fn or _rewards.REGISTRY.get(fn.__name__) is fn
+        if not fast or not registry:
+            return fn(self.signals)
+        sc, e = self.scenario, self.view_env
+        out = {}
+        name = fn.__name__
+        for i, ts in enumerate(self.all_ts_ids):
+            o0, o1 = int(sc.sig_obs_start[i]), int(sc.sig_obs_start[i + 1])
+            if name == 'drq_norm':
+                out[ts] = np.expand_dims(self._host('drq_norm')[e, o0:o1].astype(np.float64), axis=0)
+            elif name == 'drq':
+                agg = self._host('lane_agg')[e, o0:o1].astype(np.float64)
+                ph = int(self._host('phase')[e, i])
+                rows = np.stack([(np.arange(o1 - o0) == ph).astype(np.float64), agg[:, 1], agg[:, 2], agg[:, 0],
+                                 agg[:, 4]], axis=1)
+                out[ts] = np.expand_dims(rows, axis=0)
+            elif name == 'mplight':
+                out[ts] = self._host('mplight')[e, i].astype(np.int64)
+            elif name == 'wave':
+                out[ts] = self._host('wave')[e, i].astype(np.int64)
+            elif name == 'wait':
+                w = float(self._host('wait')[e, i])      # -sum(float waiting times); the empty sum is the int 0
+                out[ts] = w if w != 0 else 0
+            elif name == 'wait_norm':
+                out[ts] = np.float32(self._host('wait_norm')[e, i])
+            elif name == 'pressure':
+                out[ts] = int(self._host('pressure')[e, i])
+            else:  # pragma: no cover
+                return fn(self.signals)
+        return out
+
+    # ------------------------------------------------------------------ gym API
+    def step_sim(self):
+        raise NotImplementedError('single simulation ticks are fused into the step kernel')
+
+    def reset(self):
+        if self.run != 0:
+            self.save_metrics()
+        self.metrics = []
+        self.run += 1
+        # the reference restarts SUMO with --random (multi_signal.py:127): a new seed per episode
+        self.sim.set_seed((self._base_seed + 0x9E3779B1 * self.run) & 0xFFFFFFFF)
+        self.sim.reset()
+        self._version += 1
+        self.signal_ids = [self.all_ts_ids[i] for i in range(self.ts_starter)]
+        for ts in self.signal_ids:
+            self.signals[ts].last_step_vehicles = None
+            self.wait_metric[ts] = 0.0
+        states = self._evaluate(self.state_fn)
+        if self.gymma:
+            return [states[ts] for ts in self.ts_order]
+        return states
+
+    def step(self, act):
+        if self.gymma:
+            act = {ts: act[i] for i, ts in enumerate(self.ts_order)}
+        a = np.asarray([[int(act[ts]) for ts in self.all_ts_ids]], dtype=np.int32)
+        self.sim.step(a)
+        self._version += 1
+        observations = self._evaluate(self.state_fn)
+        rewards = self._evaluate(self.reward_fn)
+        self.calc_metrics(rewards)
+        done = self.sim_time() >= self.end_time
+        if self.gymma:
+            return ([observations[ts] for ts in self.ts_order], [rewards[ts] for ts in self.ts_order], [done],
+                    {'eps': self.run})
+        return observations, rewards, done, {'eps': self.run}
+
+    def sim_time(self):
+        """simulation.getTime(): absolute seconds (sumocfg begin + ticks)."""
+        return float(self.scenario.begin + int(self._host('env')[self.view_env, 0]))
+
+    def calc_metrics(self, rewards):
+        qs, qm = self._host('queue_sum')[self.view_env], self._host('queue_max')[self.view_env]
+        queue_lengths = {ts: int(qs[i]) for i, ts in enumerate(self.all_ts_ids)}
+        max_queues = {ts: int(qm[i]) for i, ts in enumerate(self.all_ts_ids)}
+        self.metrics.append({'step': self.sim_time(), 'reward': rewards, 'max_queues': max_queues,
+                             'queue_lengths': queue_lengths})
+
+    def save_metrics(self):
+        log = os.path.join(self.log_dir, self.connection_name + os.sep + 'metrics_' + str(self.run) + '.csv')
+        try:
+            os.makedirs(os.path.dirname(log), exist_ok=True)
+            with open(log, 'w+') as output_file:
+                for line in self.metrics:
+                    csv_line = ''
+                    for metric in ['step', 'reward', 'max_queues', 'queue_lengths']:
+                        csv_line = csv_line + str(line[metric]) + ', '
+                    output_file.write(csv_line + '\n')
+        except OSError:
+            pass
+
+    def trip_stats(self):
+        """tripinfo-style episode aggregates of this environment (avg duration / timeLoss / departDelay)."""
+        st = {k: int(v[self.view_env]) for k, v in self.sim.stats().items()}
+        n = max(1, st['arrived'])
+        st.update(avg_duration=st['sum_duration'] / n, avg_time_loss=st['sum_time_loss_q10'] / 1024.0 / n,
+                  avg_depart_delay=st['sum_depart_delay'] / max(1, st['inserted']),
+                  mean_active=st['active_ticks'] / max(1, st['ticks']))
+        return st
+
+    def render(self, mode='human'):
+        pass
+
+    def close(self):
+        self.save_metrics()
+        self.sim.close()
+
+
+class VecMultiSignal:
+    """N lock-step environments on one GPU; observations / rewards are zero-copy torch tensors over the
+    library-owned device buffers (the agent boundary), actions are an int32 [N, S] tensor or None (actions
+    already written on device by act_random / act_maxwave)."""
+
+    def __init__(self, map_name, n_envs, states=('drq_norm',), rewards=('wait',), net=None, device=0, seed=0,
+                 max_distance=200, step_length=10, yellow_length=3, sigma=-1.0, speed_dev=1, fixed_program=False,
+                 env_base=0, block_threads=0, scenario=None):
+        mc = map_configs.get(map_name, {})
+        self.scenario = scenario if scenario is not None else load_scenario(map_name, net, mc.get('lights', ()),
+                                                                            yellow_length)
+        self.sim = BatchedSim(self.scenario, n_envs, device=device, seed=seed, max_distance=max_distance,
+                              sigma=sigma, speed_dev=speed_dev, fixed_program=1 if fixed_program else 0,
+                              env_base=env_base, step_length=step_length, yellow_length=yellow_length,
+                              block_threads=block_threads)
+        self.n_envs, self.n_signals = n_envs, self.scenario.n_signals
+        self.state_names, self.reward_names = tuple(states), tuple(rewards)
+        self.step_length = step_length
+        self.horizon_steps = self.scenario.horizon // step_length
+        self.steps = 0
+        self.all_ts_ids = list(self.scenario.signal_ids)
+        self.n_actions = [int(g) for g in self.scenario.tls_ngreen]
+        self._tensors = {}
+
+    def tensor(self, name):
+        t = self._tensors.get(name)
+        if t is None:
+            t = self._tensors[name] = self.sim.tensor(name)
+        return t
+
+    def _pack(self):
+        return ({n: self.tensor(n) for n in self.state_names}, {n: self.tensor(n) for n in self.reward_names})
+
+    def reset(self, stream=None):
+        self.sim.reset(stream)
+        self.steps = 0
+        return self._pack()[0]
+
+    def step(self, actions=None, stream=None):
+        self.sim.step(actions, stream)
+        self.steps += 1
+        obs, rew = self._pack()
+        return obs, rew, self.steps >= self.horizon_steps, {'steps': self.steps}
+
+    def sync(self):
+        self.sim.sync()
+
+    def close(self):
+        self.sim.close()

@@ -639,7 +639,7 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
             fix_dur.append(d)
             fix_states.extend(_TLS_CODE[ch] for ch in s)
         signal_meta[sid] = dict(phases=[[d, s] for d, s in phases], yellow_dict=ydict, n_green=G,
-                                green_durations=[d for d, _ in greens])
+                                green_durations=[d for d, _ in greens], orig_program=[[d, s] for d, s in prog])
 
     # ---- flatten links
     nk = len(links)
@@ -823,14 +823,15 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
         A[k] = np.ascontiguousarray(A[k])
 
     if capacity is None:
-        # ring slots: next power of two above ~3x the free-flow concurrency estimate
+        # vehicle slots per environment: next power of two above ~4x the free-flow concurrency estimate
+        # (trips wait for a free slot when an environment is full; that shows up as departDelay)
         dur = []
         for r in routes:
             dur.append(sum(cost[e] for e in r))
         mean_dur = float(np.mean([dur[i] for i in trip_route])) if trip_route else 1.0
         conc = len(trip_route) * mean_dur / max(1, horizon)
         capacity = 64
-        while capacity < 8 * conc + 32:
+        while capacity < 4 * conc + 32:
             capacity *= 2
         capacity = min(capacity, 4096)
 

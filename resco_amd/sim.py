@@ -25,7 +25,7 @@ STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_wai
 # every symbol include/resco_sim.h declares
 ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
-               'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_info']
+               'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_info']
 
 _lib = None
 
@@ -59,6 +59,7 @@ def load_library():
     L.rs_snapshot_free.restype = None
     L.rs_timing.argtypes = [vp, i32]
     L.rs_timing_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+    L.rs_set_seed.argtypes = [vp, C.c_uint32]
     L.rs_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
@@ -140,6 +141,9 @@ class BatchedSim:
         a = np.ascontiguousarray(actions, dtype=np.int32)
         assert a.shape == (self.n_envs, self.S), a.shape
         self._check(self._lib.rs_step(self._h, a.ctypes.data, 0, stream))
+
+    def set_seed(self, seed):
+        self._check(self._lib.rs_set_seed(self._h, int(seed) & 0xFFFFFFFF))
 
     def sync(self):
         self._check(self._lib.rs_sync(self._h))

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+HOT_CASES = ['cologne1_d200', 'cologne8_d200', 'cologne8_d50', 'ingolstadt21_d200']
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def root():
+    return ROOT
+
+
+def load_scenario(name):
+    from resco_amd.scenario import Scenario
+    return Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
+
+
+def load_golden(tag):
+    import json
+
+    import numpy as np
+    with open(os.path.join(GOLDEN, tag + '.json')) as f:
+        meta = json.load(f)
+    arr = dict(np.load(os.path.join(GOLDEN, tag + '.npz')))
+    return meta, arr

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ (BUILD CONTAINER ONLY).
+
+Runs the reference's unmodified MultiSignal / Signal / states / rewards / MAXPRESSURE / MAXWAVE (imported
+from /root/reference through oracle/ref_harness.py) over a FakeSumo backed by the CPU oracle, on a fixed
+action script, and stores the inputs (actions, seeds) and the expected outputs.  Re-run after any change of
+the dynamics model:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import ref_harness                                   # noqa: E402
+from oracle.pyoracle import OracleEnv                            # noqa: E402
+from resco_amd.scenario import Scenario                          # noqa: E402
+from resco_amd.config.map_config import map_configs              # noqa: E402
+
+BASE_SEED = 7
+CASES = [  # (map, steps, max_distance)
+    ('cologne1', 48, 200), ('cologne8', 40, 200), ('cologne8', 24, 50), ('ingolstadt21', 30, 200),
+]
+STATE_FNS = ['drq', 'drq_norm', 'mplight', 'mplight_full', 'wave']
+REWARD_FNS = ['wait', 'wait_norm', 'pressure']
+
+
+def episode_seed(run):
+    return (BASE_SEED + 0x9E3779B1 * run) & 0xFFFFFFFF
+
+
+def run_case(map_name, steps, max_distance):
+    sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', map_name + '.npz'))
+    mc = map_configs[map_name]
+    state = {'n': 0}
+
+    def factory(cmd):
+        # every traci.start is a fresh SUMO: the probe run of __init__ is start #0, episode k is start #k
+        orc = OracleEnv(sc, env_index=0, seed=episode_seed(state['n']), max_distance=max_distance, sigma=-1.0,
+                        speed_dev=1)
+        state['n'] += 1
+        state['orc'] = orc
+        return ref_harness.FakeSumo(sc, orc)
+
+    ref_harness.install_stubs(factory)
+    ref = ref_harness.import_reference()
+    states, rewards = ref['states'], ref['rewards']
+    tmp = tempfile.mkdtemp() + os.sep
+    env = ref['MultiSignal']('golden', map_name, 'x.sumocfg', states.mplight, rewards.wait, step_length=mc['step_length'],
+                             yellow_length=mc['yellow_length'], end_time=mc['end_time'], max_distance=max_distance,
+                             lights=mc['lights'], log_dir=tmp)
+    ids = list(env.all_ts_ids)
+    S = len(ids)
+    mp = ref['MAXPRESSURE']({}, None, map_name, 0)
+    mw = ref['MAXWAVE']({}, None, map_name, 0)
+    rng = np.random.default_rng(1234)
+    n_green = [len(env.phases[ts]) for ts in ids]
+
+    rec = {k: [] for k in STATE_FNS + REWARD_FNS + ['agg', 'phase', 'act_maxpressure', 'act_maxwave', 'time', 'done',
+                                                    'queue_sum', 'queue_max']}
+
+    def snapshot():
+        for fn in STATE_FNS:
+            out = getattr(states, fn)(env.signals)
+            rec[fn].append(np.concatenate([np.asarray(out[ts], dtype=np.float64).reshape(-1) for ts in ids]))
+        for fn in REWARD_FNS:
+            out = getattr(rewards, fn)(env.signals)
+            rec[fn].append(np.asarray([float(out[ts]) for ts in ids]))
+        agg = []
+        for ts in ids:
+            sig = env.signals[ts]
+            for lane in sig.lanes:
+                fo = sig.full_observation[lane]
+                agg.append([fo['queue'], fo['approach'], fo['total_wait'], fo['max_wait'],
+                            sum(v['speed'] for v in fo['vehicles'])])
+        rec['agg'].append(np.asarray(agg, dtype=np.float64))
+        rec['phase'].append(np.asarray([env.signals[ts].phase for ts in ids]))
+        a1 = mp.act(states.mplight(env.signals))
+        a2 = mw.act(states.wave(env.signals))
+        rec['act_maxpressure'].append(np.asarray([int(a1[ts]) for ts in ids]))
+        rec['act_maxwave'].append(np.asarray([int(a2[ts]) for ts in ids]))
+        rec['time'].append(env.sumo.simulation.getTime())
+
+    obs0 = env.reset()
+    assert list(obs0.keys()) == ids
+    snapshot()
+    actions = []
+    for k in range(steps):
+        if k < steps // 3:
+            act = [int(rng.integers(0, g)) for g in n_green]
+        elif k < 2 * steps // 3:
+            act = [int(a) for a in rec['act_maxpressure'][-1]]
+        else:
+            act = [int(a) for a in rec['act_maxwave'][-1]]
+        # sprinkle "keep current phase" actions to exercise the no-change branch of prep_phase
+        if k % 7 == 3:
+            act = [int(p) if p < g else a for p, g, a in zip(rec['phase'][-1], n_green, act)]
+        actions.append(act)
+        obs, rew, done, info = env.step({ts: a for ts, a in zip(ids, act)})
+        assert info == {'eps': 1}
+        snapshot()
+        rec['done'].append(bool(done))
+        m = env.metrics[-1]
+        rec['queue_sum'].append([m['queue_lengths'][ts] for ts in ids])
+        rec['queue_max'].append([m['max_queues'][ts] for ts in ids])
+    orc_stats = state['orc'].stats()
+    env.reset()                                       # writes metrics_1.csv
+    with open(os.path.join(tmp, env.connection_name, 'metrics_1.csv')) as f:
+        csv_text = f.read()
+
+    tag = '%s_d%d' % (map_name, max_distance)
+    meta = dict(map=map_name, steps=steps, max_distance=max_distance, base_seed=BASE_SEED, seed=episode_seed(1),
+                all_ts_ids=ids, ts_order=list(env.ts_order), obs_shape={ts: list(env.obs_shape[ts]) for ts in ids},
+                n_green=n_green, connection_name=env.connection_name, metrics_csv=csv_text,
+                oracle_stats=orc_stats, signals={})
+    for ts in ids:
+        sig = env.signals[ts]
+        meta['signals'][ts] = dict(
+            lanes=list(sig.lanes), lane_sets=sig.lane_sets,
+            lane_sets_outbound={k: sorted(v) for k, v in sig.lane_sets_outbound.items()},
+            outbound_lanes=list(sig.outbound_lanes), out_lane_to_signalid=sig.out_lane_to_signalid,
+            inbounds_fr_direction=sig.inbounds_fr_direction, downstream=sig.downstream,
+            phases=[[p.duration, p.state] for p in sig.phases], yellow_dict=sig.yellow_dict,
+            green_phases=[[p.duration, p.state] for p in env.phases[ts]])
+    with open(os.path.join(HERE, tag + '.json'), 'w') as f:
+        json.dump(meta, f, indent=0)
+    arrays = {k: np.asarray(v) for k, v in rec.items()}
+    arrays['actions'] = np.asarray(actions, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, tag + '.npz'), **arrays)
+    print(tag, 'steps', steps, 'final queue', int(arrays['queue_sum'][-1].sum()), 'arrived', orc_stats['arrived'],
+          'max wait', float(arrays['agg'][:, :, 3].max()))
+
+
+if __name__ == '__main__':
+    for case in CASES:
+        run_case(*case)

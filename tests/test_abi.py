@@ -1,0 +1,52 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/resco_sim.h declares, and fails loudly
+(without computing anything) when no GPU is visible."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_scenario
+from resco_amd import sim as rsim
+
+
+def header_symbols():
+    with open(os.path.join(ROOT, 'include', 'resco_sim.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(rs_[a-z_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from resco_amd.build import build_library
+    build_library()
+    L = rsim.load_library()
+    syms = header_symbols()
+    assert sorted(rsim.ABI_SYMBOLS) == syms
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_struct_layout_matches_header():
+    """the ctypes mirror lists the fields of rs_scenario in header order"""
+    with open(os.path.join(ROOT, 'include', 'resco_sim.h')) as f:
+        text = f.read()
+    body = text[text.index('typedef struct rs_scenario {') + len('typedef struct rs_scenario {'):text.index('} rs_scenario;')]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl or decl.startswith('typedef'):
+            continue
+        decl = re.sub(r'^(const\s+)?(int32_t|uint32_t|float)\s*', '', decl)
+        names += [n.strip().lstrip('*') for n in decl.split(',')]
+    from resco_amd._abi import ScenarioStruct
+    assert [f[0] for f in ScenarioStruct._fields_] == names
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    sc = load_scenario('cologne1')
+    with pytest.raises(RuntimeError, match='rs_create failed'):
+        rsim.BatchedSim(sc, 2)

@@ -1,0 +1,67 @@
+"""CPU, world_size 2, gloo: the multi-GPU path of bench.py is an env-batch split with no data-path
+collective -- ranks own disjoint environment ranges keyed by their GLOBAL index, meet at a barrier, and
+report the MAX of their times.  The union of the shards must equal the single-process batch."""
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_scenario
+
+ENVS_PER_RANK, STEPS, WARMUP, SEED = 3, 4, 2, 21
+
+
+def _rank_main(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    from oracle_batch import OracleBatch
+    sc = load_scenario('cologne1')
+    base, n = bench.shard(rank, world, ENVS_PER_RANK)
+    sim = OracleBatch(sc, n, seed=SEED, env_base=base)
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed, kms, launches, st0, st1 = bench.run_timed(sim, STEPS, WARMUP, dist.barrier, sim.sync, reduce_max)
+    with open(os.path.join(outdir, 'rank%d.pkl' % rank), 'wb') as f:
+        pickle.dump(dict(base=base, n=n, elapsed=elapsed, launches=launches, mplight=sim.read('mplight'),
+                         lane_agg=sim.read('lane_agg'), ticks=(st1['ticks'] - st0['ticks'])), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_env_batch_split_over_two_ranks():
+    outdir = tempfile.mkdtemp()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_rank_main, args=(2, port, outdir), nprocs=2, join=True)
+    parts = [pickle.load(open(os.path.join(outdir, 'rank%d.pkl' % r), 'rb')) for r in range(2)]
+    assert [p['base'] for p in parts] == [0, ENVS_PER_RANK] and all(p['n'] == ENVS_PER_RANK for p in parts)
+    assert parts[0]['elapsed'] == parts[1]['elapsed'] > 0          # MAX over ranks, identical everywhere
+    assert all(p['launches'] == STEPS for p in parts)
+    assert all((p['ticks'] == STEPS * 10).all() for p in parts)
+    # single-process reference batch of 2 x ENVS_PER_RANK environments
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import bench
+    from oracle_batch import OracleBatch
+    whole = OracleBatch(load_scenario('cologne1'), 2 * ENVS_PER_RANK, seed=SEED, env_base=0)
+    bench.run_timed(whole, STEPS, WARMUP, lambda: None, whole.sync, lambda x: x)
+    np.testing.assert_array_equal(whole.read('mplight'), np.concatenate([p['mplight'] for p in parts]))
+    np.testing.assert_array_equal(whole.read('lane_agg'), np.concatenate([p['lane_agg'] for p in parts]))
+
+
+def test_algorithmic_bytes_formula():
+    import bench
+    sc = load_scenario('ingolstadt21')
+    b = bench.algorithmic_bytes_per_env_step(sc, 300.0)
+    # 60 B per active vehicle + 152 B per signal + 40 B per observed lane + fp16 padded obs + scalars
+    assert b == 300 * 60 + 21 * 152 + 163 * 40 + 21 * 17 * 10 + 104

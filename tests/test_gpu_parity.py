@@ -1,0 +1,287 @@
+"""GPU (-m gpu): the HIP library through the C ABI vs the CPU oracle (bit-exact) and vs the golden outputs
+of the reference's own Python, plus size-independent properties at the BASELINE sizes."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import sys
+
+from conftest import HOT_CASES, ROOT, load_golden, load_scenario
+
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+pytestmark = pytest.mark.gpu
+
+INT_BUFS = ['phase', 'mplight', 'wave', 'pressure', 'queue_sum', 'queue_max']
+FLT_BUFS = ['lane_agg', 'drq_norm', 'wait', 'wait_norm']
+VEH = [('veh_lane', 'lane'), ('veh_trip', 'trip'), ('veh_pos', 'pos'), ('veh_speed', 'speed'),
+       ('veh_cursor', 'cursor'), ('veh_swait', 'sumo_wait'), ('veh_tloss', 'time_loss'), ('veh_rwait', 'resco_wait'),
+       ('veh_owner', 'owner'), ('veh_depart', 'depart'), ('veh_accel', 'accel')]
+
+
+def assert_env_equal(sim, orcs, step):
+    out = sim.outputs()
+    vg = {g: sim.read(g) for g, _ in VEH}
+    env = sim.read('env')
+    for e, o in enumerate(orcs):
+        ref = o.outputs()
+        for b in INT_BUFS + FLT_BUFS:      # floats too: both sides are IEEE fp32 without contraction
+            np.testing.assert_array_equal(out[b][e], ref[b], err_msg='%s env %d step %d' % (b, e, step))
+        vo = o.vehicles()
+        assert env[e, 2] == vo['hw'] and env[e, 1] == vo['next_trip'] and env[e, 0] == o.time
+        hw = vo['hw']
+        free = vo['lane'][:hw] == 0xFFFF
+        active = vo['lane'][:hw] < 0xFFFE
+        for g, r in VEH:
+            a, b_ = vg[g][e][:hw], vo[r][:hw]
+            if r == 'trip':
+                a, b_ = a.astype(np.int64), b_.astype(np.int64) & 0xFFFF
+            elif r in ('resco_wait', 'owner', 'depart', 'accel'):
+                a, b_ = a[active], b_[active]
+            elif r != 'lane':
+                a, b_ = a[~free], b_[~free]
+            np.testing.assert_array_equal(a, b_, err_msg='%s env %d step %d' % (g, e, step))
+
+
+@pytest.mark.parametrize('name,n_envs,steps,sigma,speed_dev,fixed', [
+    ('cologne1', 5, 40, 0.0, 0, 0),          # parity mode (deterministic)
+    ('cologne1', 3, 60, -1.0, 1, 0),         # bench mode (dawdling + speedFactor)
+    ('cologne1', 2, 30, -1.0, 1, 1),         # FIXED programme (BASELINE config 1 plumbing)
+    ('cologne8', 3, 40, -1.0, 1, 0),
+    ('ingolstadt21', 2, 45, -1.0, 1, 0),
+])
+def test_gpu_equals_oracle_bit_exact(name, n_envs, steps, sigma, speed_dev, fixed):
+    from oracle.pyoracle import OracleEnv
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario(name)
+    base = 17
+    sim = BatchedSim(sc, n_envs, seed=3, sigma=sigma, speed_dev=speed_dev, fixed_program=fixed, env_base=base)
+    orcs = [OracleEnv(sc, env_index=base + e, seed=3, sigma=sigma, speed_dev=speed_dev, fixed_program=fixed)
+            for e in range(n_envs)]
+    for o in orcs:
+        o.observe()
+    assert_env_equal(sim, orcs, -1)
+    rng = np.random.default_rng(0)
+    for step in range(steps):
+        acts = np.stack([rng.integers(0, sc.tls_ngreen) for _ in range(n_envs)]).astype(np.int32)
+        if step == 5:
+            acts[0, 0] = 99                  # out-of-range action: ignored, phase kept
+        sim.step(acts)
+        for e, o in enumerate(orcs):
+            o.step(acts[e])
+        assert_env_equal(sim, orcs, step)
+    st = sim.stats()
+    for e, o in enumerate(orcs):
+        so = o.stats()
+        for k in st:
+            assert st[k][e] == so[k], (k, e)
+    sim.close()
+
+
+@pytest.mark.parametrize('tag', HOT_CASES)
+@pytest.mark.parametrize('fast', [True, False])
+def test_multisignal_matches_reference_python(tag, fast):
+    """The reference's MultiSignal/Signal/states/rewards (golden) vs resco_amd.MultiSignal on the HIP path."""
+    from resco_amd import rewards, states
+    from resco_amd.config.map_config import map_configs
+    from resco_amd.multi_signal import MultiSignal
+    meta, g = load_golden(tag)
+    mc = map_configs[meta['map']]
+    tmp = tempfile.mkdtemp() + os.sep
+    env = MultiSignal('golden', meta['map'], mc['net'], states.mplight, rewards.wait, step_length=mc['step_length'],
+                      yellow_length=mc['yellow_length'], end_time=mc['end_time'], max_distance=meta['max_distance'],
+                      lights=mc['lights'], log_dir=tmp, seed=meta['base_seed'], use_fast_path=fast)
+    ids = meta['all_ts_ids']
+    assert env.all_ts_ids == ids and env.ts_order == meta['ts_order']
+    assert {k: list(v) for k, v in env.obs_shape.items()} == meta['obs_shape']
+    assert env.connection_name == meta['connection_name'] and env.n_agents == len(ids)
+    assert [len(env.phases[t]) for t in ids] == meta['n_green']
+    for t in ids:
+        assert env.signals[t].lanes == meta['signals'][t]['lanes']
+        assert env.signals[t].yellow_dict == meta['signals'][t]['yellow_dict']
+    obs = env.reset()
+    assert list(obs.keys()) == ids
+
+    def check(k):
+        for fn in ('drq', 'drq_norm', 'mplight', 'mplight_full', 'wave'):
+            f = getattr(states, fn)
+            out = env._evaluate(f) if fast else f(env.signals)
+            flat = np.concatenate([np.asarray(out[t], dtype=np.float64).reshape(-1) for t in ids])
+            if fn in ('mplight', 'wave'):
+                np.testing.assert_array_equal(flat, g[fn][k], err_msg=fn)
+            else:   # fp32 kernels vs the reference's float64 sums of per-vehicle speeds
+                np.testing.assert_allclose(flat, g[fn][k], rtol=2e-6, atol=1e-3 if fn in ('drq', 'mplight_full') else 2e-6, err_msg=fn)
+        for fn in ('wait', 'wait_norm', 'pressure'):
+            f = getattr(rewards, fn)
+            out = env._evaluate(f) if fast else f(env.signals)
+            np.testing.assert_array_equal(np.asarray([float(out[t]) for t in ids], np.float32),
+                                          g[fn][k].astype(np.float32), err_msg=fn)
+        assert [env.signals[t].phase for t in ids] == g['phase'][k].tolist()
+        assert env.sim_time() == g['time'][k]
+
+    check(0)
+    for k in range(meta['steps']):
+        obs, rew, done, info = env.step({t: int(a) for t, a in zip(ids, g['actions'][k])})
+        assert done == bool(g['done'][k]) and info == {'eps': 1}
+        np.testing.assert_array_equal(np.concatenate([obs[t] for t in ids]), g['mplight'][k + 1])
+        assert [float(rew[t]) for t in ids] == g['wait'][k + 1].tolist()
+        check(k + 1)
+    ts = env.trip_stats()
+    for key in ('inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10'):
+        assert ts[key] == meta['oracle_stats'][key], key
+    env.reset()
+    with open(os.path.join(tmp, env.connection_name, 'metrics_1.csv')) as f:
+        assert f.read() == meta['metrics_csv']          # calc_metrics / save_metrics text, byte for byte
+    env.close()
+
+
+@pytest.mark.parametrize('tag', HOT_CASES)
+def test_device_agents_match_reference(tag):
+    """rs_act_maxwave (MAXPRESSURE / MAXWAVE on device) vs the reference agents' actions (golden)."""
+    from resco_amd.sim import BatchedSim
+    meta, g = load_golden(tag)
+    sc = load_scenario(meta['map'])
+    sim = BatchedSim(sc, 3, seed=meta['seed'], max_distance=meta['max_distance'])
+    # env 0 is the golden environment; envs 1,2 differ (other RNG keys) and only have to stay in range
+    for k in range(meta['steps'] + 1):
+        sim.act_maxwave(1)
+        sim.sync()
+        a1 = sim.read('actions')
+        sim.act_maxwave(0)
+        sim.sync()
+        a2 = sim.read('actions')
+        np.testing.assert_array_equal(a1[0], g['act_maxpressure'][k])
+        np.testing.assert_array_equal(a2[0], g['act_maxwave'][k])
+        assert (a1 >= 0).all() and (a1 < sc.tls_ngreen[None, :]).all()
+        if k < meta['steps']:
+            sim.step(np.repeat(g['actions'][k][None, :], 3, axis=0))
+    sim.close()
+
+
+def test_gymma_list_api_and_custom_state_fn():
+    from resco_amd import rewards, states
+    from resco_amd.multi_signal import MultiSignal
+
+    def my_state(signals):          # an unmodified states.py-style plugin the registry has never heard of
+        return {sid: np.asarray([s.phase, sum(s.full_observation[l]['queue'] for l in s.lanes),
+                                 len(s.full_observation['num_vehicles'])]) for sid, s in signals.items()}
+
+    env = MultiSignal('t', 'cologne8', None, my_state, rewards.pressure, yellow_length=3, end_time=28800,
+                      log_dir=tempfile.mkdtemp() + os.sep, seed=1, gymma=True)
+    obs = env.reset()
+    assert isinstance(obs, list) and len(obs) == 8 and obs[0].shape == (3,)
+    for _ in range(12):
+        obs, rew, done, info = env.step([0] * 8)
+    assert isinstance(rew, list) and done == [False] and info == {'eps': 1}
+    ref = states.mplight(env.signals)
+    for i, t in enumerate(env.ts_order):
+        assert obs[i][0] == ref[t][0]
+        fo = env.signals[t].full_observation
+        assert obs[i][1] == sum(fo[l]['queue'] for l in env.signals[t].lanes)
+        assert fo['arrivals'] <= fo['num_vehicles']
+        assert set(env.signals[t].waiting_times) <= fo['num_vehicles']
+    env.close()
+
+
+def test_properties_at_baseline_size():
+    """BASELINE config 3 size: ingolstadt21 x 4096 lock-step environments, on-device random policy."""
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('ingolstadt21')
+    N = 4096
+    sim = BatchedSim(sc, N, seed=5)
+    for k in range(12):
+        sim.act_random(k)
+        sim.step(None)
+    sim.sync()
+    st = sim.stats()
+    env = sim.read('env')
+    assert (env[:, 0] == 120).all()
+    assert (st['inserted'] == st['arrived'] + st['active']).all()          # vehicle conservation per env
+    assert (env[:, 1] == st['inserted'] + st['pending']).all()
+    lane = sim.read('veh_lane')
+    assert ((lane < 0xFFFE).sum(axis=1) == st['active']).all()
+    assert len(np.unique(st['active'])) > 8                                  # environments decorrelate
+    pos, spd = sim.read('veh_pos'), sim.read('veh_speed')
+    act = lane < 0xFFFE
+    assert (pos[act] <= sc.lane_len[lane[act]] + 1e-3).all() and (spd[act] >= 0).all()
+    agg = sim.read('lane_agg')
+    q = agg[:, :, 0]
+    mp = sim.read('mplight')
+    ph = sim.read('phase')
+    assert (mp[:, :, 0] == ph).all() and (ph < sc.tls_nphase[None, :]).all()
+    # rewards.pressure == -(sum of own queues - sum of downstream queues): recompute from the aggregates
+    pr = sim.read('pressure')
+    for s in (0, 9, 20):
+        own = q[:, sc.sig_obs_start[s]:sc.sig_obs_start[s + 1]].sum(axis=1)
+        down = q[:, sc.pr_out_idx[sc.pr_out_start[s]:sc.pr_out_start[s + 1]]].sum(axis=1)
+        np.testing.assert_array_equal(pr[:, s], -(own - down).astype(np.int32))
+    np.testing.assert_array_equal(sim.read('wait'), -np.add.reduceat(agg[:, :, 2], sc.sig_obs_start[:-1], axis=1))
+    h = sim.read('drq_norm_f16').astype(np.float32)
+    dn = sim.read('drq_norm')
+    s, o0, o1 = 13, sc.sig_obs_start[13], sc.sig_obs_start[14]
+    np.testing.assert_allclose(h[:, s, :o1 - o0], dn[:, o0:o1], rtol=1e-3, atol=1e-3)
+    assert (h[:, 0, sc.sig_obs_start[1] - sc.sig_obs_start[0]:] == 0).all()         # zero padding
+    sim.close()
+
+
+def test_determinism_sharding_and_snapshot():
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('cologne8')
+    keys = ['lane_agg', 'mplight', 'veh_pos', 'veh_lane', 'veh_rwait', 'wait']
+
+    def run(n, base, steps, sim=None):
+        sim = sim or BatchedSim(sc, n, seed=9, env_base=base)
+        for k in range(steps):
+            sim.act_random(k)
+            sim.step(None)
+        return sim, {k: sim.read(k) for k in keys}
+
+    whole, a = run(64, 0, 30)
+    _, a2 = run(64, 0, 30)
+    lo, b0 = run(32, 0, 30)
+    hi, b1 = run(32, 32, 30)
+    for k in keys:
+        np.testing.assert_array_equal(a[k], a2[k])                                   # same seed -> same batch
+        np.testing.assert_array_equal(a[k], np.concatenate([b0[k], b1[k]]))          # env-batch split == whole
+    snap = whole.snapshot()
+    _, c1 = run(64, 0, 5, whole)
+    whole.restore(snap)
+    for k in keys:
+        np.testing.assert_array_equal(whole.read(k), a[k])
+    _, c2 = run(64, 0, 5, whole)
+    for k in keys:
+        np.testing.assert_array_equal(c1[k], c2[k])
+    whole.free_snapshot(snap)
+
+
+def test_device_random_policy_matches_its_definition():
+    from oracle_batch import hashed_random_actions
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('cologne8')
+    sim = BatchedSim(sc, 6, seed=77, env_base=40)
+    for key in (0, 1, 359, 123456):
+        sim.act_random(key)
+        sim.sync()
+        np.testing.assert_array_equal(sim.read('actions'), hashed_random_actions(sc, 77, 40, 6, key))
+    sim.close()
+
+
+def test_zero_copy_tensors_at_the_agent_boundary():
+    import torch
+    from resco_amd.multi_signal import VecMultiSignal
+    env = VecMultiSignal('cologne1', 1024, states=('drq_norm', 'mplight'), rewards=('pressure', 'wait'), seed=2)
+    obs = env.reset()
+    assert obs['drq_norm'].shape == (1024, 8, 5) and obs['drq_norm'].is_cuda and obs['mplight'].dtype == torch.int32
+    done = False
+    for k in range(20):
+        acts = torch.randint(0, 4, (1024, 1), dtype=torch.int32, device='cuda')
+        torch.cuda.synchronize()
+        obs, rew, done, info = env.step(acts)
+    env.sync()
+    assert not done
+    np.testing.assert_array_equal(obs['mplight'].cpu().numpy(), env.sim.read('mplight'))
+    np.testing.assert_array_equal(rew['pressure'].cpu().numpy(), env.sim.read('pressure'))
+    assert float(rew['wait'].min()) < 0
+    env.close()
