@@ -137,6 +137,7 @@ enum rs_buffer {
     RS_BUF_VEH_OWNER,      /* u8  [N][C]  index of the signal that observed the vehicle last, 0xFF none */
     RS_BUF_STATS,          /* i64 [N][10] see rs_stats */
     RS_BUF_DRQ_NORM_F16,   /* f16 [N][S][Lmax][5] zero padded states.drq_norm (IDQN rollout layout) */
+    RS_BUF_VEH_SF,         /* f32 [N][C]  per-vehicle speedFactor */
     RS_BUF_COUNT
 };
 enum rs_dtype { RS_F32 = 0, RS_I32 = 1, RS_U16 = 2, RS_U8 = 3, RS_F16 = 4, RS_I64 = 5 };

@@ -80,7 +80,7 @@ struct Tab {
 };
 
 struct State {      // env-major SoA in HBM
-    float *pos, *speed, *accel, *tloss;
+    float *pos, *speed, *accel, *tloss, *sf;
     uint16_t *lane, *trip, *cursor, *swait, *rwait, *depart;
     uint8_t *owner;
     int32_t *env;       // [N][4] t, next_trip, hw, reserved
@@ -152,34 +152,92 @@ __device__ __forceinline__ float d_follow_speed(float gap, float vl, float b, fl
     return d_stop_speed(gap + d_brake_gap(vl, bm), b, tau);
 }
 
+// ------------------------------------------------------------------------------------------------ packed tables
+// The step kernel reads the scenario through 16-byte records (one global_load_dwordx4 per lane / link /
+// route step) built by rs_create from the flat rs_scenario arrays.
+struct __attribute__((aligned(16))) LaneRec {
+    float len, vmax;
+    uint16_t link_start;
+    uint8_t link_cnt;
+    uint8_t flags;          // bit0 junction-internal; bits 2..7 number of lanes of the edge
+    int16_t obs;            // observed-lane index or -1
+    uint16_t edge_lane0;
+};
+struct __attribute__((aligned(16))) LinkRec {
+    uint16_t to_lane, to_edge, foe_start, via2;     // via2 0xFFFF: none
+    int16_t arr_idx;                                // approach register of this link (only foe targets have one)
+    uint8_t tls, tls_pos;                           // tls 0xFF: uncontrolled
+    uint8_t foe_cnt, flags;                         // flags bit0 minor, bit1 cont, bit2 to_lane is internal (= via1)
+    uint8_t dest_k, pad;                            // lane index of the destination lane inside to_edge
+};
+struct __attribute__((aligned(8))) FoeRec {
+    int16_t arr_idx;
+    uint8_t tls, tls_pos;
+    uint16_t via1, via2;
+};
+struct __attribute__((aligned(16))) RStep {
+    uint16_t edge, next_edge;       // next_edge 0xFFFF: last edge of the route
+    uint32_t next_mask2, next_mask1;
+    float tlsdist;
+};
+struct __attribute__((aligned(8))) RouteRec {
+    uint32_t start;
+    uint16_t depart_lane;
+    int16_t depart_arr;
+};
+#define LF_INTERNAL 1u
+#define KF_MINOR 1u
+#define KF_CONT 2u
+#define KF_VIA1 4u
+
+struct KTab {
+    const LaneRec *lanes;
+    const LinkRec *links;
+    const FoeRec *foes;
+    const RStep *rsteps;
+    const uint32_t *route_mask2;
+    const RouteRec *routes;
+    const uint16_t *trip_route;
+    const uint8_t *trip_vtype;
+    const int32_t *trip_depart, *trips_cum;
+    const float *vtype_params;
+    const uint8_t *tls8, *fix8;
+    const int32_t *tls_nphase, *tls_ngreen, *tls_nlinks, *tls_state_off, *tls_dur_off, *tls_yel_off, *tls_dur, *tls_yellow;
+    const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_dur;
+    const int32_t *obs_sig, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx, *pr_out_start, *pr_out_idx;
+    int32_t n_lanes, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr;
+};
+
 // ------------------------------------------------------------------------------------------------ LDS view
 struct Lds {
-    float *pos, *speed, *vnx, *sf, *tloss, *vtp;
-    uint16_t *lane, *nxt, *trip, *cursor, *swait, *route;
+    float *pos, *speed, *vnx, *vtp;
+    uint16_t *lane, *nxt, *trip, *rq, *swait, *nlink, *head;
     uint8_t *vt;
-    int32_t *head, *arr;
+    int32_t *arr;
     int32_t *agg_q, *agg_a, *agg_w, *agg_m;
     uint32_t *agg_s;
-    int32_t *phase, *left, *nextp;
-    int32_t *sc;        // scalars: 0 t, 1 next_trip, 2 hw, 3 hw_new, 4.. stats
+    int32_t *phase, *left, *nextp, *tbase;
+    int32_t *sc;        // scalars, see SC_*
 };
 #define SC_T 0
 #define SC_NEXT 1
 #define SC_HW 2
 #define SC_HWNEW 3
-#define SC_STATS 4
+#define SC_NPEND 4
+#define SC_NLC 5
+#define SC_STATS 6
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t lds_bytes_for(int C, int n_lanes, int n_arr, int n_obs, int S, int n_vt) {
     size_t o = 0;
-    o += align16((size_t)C * 4) * 5;                 // pos speed vnx sf tloss
+    o += align16((size_t)C * 4) * 3;                 // pos speed vnx
     o += align16((size_t)n_vt * VT_COLS * 4);        // vtype table
-    o += align16((size_t)C * 2) * 6;                 // lane nxt trip cursor swait route
+    o += align16((size_t)C * 2) * 6;                 // lane nxt trip rq swait nlink
+    o += align16((size_t)(n_lanes + 2) * 2);         // head (u16, CAS on the containing dword)
     o += align16((size_t)C);                         // vt
-    o += align16((size_t)n_lanes * 4);               // head
-    o += align16((size_t)n_arr * 4);                 // arr
+    o += align16((size_t)n_arr * 4);                 // approach / insertion registers
     o += align16((size_t)n_obs * 4) * 5;             // aggregates
-    o += align16((size_t)S * 4) * 3;                 // tls
+    o += align16((size_t)S * 4) * 4;                 // tls
     o += align16((size_t)(SC_STATS + ST_N) * 4);
     return o;
 }
@@ -187,16 +245,17 @@ __device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_lanes
     size_t o = 0;
 #define CARVE(field, type, bytes) L.field = (type *)(base + o); o += align16(bytes);
     CARVE(pos, float, (size_t)C * 4) CARVE(speed, float, (size_t)C * 4) CARVE(vnx, float, (size_t)C * 4)
-    CARVE(sf, float, (size_t)C * 4) CARVE(tloss, float, (size_t)C * 4)
     CARVE(vtp, float, (size_t)n_vt * VT_COLS * 4)
     CARVE(lane, uint16_t, (size_t)C * 2) CARVE(nxt, uint16_t, (size_t)C * 2) CARVE(trip, uint16_t, (size_t)C * 2)
-    CARVE(cursor, uint16_t, (size_t)C * 2) CARVE(swait, uint16_t, (size_t)C * 2) CARVE(route, uint16_t, (size_t)C * 2)
+    CARVE(rq, uint16_t, (size_t)C * 2) CARVE(swait, uint16_t, (size_t)C * 2) CARVE(nlink, uint16_t, (size_t)C * 2)
+    CARVE(head, uint16_t, (size_t)(n_lanes + 2) * 2)
     CARVE(vt, uint8_t, (size_t)C)
-    CARVE(head, int32_t, (size_t)n_lanes * 4) CARVE(arr, int32_t, (size_t)n_arr * 4)
+    CARVE(arr, int32_t, (size_t)n_arr * 4)
     CARVE(agg_q, int32_t, (size_t)n_obs * 4) CARVE(agg_a, int32_t, (size_t)n_obs * 4)
     CARVE(agg_w, int32_t, (size_t)n_obs * 4) CARVE(agg_m, int32_t, (size_t)n_obs * 4)
     CARVE(agg_s, uint32_t, (size_t)n_obs * 4)
     CARVE(phase, int32_t, (size_t)S * 4) CARVE(left, int32_t, (size_t)S * 4) CARVE(nextp, int32_t, (size_t)S * 4)
+    CARVE(tbase, int32_t, (size_t)S * 4)
     CARVE(sc, int32_t, (size_t)(SC_STATS + ST_N) * 4)
 #undef CARVE
 }
@@ -204,7 +263,7 @@ __device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_lanes
 // ------------------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
 
-__device__ __forceinline__ float speed_factor(const Tab &T, const KParams &P, int env, int trip, const float *vt) {
+__device__ __forceinline__ float speed_factor(const KParams &P, int env, int trip, const float *vt) {
     if (!P.speed_dev) return vt[VT_SF_MEAN];
     float s = 0.0f;
 #pragma unroll
@@ -216,41 +275,41 @@ __device__ __forceinline__ float speed_factor(const Tab &T, const KParams &P, in
     return f;
 }
 
-__device__ __forceinline__ int choose_link(const Tab &T, int lane, int route, int cursor) {
-    int ls = T.lane_link_start[lane], lc = T.lane_link_cnt[lane];
+// push slot s on the list of `lane`; returns the previous head.  16-bit heads, exchanged with a CAS on the
+// containing dword (LDS has no 16-bit atomics; a dword holds the heads of two neighbouring lanes)
+__device__ __forceinline__ uint16_t list_push(Lds &L, int lane, int s) {
+    uint32_t *w = (uint32_t *)L.head + (lane >> 1);
+    const int sh = (lane & 1) * 16;
+    uint32_t old = *w, assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(w, assumed, (assumed & ~(0xFFFFu << sh)) | ((uint32_t)s << sh));
+    } while (old != assumed);
+    return (uint16_t)(old >> sh);
+}
+
+// the link a vehicle on `lane` (record LR) takes at route step rq; -1: none (last edge / wrong lane)
+__device__ __forceinline__ int choose_link(const KTab &T, const LaneRec &LR, int rq) {
+    const int ls = LR.link_start, lc = LR.link_cnt;
     if (lc == 0) return -1;
-    if (T.lane_internal[lane]) return ls;
-    int rs = T.route_start[route], rn = T.route_start[route + 1] - rs;
-    if (cursor + 1 >= rn) return -1;
-    int ne = T.route_edge[rs + cursor + 1];
-    uint32_t pref = T.route_mask2[rs + cursor + 1], okm = T.route_mask1[rs + cursor + 1];
-    int l0 = T.edge_lane0[ne];
+    if (LR.flags & LF_INTERNAL) return ls;
+    const RStep R = T.rsteps[rq];
+    if (R.next_edge == 0xFFFF) return -1;
     int best = -1, any = -1;
     for (int l = ls; l < ls + lc; ++l) {
-        if (T.link_to_edge[l] != ne) continue;
-        int k = T.link_dest_lane[l] - l0;
-        if ((pref >> k) & 1u) return l;
-        if (best < 0 && ((okm >> k) & 1u)) best = l;
+        const LinkRec K = T.links[l];
+        if (K.to_edge != R.next_edge) continue;
+        if ((R.next_mask2 >> K.dest_k) & 1u) return l;
+        if (best < 0 && ((R.next_mask1 >> K.dest_k) & 1u)) best = l;
         if (any < 0) any = l;
     }
     return best >= 0 ? best : any;
 }
 
-__device__ __forceinline__ int tls_state(const Tab &T, const Lds &L, const KParams &P, int link) {
-    int s = T.link_tls[link];
-    if (s < 0) return TLS_G;
-    if (P.fixed_program) return T.fix_states[T.fix_state_off[s] + L.phase[s] * T.tls_nlinks[s] + T.link_tls_pos[link]];
-    return T.tls_states[T.tls_state_off[s] + L.phase[s] * T.tls_nlinks[s] + T.link_tls_pos[link]];
-}
-
-__device__ __forceinline__ int depart_lane(const Tab &T, int route) {
-    int rs = T.route_start[route];
-    uint32_t m = T.route_mask2[rs];
-    int e = T.route_edge[rs];
-    int k = 0;
-    while (k < 31 && !((m >> k) & 1u)) k += 1;
-    if (k >= T.edge_nlanes[e]) k = 0;
-    return T.edge_lane0[e] + k;
+__device__ __forceinline__ int tls_state(const KTab &T, const Lds &L, const KParams &P, int tls, int pos) {
+    if (tls == 0xFF) return TLS_G;
+    const uint8_t *tab = P.fixed_program ? T.fix8 : T.tls8;
+    return tab[L.tbase[tls] + pos];
 }
 
 __device__ __forceinline__ int rearmost(const Lds &L, int lane) {
@@ -286,28 +345,29 @@ __device__ __forceinline__ bool lane_has_mover(const Lds &L, int lane) {
     return false;
 }
 
-__device__ __forceinline__ bool foe_blocked(const Tab &T, const Lds &L, const KParams &P, int link) {
-    int fs = T.link_foe_start[link], fc = T.link_foe_cnt[link];
-    for (int i = fs; i < fs + fc; ++i) {
-        int f = T.foe_link[i];
-        if (T.link_tls[f] >= 0 && tls_state(T, L, P, f) == TLS_R) continue;
-        if (L.arr[f] < FOE_GAP_Q) return true;
-        int v1 = T.link_via1[f], v2 = T.link_via2[f];
-        if (v1 >= 0 && lane_has_mover(L, v1)) return true;
-        if (v2 >= 0 && lane_has_mover(L, v2)) return true;
+__device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const KParams &P, const LinkRec &K) {
+    for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
+        const FoeRec F = T.foes[i];
+        if (F.tls != 0xFF && tls_state(T, L, P, F.tls, F.tls_pos) == TLS_R) continue;
+        if (F.arr_idx >= 0 && L.arr[F.arr_idx] < FOE_GAP_Q) return true;
+        if (F.via1 != 0xFFFF && lane_has_mover(L, F.via1)) return true;
+        if (F.via2 != 0xFFFF && lane_has_mover(L, F.via2)) return true;
     }
     return false;
 }
 
-__device__ __forceinline__ void set_phase(const Tab &T, Lds &L, int s, int ph) {
+__device__ __forceinline__ void set_phase(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
     if (ph < 0 || ph >= T.tls_nphase[s]) return;
     L.phase[s] = ph;
     L.left[s] = T.tls_dur[T.tls_dur_off[s] + ph];
+    L.tbase[s] = T.tls_state_off[s] + ph * T.tls_nlinks[s];
 }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
-// grid = n_envs workgroups; blockDim.x = 64 * waves.  Dynamic LDS = lds_bytes_for(...).
-extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
+// grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 512).
+// __launch_bounds__(512, 8): <= 64 VGPRs so that four 512-thread workgroups (32 waves) share a CU.
+extern "C" __global__ void __launch_bounds__(512, 8)
+rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int env = blockIdx.x;
     if (env >= P.n_envs) return;
@@ -321,28 +381,34 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
     // ---- load the environment slab (once per env-step)
     if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 3 ? G.env[env * 4 + tid] : 0;
     for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.vtype_params[i];
-    for (int i = tid; i < T.n_lanes; i += B) L.head[i] = NIL;
+    for (int i = tid; i < (T.n_lanes + 2) / 2; i += B) ((uint32_t *)L.head)[i] = 0xFFFFFFFFu;
     for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
     for (int i = tid; i < S; i += B) {
-        L.phase[i] = G.tls[(env * S + i) * 3 + 0];
+        int ph = G.tls[(env * S + i) * 3 + 0];
+        L.phase[i] = ph;
         L.left[i] = G.tls[(env * S + i) * 3 + 1];
         L.nextp[i] = G.tls[(env * S + i) * 3 + 2];
+        L.tbase[i] = (P.fixed_program ? T.fix_state_off[i] : T.tls_state_off[i]) + ph * T.tls_nlinks[i];
     }
     __syncthreads();
     {
         const int hw0 = L.sc[SC_HW];
+        int npend = 0;
         for (int s = tid; s < C; s += B) {
             uint16_t ln = LANE_NONE, tr = 0xFFFF;
             if (s < hw0) { ln = G.lane[eo + s]; tr = G.trip[eo + s]; }
             L.lane[s] = ln; L.trip[s] = tr;
             if (ln != LANE_NONE) {
-                L.pos[s] = G.pos[eo + s]; L.speed[s] = G.speed[eo + s]; L.tloss[s] = G.tloss[eo + s];
-                L.cursor[s] = G.cursor[eo + s]; L.swait[s] = G.swait[eo + s];
-                int v = T.trip_vtype[tr];
-                L.vt[s] = (uint8_t)v; L.route[s] = (uint16_t)T.trip_route[tr];
-                L.sf[s] = speed_factor(T, P, genv, tr, T.vtype_params + v * VT_COLS);
+                L.pos[s] = G.pos[eo + s]; L.speed[s] = G.speed[eo + s]; L.swait[s] = G.swait[eo + s];
+                const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor[eo + s];
+                L.rq[s] = (uint16_t)rq;
+                L.vt[s] = T.trip_vtype[tr];
+                int nl = -1;
+                if (ln != LANE_PENDING) nl = choose_link(T, T.lanes[ln], rq); else npend += 1;
+                L.nlink[s] = (uint16_t)nl;
             }
         }
+        if (npend) atomicAdd(&L.sc[SC_NPEND], npend);
     }
     // ---- Signal.prep_phase for every signal (traffic_signal.py:176-184)
     if (P.do_fsm && !P.fixed_program) {
@@ -352,15 +418,14 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
             L.nextp[s] = a;
             if (cur != a && cur < Gn && a < Gn) {
                 int y = T.tls_yellow[T.tls_yel_off[s] + cur * Gn + a];
-                if (y >= 0) set_phase(T, L, s, y);
+                if (y >= 0) set_phase(T, L, P, s, y);
             }
         }
     }
     __syncthreads();
-    // lists for the state we loaded
     for (int s = tid; s < L.sc[SC_HW]; s += B) {
         int ln = L.lane[s];
-        if (ln < LANE_PENDING) L.nxt[s] = (uint16_t)atomicExch(&L.head[ln], s);
+        if (ln < LANE_PENDING) L.nxt[s] = list_push(L, ln, s);
     }
     __syncthreads();
 
@@ -368,112 +433,127 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
         const int t = L.sc[SC_T];
         // ---- Signal.set_phase after the yellow ticks (traffic_signal.py:186-187)
         if (P.do_fsm && !P.fixed_program && tick == T.yellow_length) {
-            for (int s = tid; s < S; s += B) set_phase(T, L, s, L.nextp[s]);
+            for (int s = tid; s < S; s += B) set_phase(T, L, P, s, L.nextp[s]);
             __syncthreads();
         }
         // ---- P0: TLS switch events at the beginning of the tick
         for (int s = tid; s < S; s += B) {
-            const int32_t *dur = P.fixed_program ? T.fix_dur + T.fix_dur_off[s] : T.tls_dur + T.tls_dur_off[s];
-            int Pn = P.fixed_program ? T.fix_nphase[s] : T.tls_nphase[s];
-            int left = L.left[s], ph = L.phase[s];
-            if (left == 0) { ph = (ph + 1) % Pn; left = dur[ph]; L.phase[s] = ph; }
+            int left = L.left[s];
+            if (left == 0) {
+                const int32_t *dur = P.fixed_program ? T.fix_dur + T.fix_dur_off[s] : T.tls_dur + T.tls_dur_off[s];
+                const int Pn = P.fixed_program ? T.fix_nphase[s] : T.tls_nphase[s];
+                const int ph = (L.phase[s] + 1) % Pn;
+                left = dur[ph];
+                L.phase[s] = ph;
+                L.tbase[s] = (P.fixed_program ? T.fix_state_off[s] : T.tls_state_off[s]) + ph * T.tls_nlinks[s];
+            }
             L.left[s] = left - 1;
         }
         // ---- P2a: departed trips take the lowest free slots in trip order (wave 0 only)
         {
-            int hz = t - 1 <= T.horizon ? t - 1 : T.horizon;
-            int due = t >= 1 ? T.trips_cum[hz] : 0;
-            int nt = L.sc[SC_NEXT];
-            int m = due - nt;
+            const int hz = t - 1 <= T.horizon ? t - 1 : T.horizon;
+            const int due = t >= 1 ? T.trips_cum[hz] : 0;
+            const int nt = L.sc[SC_NEXT];
+            const int m = due - nt;
             if (m > 0 && tid < 64) {
                 int base = 0;
                 for (int c0 = 0; c0 < C && base < m; c0 += 64) {
-                    int s = c0 + tid;
-                    bool fr = L.lane[s] == LANE_NONE;
-                    unsigned long long mask = __ballot(fr);
-                    int rank = __popcll(mask & ((1ull << tid) - 1ull));
+                    const int s = c0 + tid;
+                    const bool fr = L.lane[s] == LANE_NONE;
+                    const unsigned long long mask = __ballot(fr);
+                    const int rank = __popcll(mask & ((1ull << tid) - 1ull));
                     if (fr && base + rank < m) {
-                        int k = nt + base + rank;
-                        int v = T.trip_vtype[k];
+                        const int k = nt + base + rank;
+                        const int v = T.trip_vtype[k];
                         L.trip[s] = (uint16_t)k; L.lane[s] = LANE_PENDING;
-                        L.pos[s] = 0.0f; L.speed[s] = 0.0f; L.tloss[s] = 0.0f; L.cursor[s] = 0; L.swait[s] = 0;
-                        L.vt[s] = (uint8_t)v; L.route[s] = (uint16_t)T.trip_route[k];
-                        L.sf[s] = speed_factor(T, P, genv, k, T.vtype_params + v * VT_COLS);
+                        L.pos[s] = 0.0f; L.speed[s] = 0.0f; L.swait[s] = 0; L.nlink[s] = 0xFFFF;
+                        L.vt[s] = (uint8_t)v; L.rq[s] = (uint16_t)T.routes[T.trip_route[k]].start;
+                        G.sf[eo + s] = speed_factor(P, genv, k, T.vtype_params + v * VT_COLS);
+                        G.tloss[eo + s] = 0.0f;
                         G.rwait[eo + s] = 0; G.owner[eo + s] = OWNER_NONE; G.depart[eo + s] = 0; G.accel[eo + s] = 0.0f;
                         atomicMax(&L.sc[SC_HW], s + 1);
                     }
                     base += __popcll(mask);
                 }
-                if (tid == 0) L.sc[SC_NEXT] = nt + (base < m ? base : m);
+                if (tid == 0) { const int got = base < m ? base : m; L.sc[SC_NEXT] = nt + got; L.sc[SC_NPEND] += got; }
             }
         }
         __syncthreads();
-        const int hw = L.sc[SC_HW];
-        // ---- P2b: lowest pending trip per departure lane is the insertion candidate
-        for (int s = tid; s < hw; s += B)
-            if (L.lane[s] == LANE_PENDING) atomicMin(&L.arr[depart_lane(T, L.route[s])], (int)L.trip[s]);
-        __syncthreads();
-        // ---- P2c: candidates check the space on their lane
-        for (int s = tid; s < hw; s += B) {
-            if (L.lane[s] != LANE_PENDING) continue;
-            int k = L.trip[s];
-            int dl = depart_lane(T, L.route[s]);
-            bool ins = false;
-            float mypos = 0.0f;
-            if (L.arr[dl] == k) {
-                const float *vt = L.vtp + L.vt[s] * VT_COLS;
-                float ll = T.lane_len[dl];
-                mypos = vt[VT_LENGTH] < ll ? vt[VT_LENGTH] : ll;
-                ins = true;
-                for (int o = L.head[dl]; o != NIL; o = L.nxt[o]) {
-                    float back = L.pos[o] - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
-                    if (back - mypos - vt[VT_MINGAP] < 0.0f) ins = false;
+        int hw = L.sc[SC_HW];
+        if (L.sc[SC_NPEND] > 0) {       // block-uniform: the insertion phases only run while something is pending
+            // ---- P2b: lowest pending trip per departure lane is the insertion candidate
+            for (int s = tid; s < hw; s += B)
+                if (L.lane[s] == LANE_PENDING) atomicMin(&L.arr[T.routes[T.trip_route[L.trip[s]]].depart_arr], (int)L.trip[s]);
+            __syncthreads();
+            // ---- P2c: candidates check the space on their lane
+            for (int s = tid; s < hw; s += B) {
+                if (L.lane[s] != LANE_PENDING) continue;
+                const int k = L.trip[s];
+                const RouteRec RR = T.routes[T.trip_route[k]];
+                bool ins = false;
+                float mypos = 0.0f;
+                if (L.arr[RR.depart_arr] == k) {
+                    const float *vt = L.vtp + L.vt[s] * VT_COLS;
+                    const float ll = T.lanes[RR.depart_lane].len;
+                    mypos = vt[VT_LENGTH] < ll ? vt[VT_LENGTH] : ll;
+                    ins = true;
+                    for (int o = L.head[RR.depart_lane]; o != NIL; o = L.nxt[o]) {
+                        float back = L.pos[o] - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
+                        if (back - mypos - vt[VT_MINGAP] < 0.0f) ins = false;
+                    }
                 }
+                L.vnx[s] = ins ? mypos : -1.0f;
             }
-            L.vnx[s] = ins ? mypos : -1.0f;
+            __syncthreads();
+            // ---- P2d: apply insertions, reset the candidate registers
+            for (int s = tid; s < hw; s += B) {
+                if (L.lane[s] != LANE_PENDING) continue;
+                const int k = L.trip[s];
+                const RouteRec RR = T.routes[T.trip_route[k]];
+                L.arr[RR.depart_arr] = ARR_NONE;
+                if (L.vnx[s] < 0.0f) continue;
+                const int dl = RR.depart_lane;
+                L.lane[s] = (uint16_t)dl; L.pos[s] = L.vnx[s]; L.speed[s] = 0.0f;
+                L.nlink[s] = (uint16_t)choose_link(T, T.lanes[dl], RR.start);
+                G.depart[eo + s] = (uint16_t)t;
+                L.nxt[s] = list_push(L, dl, s);
+                atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
+                atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.trip_depart[k]);
+                atomicSub(&L.sc[SC_NPEND], 1);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // ---- P2d: apply insertions, reset the candidate table
+        // ---- P3: vehicles that will pass a link somebody may have to yield to register their arrival time
         for (int s = tid; s < hw; s += B) {
-            if (L.lane[s] != LANE_PENDING) continue;
-            int dl = depart_lane(T, L.route[s]);
-            L.arr[dl] = ARR_NONE;
-            if (L.vnx[s] < 0.0f) continue;
-            L.lane[s] = (uint16_t)dl; L.pos[s] = L.vnx[s]; L.speed[s] = 0.0f; L.cursor[s] = 0;
-            G.depart[eo + s] = (uint16_t)t;
-            L.nxt[s] = (uint16_t)atomicExch(&L.head[dl], s);
-            atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
-            atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.trip_depart[L.trip[s]]);
-        }
-        __syncthreads();
-        // ---- P3: vehicles that will pass their next link register an arrival-time estimate on it
-        for (int s = tid; s < hw; s += B) {
-            int lane = L.lane[s];
+            const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
-            int link = choose_link(T, lane, L.route[s], L.cursor[s]);
-            if (link < 0) continue;
-            float v = L.speed[s];
+            const int link = L.nlink[s];
+            if (link == 0xFFFF) continue;
+            const float v = L.speed[s];
             if (v <= HALT_SPEED) continue;
-            int st = tls_state(T, L, P, link);
+            const LinkRec K = T.links[link];
+            if (K.arr_idx < 0) continue;
+            const int st = tls_state(T, L, P, K.tls, K.tls_pos);
             if (st == TLS_R) continue;
-            float dist = T.lane_len[lane] - L.pos[s];
+            const float dist = T.lanes[lane].len - L.pos[s];
             if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) continue;
-            float ta = dist / (v > 1.0f ? v : 1.0f);
-            int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
-            atomicMin(&L.arr[link], q);
+            const float ta = dist / (v > 1.0f ? v : 1.0f);
+            const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
+            atomicMin(&L.arr[K.arr_idx], q);
         }
         __syncthreads();
         // ---- P4: plan (Krauss car-following + links)
         for (int s = tid; s < hw; s += B) {
-            int lane = L.lane[s];
+            const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
             const int k = L.trip[s];
             const float *vt = L.vtp + L.vt[s] * VT_COLS;
             const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
-            const int route = L.route[s], cursor = L.cursor[s];
             const float v = L.speed[s], x = L.pos[s];
+            const float sf = G.sf[eo + s];
+            LaneRec LR = T.lanes[lane];
             float vfree = v + a;
-            float vl = T.lane_vmax[lane] * L.sf[s];
+            const float vl = LR.vmax * sf;
             if (vl < vfree) vfree = vl;
             if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
             float vsafe = BIGF;
@@ -486,29 +566,30 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
                 vsafe = d_follow_speed(gap, L.speed[lead], b, vo[VT_DECEL], tau);
                 found = true;
             }
-            float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
-            float seen = T.lane_len[lane] - x;
-            int cur = lane, cur_cursor = cursor;
-            const int rn = T.route_start[route + 1] - T.route_start[route];
+            const float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
+            float seen = LR.len - x;
+            int rq = L.rq[s];
+            int link = (int)L.nlink[s];
+            if (link == 0xFFFF) link = -1;
             for (int hop = 0; hop < MAX_HOPS && !found && seen < look; ++hop) {
-                const bool cur_int = T.lane_internal[cur] != 0;
-                if (!cur_int && cur_cursor + 1 >= rn) break;
-                int link = choose_link(T, cur, route, cur_cursor);
+                const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
+                if (hop > 0) link = choose_link(T, LR, rq);
                 if (link < 0) {
+                    // last edge of the route: free run to its end; otherwise wrong lane: wait for a lane change
+                    if (!cur_int && T.rsteps[rq].next_edge == 0xFFFF) break;
                     float g = seen - STOP_OFFSET;
                     float vs = d_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
                     if (vs < vsafe) vsafe = vs;
                     break;
                 }
-                int st = tls_state(T, L, P, link);
-                const int ltls = T.link_tls[link];
+                const LinkRec K = T.links[link];
+                const int st = tls_state(T, L, P, K.tls, K.tls_pos);
                 bool stop_here = false;
-                if (ltls >= 0 && (st == TLS_R || st == TLS_Y)) {
+                if (K.tls != 0xFF && (st == TLS_R || st == TLS_Y)) {
                     if (seen >= d_brake_gap(v, b)) stop_here = true;
                 }
-                if (!stop_here && !T.link_cont[link] && T.link_foe_cnt[link] > 0 &&
-                    (T.link_minor[link] || (ltls >= 0 && st == TLS_g))) {
-                    if (foe_blocked(T, L, P, link)) stop_here = true;
+                if (!stop_here && !(K.flags & KF_CONT) && K.foe_cnt > 0 && ((K.flags & KF_MINOR) || (K.tls != 0xFF && st == TLS_g))) {
+                    if (foe_blocked(T, L, P, K)) stop_here = true;
                 }
                 if (stop_here) {
                     float g = seen - STOP_OFFSET;
@@ -516,15 +597,16 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
                     if (vs < vsafe) vsafe = vs;
                     break;
                 }
-                int nl = T.link_to_lane[link];
+                const int nl = K.to_lane;
+                LR = T.lanes[nl];
                 {   // slow down in time for a lower speed limit on the next lane
-                    float vnl = T.lane_vmax[nl] * L.sf[s];
+                    float vnl = LR.vmax * sf;
                     if (vnl < vfree) {
                         float vs = d_free_speed(seen, vnl, b);
                         if (vs < vsafe) vsafe = vs;
                     }
                 }
-                int o = rearmost(L, nl);
+                const int o = rearmost(L, nl);
                 if (o != NIL) {
                     const float *vo = L.vtp + L.vt[o] * VT_COLS;
                     float gap = seen + L.pos[o] - vo[VT_LENGTH] - mingap;
@@ -533,108 +615,106 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
                     found = true;
                     break;
                 }
-                if (!cur_int) cur_cursor += 1;
-                seen += T.lane_len[nl];
-                cur = nl;
+                if (!cur_int) rq += 1;
+                seen += LR.len;
             }
             float vmin_n = v - b; if (vmin_n < 0.0f) vmin_n = 0.0f;
             float vmin_e = v - vt[VT_EMERGENCY]; if (vmin_e < 0.0f) vmin_e = 0.0f;
-            float lo = vsafe > vmin_e ? vsafe : vmin_e;
-            float vmin = vmin_n < lo ? vmin_n : lo;
+            const float lo = vsafe > vmin_e ? vsafe : vmin_e;
+            const float vmin = vmin_n < lo ? vmin_n : lo;
             float vmax = vfree < vsafe ? vfree : vsafe;
             if (vmax < vmin) vmax = vmin;
-            float sigma = P.sigma >= 0.0f ? P.sigma : vt[VT_SIGMA];
+            const float sigma = P.sigma >= 0.0f ? P.sigma : vt[VT_SIGMA];
             float vd = vmax;
             if (sigma > 0.0f) {
-                float r = d_u01(d_hash(P.seed, (uint32_t)genv, (uint32_t)k, (uint32_t)t, 0u));
+                const float r = d_u01(d_hash(P.seed, (uint32_t)genv, (uint32_t)k, (uint32_t)t, 0u));
                 if (vd < a) vd -= sigma * vd * r; else vd -= sigma * a * r;
                 if (vd < 0.0f) vd = 0.0f;
             }
             L.vnx[s] = vd > vmin ? vd : vmin;
         }
         __syncthreads();
-        // ---- P5: move (and drop this tick's approach registrations, clear the list heads)
-        if (tid == 0) L.sc[SC_HWNEW] = 0;
-        for (int s = tid; s < hw; s += B) {
-            int lane = L.lane[s];
-            if (lane >= LANE_PENDING) continue;
-            int lk = choose_link(T, lane, L.route[s], L.cursor[s]);
-            if (lk >= 0) L.arr[lk] = ARR_NONE;
-        }
-        for (int i = tid; i < T.n_lanes; i += B) L.head[i] = NIL;
+        // ---- P5: move; drop this tick's approach registrations; clear the list heads (nobody reads them here)
+        if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_NLC] = 0; }
+        for (int i = tid; i < (T.n_lanes + 2) / 2; i += B) ((uint32_t *)L.head)[i] = 0xFFFFFFFFu;
         __syncthreads();
         {
-            int active = 0, halted = 0;
+            int active = 0, halted = 0, top = 0;
             for (int s = tid; s < hw; s += B) {
                 int lane = L.lane[s];
                 if (lane == LANE_NONE) continue;
-                if (lane == LANE_PENDING) { atomicMax(&L.sc[SC_HWNEW], s + 1); continue; }
-                const int route = L.route[s];
-                const int rn = T.route_start[route + 1] - T.route_start[route];
+                if (lane == LANE_PENDING) { top = s + 1; continue; }
+                int link = (int)L.nlink[s];
+                if (link == 0xFFFF) link = -1;
+                if (link >= 0) { const int ai = T.links[link].arr_idx; if (ai >= 0) L.arr[ai] = ARR_NONE; }
+                LaneRec LR = T.lanes[lane];
                 const float vn = L.vnx[s];
-                const float vref = T.lane_vmax[lane] * L.sf[s];
+                const float vref = LR.vmax * G.sf[eo + s];
                 if (tick == P.n_ticks - 1) G.accel[eo + s] = vn - L.speed[s];
                 L.speed[s] = vn;
                 if (vn <= HALT_SPEED) { int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1); halted += 1; }
                 else L.swait[s] = 0;
-                if (vref > 0.0f && vn < vref) L.tloss[s] += (vref - vn) / vref;
+                float tl = G.tloss[eo + s];
+                if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss[eo + s] = tl; }
                 float x = L.pos[s] + vn;
-                int cursor = L.cursor[s];
-                bool arrived = false;
+                int rq = L.rq[s];
+                bool arrived = false, moved = false;
                 for (int it = 0; it < 16; ++it) {
-                    float len = T.lane_len[lane];
-                    if (!(x > len)) break;
-                    const bool li = T.lane_internal[lane] != 0;
-                    if (!li && cursor + 1 >= rn) { arrived = true; break; }
-                    int link = choose_link(T, lane, route, cursor);
-                    if (link < 0) { x = len; break; }
-                    x -= len;
-                    if (!li) cursor += 1;
-                    lane = T.link_to_lane[link];
+                    if (!(x > LR.len)) break;
+                    const bool li = (LR.flags & LF_INTERNAL) != 0;
+                    if (moved) link = choose_link(T, LR, rq);
+                    if (link < 0) {
+                        if (!li && T.rsteps[rq].next_edge == 0xFFFF) arrived = true; else x = LR.len;
+                        break;
+                    }
+                    x -= LR.len;
+                    if (!li) rq += 1;
+                    lane = T.links[link].to_lane;
+                    LR = T.lanes[lane];
+                    moved = true;
                 }
                 if (arrived) {
                     L.lane[s] = LANE_NONE; L.trip[s] = 0xFFFF;
                     G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0;
                     atomicAdd(&L.sc[SC_STATS + ST_ARRIVED], 1);
                     atomicAdd(&L.sc[SC_STATS + ST_DURATION], t + 1 - (int)G.depart[eo + s]);
-                    atomicAdd(&L.sc[SC_STATS + ST_TLOSS], (int)(L.tloss[s] * 1024.0f + 0.5f));
+                    atomicAdd(&L.sc[SC_STATS + ST_TLOSS], (int)(tl * 1024.0f + 0.5f));
                 } else {
-                    L.lane[s] = (uint16_t)lane; L.cursor[s] = (uint16_t)cursor; L.pos[s] = x;
+                    L.pos[s] = x;
+                    if (moved) {
+                        L.lane[s] = (uint16_t)lane; L.rq[s] = (uint16_t)rq;
+                        L.nlink[s] = (uint16_t)choose_link(T, LR, rq);
+                    }
                     active += 1;
-                    atomicMax(&L.sc[SC_HWNEW], s + 1);
+                    top = s + 1;
+                    L.nxt[s] = list_push(L, lane, s);        // P6 fused: the heads were cleared before the barrier
                 }
             }
             if (active) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
             if (halted) atomicAdd(&L.sc[SC_STATS + ST_WAITING], halted);
-        }
-        __syncthreads();
-        // ---- P6: lists of the moved state
-        const int hw2 = L.sc[SC_HWNEW];
-        for (int s = tid; s < hw2; s += B) {
-            int ln = L.lane[s];
-            if (ln < LANE_PENDING) L.nxt[s] = (uint16_t)atomicExch(&L.head[ln], s);
+            if (top) atomicMax(&L.sc[SC_HWNEW], top);
         }
         __syncthreads();
         // ---- P7a: lane-change decisions (all changes of a tick go the same way: left on even ticks)
+        const int hw2 = L.sc[SC_HWNEW];
         const int dir_allowed = (t & 1) ? -1 : +1;
         for (int s = tid; s < hw2; s += B) {
             int target = -1;
-            int lane = L.lane[s];
-            if (lane < LANE_PENDING && !T.lane_internal[lane]) {
-                const int ed = T.lane_edge[lane];
-                const int n = T.edge_nlanes[ed];
-                const int l0 = T.edge_lane0[ed];
+            const int lane = L.lane[s];
+            if (lane < LANE_PENDING) {
+                const LaneRec LR = T.lanes[lane];
+                const int n = LR.flags >> 2;
+                const int l0 = LR.edge_lane0;
                 const int kk = lane - l0;
                 const int tk = kk + dir_allowed;
-                if (n >= 2 && tk >= 0 && tk < n) {
+                if (!(LR.flags & LF_INTERNAL) && n >= 2 && tk >= 0 && tk < n) {
                     const int k = L.trip[s];
-                    const uint32_t m2 = T.route_mask2[T.route_start[L.route[s]] + L.cursor[s]];
+                    const uint32_t m2 = T.route_mask2[L.rq[s]];
                     const float *vt = L.vtp + L.vt[s] * VT_COLS;
                     const float x = L.pos[s], v = L.speed[s];
                     const int tl = l0 + tk;
                     int want = 0;
-                    int lead_t, foll_t;
-                    neighbours(L, tl, x, k, s, lead_t, foll_t);
+                    int lead_t = NIL, foll_t = NIL;
                     if (!((m2 >> kk) & 1u)) {
                         int dl = 1000, dr = 1000;
                         for (int j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
@@ -642,10 +722,12 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
                         int dir = 0;
                         if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
                         want = (dir == dir_allowed) ? 2 : 0;
+                        if (want) neighbours(L, tl, x, k, s, lead_t, foll_t);
                     } else if ((m2 >> tk) & 1u) {
                         int lead_c, foll_c;
                         neighbours(L, lane, x, k, s, lead_c, foll_c);
                         if (lead_c != NIL) {
+                            neighbours(L, tl, x, k, s, lead_t, foll_t);
                             float gcur = L.pos[lead_c] - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
                             float gtgt = BIGF;
                             if (lead_t != NIL) gtgt = L.pos[lead_t] - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
@@ -653,7 +735,7 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
                         }
                     }
                     if (want) {
-                        const bool urgent = want == 2 && (T.lane_len[lane] - x) <= URGENT_DIST;
+                        const bool urgent = want == 2 && (LR.len - x) <= URGENT_DIST;
                         bool safe = true;
                         if (lead_t != NIL) {
                             const float *vo = L.vtp + L.vt[lead_t] * VT_COLS;
@@ -674,59 +756,80 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
                 }
             }
             L.vnx[s] = __int_as_float(target);
-        }
-        __syncthreads();
-        // ---- P7b: apply the lane changes, rebuild the lists for the next tick
-        for (int i = tid; i < T.n_lanes; i += B) L.head[i] = NIL;
-        for (int s = tid; s < hw2; s += B) {
-            int target = __float_as_int(L.vnx[s]);
-            if (L.lane[s] < LANE_PENDING && target >= 0) L.lane[s] = (uint16_t)target;
+            if (target >= 0) L.sc[SC_NLC] = 1;
         }
         if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
         __syncthreads();
-        for (int s = tid; s < hw2; s += B) {
-            int ln = L.lane[s];
-            if (ln < LANE_PENDING) L.nxt[s] = (uint16_t)atomicExch(&L.head[ln], s);
+        // ---- P7b: only when somebody changes lane: apply, rebuild the lists
+        if (L.sc[SC_NLC]) {
+            for (int i = tid; i < (T.n_lanes + 2) / 2; i += B) ((uint32_t *)L.head)[i] = 0xFFFFFFFFu;
+            for (int s = tid; s < hw2; s += B) {
+                const int target = __float_as_int(L.vnx[s]);
+                if (L.lane[s] < LANE_PENDING && target >= 0) {
+                    L.lane[s] = (uint16_t)target;
+                    L.nlink[s] = (uint16_t)choose_link(T, T.lanes[target], L.rq[s]);
+                }
+            }
+            __syncthreads();
+            for (int s = tid; s < hw2; s += B) {
+                const int ln = L.lane[s];
+                if (ln < LANE_PENDING) L.nxt[s] = list_push(L, ln, s);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- Signal.observe for every signal (traffic_signal.py:189-247)
     for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
     __syncthreads();
     const int hwf = L.sc[SC_HW];
-    for (int s = tid; s < hwf; s += B) {
-        int lane = L.lane[s];
-        if (lane >= LANE_PENDING) continue;
-        int oi = T.lane_obs[lane];
-        bool detect = false;
-        if (oi >= 0) {
-            float d = (T.lane_len[lane] - L.pos[s]) + T.route_tlsdist[T.route_start[L.route[s]] + L.cursor[s]];
-            detect = d <= P.max_distance;
+    {
+        const int hw0 = G.env[env * 4 + 2];
+        const int top = hwf > hw0 ? hwf : hw0;
+        int act = 0, pend = 0;
+        for (int s = tid; s < top; s += B) {
+            const int lane = L.lane[s];
+            G.lane[eo + s] = (uint16_t)lane; G.trip[eo + s] = L.trip[s];
+            if (lane == LANE_NONE) continue;
+            // store the slab back (once per env-step)
+            const int rq = L.rq[s];
+            G.pos[eo + s] = L.pos[s]; G.speed[eo + s] = L.speed[s]; G.swait[eo + s] = L.swait[s];
+            G.cursor[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.trip[s]]].start);
+            if (lane == LANE_PENDING) { pend += 1; continue; }
+            act += 1;
+            const LaneRec LR = T.lanes[lane];
+            const int oi = LR.obs;
+            bool detect = false;
+            if (oi >= 0) {
+                float d = (LR.len - L.pos[s]) + T.rsteps[rq].tlsdist;
+                detect = d <= P.max_distance;
+            }
+            if (!detect) { G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0; continue; }
+            const int sig = T.obs_sig[oi];
+            int rw = G.rwait[eo + s];
+            if (G.owner[eo + s] != (uint8_t)sig) rw = 0;
+            if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
+            else if (L.swait[s] > 0) rw = L.swait[s];
+            G.rwait[eo + s] = (uint16_t)rw;
+            G.owner[eo + s] = (uint8_t)sig;
+            if (rw > 0) { atomicAdd(&L.agg_q[oi], 1); atomicAdd(&L.agg_w[oi], rw); atomicMax(&L.agg_m[oi], rw); }
+            else atomicAdd(&L.agg_a[oi], 1);
+            atomicAdd(&L.agg_s[oi], (uint32_t)(L.speed[s] * 65536.0f + 0.5f));
         }
-        if (!detect) { G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0; continue; }
-        int sig = T.obs_sig[oi];
-        int rw = G.rwait[eo + s];
-        if (G.owner[eo + s] != (uint8_t)sig) rw = 0;
-        if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
-        else if (L.swait[s] > 0) rw = L.swait[s];
-        G.rwait[eo + s] = (uint16_t)rw;
-        G.owner[eo + s] = (uint8_t)sig;
-        if (rw > 0) { atomicAdd(&L.agg_q[oi], 1); atomicAdd(&L.agg_w[oi], rw); atomicMax(&L.agg_m[oi], rw); }
-        else atomicAdd(&L.agg_a[oi], 1);
-        atomicAdd(&L.agg_s[oi], (uint32_t)(L.speed[s] * 65536.0f + 0.5f));
+        if (act) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE], act);
+        if (pend) atomicAdd(&L.sc[SC_STATS + ST_PENDING], pend);
     }
     __syncthreads();
     // per observed lane rows
     for (int oi = tid; oi < NO; oi += B) {
-        int sg = T.obs_sig[oi];
-        int o0 = T.sig_obs_start[sg];
-        int ph = L.phase[sg];
-        float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
-        float q = (float)L.agg_q[oi], ap = (float)L.agg_a[oi], w = (float)L.agg_w[oi];
+        const int sg = T.obs_sig[oi];
+        const int o0 = T.sig_obs_start[sg];
+        const int ph = L.phase[sg];
+        const float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
+        const float q = (float)L.agg_q[oi], ap = (float)L.agg_a[oi], w = (float)L.agg_w[oi];
         float *la = O.lane_agg + ((size_t)env * NO + oi) * 5;
         la[0] = q; la[1] = ap; la[2] = w; la[3] = (float)L.agg_m[oi]; la[4] = sp;
-        float d0 = (oi - o0) == ph ? 1.0f : 0.0f, d1 = ap / 28.0f, d2 = w / 28.0f, d3 = q / 28.0f, d4 = sp / 20.0f / 28.0f;
+        const float d0 = (oi - o0) == ph ? 1.0f : 0.0f, d1 = ap / 28.0f, d2 = w / 28.0f, d3 = q / 28.0f, d4 = sp / 20.0f / 28.0f;
         float *dn = O.drq_norm + ((size_t)env * NO + oi) * 5;
         dn[0] = d0; dn[1] = d1; dn[2] = d2; dn[3] = d3; dn[4] = d4;
         __half *dh = O.drq_f16 + (((size_t)env * S + sg) * T.lmax + (oi - o0)) * 5;
@@ -734,14 +837,14 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
     }
     // per signal: state vectors and rewards
     for (int sg = tid; sg < S; sg += B) {
-        int ph = L.phase[sg];
-        int o0 = T.sig_obs_start[sg], o1 = T.sig_obs_start[sg + 1];
+        const int ph = L.phase[sg];
+        const int o0 = T.sig_obs_start[sg], o1 = T.sig_obs_start[sg + 1];
         int tw = 0, tq = 0, mq = 0;
         for (int oi = o0; oi < o1; ++oi) { tw += L.agg_w[oi]; int qq = L.agg_q[oi]; tq += qq; if (qq > mq) mq = qq; }
-        size_t so = (size_t)env * S + sg;
+        const size_t so = (size_t)env * S + sg;
         O.phase[so] = ph; O.queue_sum[so] = tq; O.queue_max[so] = mq;
         O.wait[so] = -(float)tw;
-        float wn = -(float)tw / 224.0f;
+        const float wn = -(float)tw / 224.0f;
         O.wait_norm[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
         int pr = tq;
         for (int i = T.pr_out_start[sg]; i < T.pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.pr_out_idx[i]];
@@ -750,7 +853,7 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
         for (int m = 0; m < 12; ++m) {
             int q = 0, wv = 0;
             for (int i = T.mv_in_start[sg * 12 + m]; i < T.mv_in_start[sg * 12 + m + 1]; ++i) {
-                int oi = T.mv_in_idx[i];
+                const int oi = T.mv_in_idx[i];
                 q += L.agg_q[oi]; wv += L.agg_q[oi] + L.agg_a[oi];
             }
             for (int i = T.mv_out_start[sg * 12 + m]; i < T.mv_out_start[sg * 12 + m + 1]; ++i) q -= L.agg_q[T.mv_out_idx[i]];
@@ -760,23 +863,6 @@ extern "C" __global__ void rs_step_kernel(Tab T, State G, Out O, KParams P, cons
         G.tls[(env * S + sg) * 3 + 0] = ph;
         G.tls[(env * S + sg) * 3 + 1] = L.left[sg];
         G.tls[(env * S + sg) * 3 + 2] = L.nextp[sg];
-    }
-    // ---- store the slab back
-    {
-        const int hw0 = G.env[env * 4 + 2];
-        const int top = hwf > hw0 ? hwf : hw0;
-        int act = 0, pend = 0;
-        for (int s = tid; s < top; s += B) {
-            uint16_t ln = L.lane[s];
-            G.lane[eo + s] = ln; G.trip[eo + s] = L.trip[s];
-            if (ln != LANE_NONE) {
-                G.pos[eo + s] = L.pos[s]; G.speed[eo + s] = L.speed[s]; G.tloss[eo + s] = L.tloss[s];
-                G.cursor[eo + s] = L.cursor[s]; G.swait[eo + s] = L.swait[s];
-                if (ln == LANE_PENDING) pend += 1; else act += 1;
-            }
-        }
-        if (act) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE], act);
-        if (pend) atomicAdd(&L.sc[SC_STATS + ST_PENDING], pend);
     }
     __syncthreads();
     if (tid < 3) G.env[env * 4 + tid] = L.sc[tid];
@@ -795,7 +881,7 @@ extern "C" __global__ void rs_reset_kernel(Tab T, State G, KParams P) {
     for (int s = threadIdx.x; s < C; s += blockDim.x) {
         G.lane[eo + s] = LANE_NONE; G.trip[eo + s] = 0xFFFF; G.owner[eo + s] = OWNER_NONE;
         G.rwait[eo + s] = 0; G.swait[eo + s] = 0; G.cursor[eo + s] = 0; G.depart[eo + s] = 0;
-        G.pos[eo + s] = 0.0f; G.speed[eo + s] = 0.0f; G.accel[eo + s] = 0.0f; G.tloss[eo + s] = 0.0f;
+        G.pos[eo + s] = 0.0f; G.speed[eo + s] = 0.0f; G.accel[eo + s] = 0.0f; G.tloss[eo + s] = 0.0f; G.sf[eo + s] = 1.0f;
     }
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         int ph, left;
@@ -846,6 +932,7 @@ struct rs_sim {
     int n_envs = 0, env_base = 0, block = 256;
     size_t lds = 0;
     Tab T{};
+    KTab K{};
     State G{};
     Out O{};
     KParams P{};
@@ -927,7 +1014,6 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     T.n_lanes = sc->n_lanes; T.n_links = sc->n_links; T.n_edges = sc->n_edges; T.n_routes = sc->n_routes;
     T.n_trips = sc->n_trips; T.n_signals = sc->n_signals; T.n_obs = sc->n_obs; T.n_vtypes = sc->n_vtypes;
     T.horizon = sc->horizon; T.capacity = C; T.step_length = sc->step_length; T.yellow_length = sc->yellow_length;
-    T.n_arr = sc->n_lanes > sc->n_links ? sc->n_lanes : sc->n_links;
     std::vector<int32_t> obs_sig((size_t)sc->n_obs > 0 ? sc->n_obs : 1, 0);
     int lmax = 1;
     for (int s = 0; s < sc->n_signals; ++s) {
@@ -938,6 +1024,107 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     T.lmax = lmax;
     if ((rc = dev_upload<int32_t>(h, &T.obs_sig, obs_sig.data(), obs_sig.size()))) return fail(rc);
     h->tls_ngreen.assign(sc->tls_ngreen, sc->tls_ngreen + sc->n_signals);
+    // ---- packed 16-byte records for the step kernel
+    {
+        if (sc->n_route_steps >= 0xFFFF || sc->n_foes >= 0xFFFF || sc->n_links >= 0xFFFF || sc->n_edges >= 0xFFFF || sc->n_obs >= 0x7FFF) {
+            h->err = "scenario exceeds packed-table id widths (route steps / foes / links / edges u16)"; return fail(RS_ELIMIT);
+        }
+        std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
+        int n_foe_targets = 0;
+        for (int l = 0; l < sc->n_links; ++l)
+            for (int i = sc->link_foe_start[l]; i < sc->link_foe_start[l] + sc->link_foe_cnt[l]; ++i) {
+                int f = sc->foe_link[i];
+                if (link_arr[f] < 0) link_arr[f] = (int16_t)n_foe_targets++;
+            }
+        std::vector<LaneRec> lanes((size_t)sc->n_lanes);
+        for (int l = 0; l < sc->n_lanes; ++l) {
+            LaneRec &R = lanes[l];
+            R.len = sc->lane_len[l]; R.vmax = sc->lane_vmax[l];
+            R.link_start = (uint16_t)sc->lane_link_start[l];
+            if (sc->lane_link_cnt[l] > 255) { h->err = "more than 255 links on one lane"; return fail(RS_ELIMIT); }
+            R.link_cnt = (uint8_t)sc->lane_link_cnt[l];
+            int e = sc->lane_edge[l];
+            int nl = e >= 0 ? sc->edge_nlanes[e] : 0;
+            R.flags = (uint8_t)((sc->lane_internal[l] ? LF_INTERNAL : 0u) | ((unsigned)nl << 2));
+            R.obs = (int16_t)sc->lane_obs[l];
+            R.edge_lane0 = (uint16_t)(e >= 0 ? sc->edge_lane0[e] : 0);
+        }
+        std::vector<LinkRec> links((size_t)sc->n_links);
+        for (int l = 0; l < sc->n_links; ++l) {
+            LinkRec &R = links[l];
+            R.to_lane = (uint16_t)sc->link_to_lane[l]; R.to_edge = (uint16_t)sc->link_to_edge[l];
+            R.foe_start = (uint16_t)sc->link_foe_start[l];
+            R.via2 = sc->link_via2[l] >= 0 ? (uint16_t)sc->link_via2[l] : (uint16_t)0xFFFF;
+            R.arr_idx = link_arr[l];
+            R.tls = sc->link_tls[l] >= 0 ? (uint8_t)sc->link_tls[l] : (uint8_t)0xFF;
+            R.tls_pos = sc->link_tls[l] >= 0 ? (uint8_t)sc->link_tls_pos[l] : (uint8_t)0;
+            if (sc->link_foe_cnt[l] > 255 || (sc->link_tls[l] >= 0 && sc->link_tls_pos[l] > 255)) { h->err = "foe count / TLS link index exceeds u8"; return fail(RS_ELIMIT); }
+            R.foe_cnt = (uint8_t)sc->link_foe_cnt[l];
+            R.flags = (uint8_t)((sc->link_minor[l] ? KF_MINOR : 0u) | (sc->link_cont[l] ? KF_CONT : 0u) | (sc->link_via1[l] >= 0 ? KF_VIA1 : 0u));
+            R.dest_k = (uint8_t)(sc->link_dest_lane[l] - sc->edge_lane0[sc->link_to_edge[l]]);
+            R.pad = 0;
+        }
+        std::vector<FoeRec> foes((size_t)(sc->n_foes > 0 ? sc->n_foes : 1));
+        for (int i = 0; i < sc->n_foes; ++i) {
+            int f = sc->foe_link[i];
+            FoeRec &R = foes[i];
+            R.arr_idx = link_arr[f];
+            R.tls = sc->link_tls[f] >= 0 ? (uint8_t)sc->link_tls[f] : (uint8_t)0xFF;
+            R.tls_pos = sc->link_tls[f] >= 0 ? (uint8_t)sc->link_tls_pos[f] : (uint8_t)0;
+            R.via1 = sc->link_via1[f] >= 0 ? (uint16_t)sc->link_via1[f] : (uint16_t)0xFFFF;
+            R.via2 = sc->link_via2[f] >= 0 ? (uint16_t)sc->link_via2[f] : (uint16_t)0xFFFF;
+        }
+        std::vector<RStep> rsteps((size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1));
+        std::vector<RouteRec> routes((size_t)sc->n_routes);
+        std::vector<int16_t> lane_dep((size_t)sc->n_lanes, -1);
+        int n_dep = 0;
+        for (int r = 0; r < sc->n_routes; ++r) {
+            const int rs = sc->route_start[r], re = sc->route_start[r + 1];
+            for (int q = rs; q < re; ++q) {
+                RStep &R = rsteps[q];
+                R.edge = (uint16_t)sc->route_edge[q];
+                const bool last = q + 1 >= re;
+                R.next_edge = last ? (uint16_t)0xFFFF : (uint16_t)sc->route_edge[q + 1];
+                R.next_mask2 = last ? 0u : sc->route_mask2[q + 1];
+                R.next_mask1 = last ? 0u : sc->route_mask1[q + 1];
+                R.tlsdist = sc->route_tlsdist[q];
+            }
+            const uint32_t m = sc->route_mask2[rs];
+            const int e = sc->route_edge[rs];
+            int k = 0;
+            while (k < 31 && !((m >> k) & 1u)) k += 1;
+            if (k >= sc->edge_nlanes[e]) k = 0;
+            const int dl = sc->edge_lane0[e] + k;
+            if (lane_dep[dl] < 0) lane_dep[dl] = (int16_t)n_dep++;
+            routes[r].start = (uint32_t)rs; routes[r].depart_lane = (uint16_t)dl; routes[r].depart_arr = lane_dep[dl];
+        }
+        std::vector<uint16_t> trip_route((size_t)sc->n_trips);
+        std::vector<uint8_t> trip_vtype((size_t)sc->n_trips);
+        for (int k = 0; k < sc->n_trips; ++k) { trip_route[k] = (uint16_t)sc->trip_route[k]; trip_vtype[k] = (uint8_t)sc->trip_vtype[k]; }
+        std::vector<uint8_t> tls8((size_t)(sc->n_tls_states > 0 ? sc->n_tls_states : 1)), fix8((size_t)(sc->n_fix_states > 0 ? sc->n_fix_states : 1));
+        for (int i = 0; i < sc->n_tls_states; ++i) tls8[i] = (uint8_t)sc->tls_states[i];
+        for (int i = 0; i < sc->n_fix_states; ++i) fix8[i] = (uint8_t)sc->fix_states[i];
+        KTab &K = h->K;
+        if ((rc = dev_upload<LaneRec>(h, &K.lanes, lanes.data(), lanes.size())) || (rc = dev_upload<LinkRec>(h, &K.links, links.data(), links.size())) ||
+            (rc = dev_upload<FoeRec>(h, &K.foes, foes.data(), foes.size())) || (rc = dev_upload<RStep>(h, &K.rsteps, rsteps.data(), rsteps.size())) ||
+            (rc = dev_upload<RouteRec>(h, &K.routes, routes.data(), routes.size())) ||
+            (rc = dev_upload<uint16_t>(h, &K.trip_route, trip_route.data(), trip_route.size())) ||
+            (rc = dev_upload<uint8_t>(h, &K.trip_vtype, trip_vtype.data(), trip_vtype.size())) ||
+            (rc = dev_upload<uint8_t>(h, &K.tls8, tls8.data(), tls8.size())) || (rc = dev_upload<uint8_t>(h, &K.fix8, fix8.data(), fix8.size())))
+            return fail(rc);
+        K.route_mask2 = T.route_mask2; K.trip_depart = T.trip_depart; K.trips_cum = T.trips_cum; K.vtype_params = T.vtype_params;
+        K.tls_nphase = T.tls_nphase; K.tls_ngreen = T.tls_ngreen; K.tls_nlinks = T.tls_nlinks; K.tls_state_off = T.tls_state_off;
+        K.tls_dur_off = T.tls_dur_off; K.tls_yel_off = T.tls_yel_off; K.tls_dur = T.tls_dur; K.tls_yellow = T.tls_yellow;
+        K.fix_nphase = T.fix_nphase; K.fix_state_off = T.fix_state_off; K.fix_dur_off = T.fix_dur_off; K.fix_dur = T.fix_dur;
+        K.obs_sig = T.obs_sig; K.sig_obs_start = T.sig_obs_start; K.mv_in_start = T.mv_in_start; K.mv_in_idx = T.mv_in_idx;
+        K.mv_out_start = T.mv_out_start; K.mv_out_idx = T.mv_out_idx; K.pr_out_start = T.pr_out_start; K.pr_out_idx = T.pr_out_idx;
+        K.n_lanes = sc->n_lanes; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
+        K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = lmax;
+        K.n_arr = n_foe_targets > n_dep ? n_foe_targets : n_dep;
+        if (K.n_arr < 1) K.n_arr = 1;
+        T.n_arr = K.n_arr;
+    }
+
 
     h->P.seed = p->seed; h->P.env_base = env_base; h->P.max_distance = p->max_distance; h->P.sigma = p->sigma;
     h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.n_envs = n_envs;
@@ -946,7 +1133,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     State &G = h->G;
     Out &O = h->O;
     if ((rc = dev_alloc(h, &G.pos, NC)) || (rc = dev_alloc(h, &G.speed, NC)) || (rc = dev_alloc(h, &G.accel, NC)) ||
-        (rc = dev_alloc(h, &G.tloss, NC)) || (rc = dev_alloc(h, &G.lane, NC)) || (rc = dev_alloc(h, &G.trip, NC)) ||
+        (rc = dev_alloc(h, &G.tloss, NC)) || (rc = dev_alloc(h, &G.sf, NC)) || (rc = dev_alloc(h, &G.lane, NC)) || (rc = dev_alloc(h, &G.trip, NC)) ||
         (rc = dev_alloc(h, &G.cursor, NC)) || (rc = dev_alloc(h, &G.swait, NC)) || (rc = dev_alloc(h, &G.rwait, NC)) ||
         (rc = dev_alloc(h, &G.depart, NC)) || (rc = dev_alloc(h, &G.owner, NC)) || (rc = dev_alloc(h, &G.env, N * 4)) ||
         (rc = dev_alloc(h, &G.tls, N * S * 3)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
@@ -984,13 +1171,14 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_VEH_OWNER, G.owner, RS_U8, 2, n, c);
     set_buf(h, RS_BUF_STATS, G.stats, RS_I64, 2, n, ST_N);
     set_buf(h, RS_BUF_DRQ_NORM_F16, O.drq_f16, RS_F16, 4, n, s, lmax, 5);
+    set_buf(h, RS_BUF_VEH_SF, G.sf, RS_F32, 2, n, c);
 
     h->lds = lds_bytes_for(C, sc->n_lanes, T.n_arr, sc->n_obs, sc->n_signals, sc->n_vtypes);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
     if (block_threads <= 0) {
-        block_threads = C >= 512 ? 256 : (C >= 128 ? 128 : 64);
+        block_threads = C >= 512 ? 512 : (C >= 256 ? 256 : (C >= 128 ? 128 : 64));
     }
-    if (block_threads % 64 || block_threads > 1024 || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024]"; return fail(RS_EINVAL); }
+    if (block_threads % 64 || block_threads > 512 || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 512]"; return fail(RS_EINVAL); }
     h->block = block_threads;
     if (hipFuncSetAttribute((const void *)rs_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
         h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
@@ -1028,7 +1216,7 @@ static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
         h->ev_used += 1;
         HIPCHK(h, hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(rs_step_kernel, dim3(h->n_envs), dim3(h->block), h->lds, st, h->T, h->G, h->O, P, (const int32_t *)h->actions);
+    hipLaunchKernelGGL(rs_step_kernel, dim3(h->n_envs), dim3(h->block), h->lds, st, h->K, h->G, h->O, P, (const int32_t *)h->actions);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     return RS_OK;
@@ -1131,7 +1319,7 @@ static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, 
                                 RS_BUF_WAIT_NORM, RS_BUF_PRESSURE, RS_BUF_QUEUE_SUM, RS_BUF_QUEUE_MAX, RS_BUF_DRQ_NORM_F16,
                                 RS_BUF_ENV, RS_BUF_TLS, RS_BUF_VEH_POS, RS_BUF_VEH_SPEED, RS_BUF_VEH_ACCEL, RS_BUF_VEH_TLOSS,
                                 RS_BUF_VEH_LANE, RS_BUF_VEH_TRIP, RS_BUF_VEH_CURSOR, RS_BUF_VEH_SWAIT, RS_BUF_VEH_RWAIT,
-                                RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_STATS};
+                                RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_VEH_SF, RS_BUF_STATS};
 extern "C" int rs_snapshot(rs_handle h, void **snap) {
     if (!h || !snap) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));

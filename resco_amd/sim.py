@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libresco_sim.so')
 
 BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure', 'queue_sum',
            'queue_max', 'actions', 'env', 'tls', 'veh_pos', 'veh_speed', 'veh_accel', 'veh_tloss', 'veh_lane',
-           'veh_trip', 'veh_cursor', 'veh_swait', 'veh_rwait', 'veh_depart', 'veh_owner', 'stats', 'drq_norm_f16']
+           'veh_trip', 'veh_cursor', 'veh_swait', 'veh_rwait', 'veh_depart', 'veh_owner', 'stats', 'drq_norm_f16',
+           'veh_sf']
 BUF_ID = {n: i for i, n in enumerate(BUFFERS)}
 _NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64]
 _TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8']
