@@ -163,6 +163,11 @@ int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches);   /* syncs;
  * multi_signal.py:127); call between rs_reset()s */
 int rs_set_seed(rs_handle h, uint32_t seed);
 
+/* in-kernel phase timers (development aid): enable, run steps, then read 16 accumulators of wall_clock64 ticks
+ * (100 MHz) summed over all workgroups: 0 load, 1 prologue, 2 A, 3 B, 4 C plan, 5 list clear, 6 D move, 7 E lane
+ * change, 8 F rebuild, 9 observe, 10 outputs.  Reading also resets. */
+int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16);
+
 /* static facts */
 int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int32_t *lds_bytes, int32_t *max_lanes_per_signal);
 

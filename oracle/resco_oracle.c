@@ -550,8 +550,10 @@ static void lane_change(orc_env *e) {
             int32_t dir = 0;
             if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
             want = (dir == dir_allowed) ? 2 : 0;
-        } else if ((m2 >> tk) & 1u) {
-            /* speed gain between equally good lanes: more room ahead on the neighbour */
+        } else if (((m2 >> tk) & 1u) && ((((uint32_t)e->t >> 1) + (uint32_t)k) & 3u) == 0u) {
+            /* speed gain between equally good lanes: more room ahead on the neighbour.  A vehicle reconsiders
+             * only on one pair of ticks (one left, one right chance) out of four (LC2013 needs several
+             * seconds of accumulated speed-gain incentive before it acts [SUMO-K]) */
             neighbours(e, lane, x, k, s, &lead_c, &foll_c);
             if (lead_c != NIL) {
                 const float *vo = vt_of(e, trip_of_slot(e, lead_c));

@@ -31,7 +31,7 @@
 #define LANE_NONE 0xFFFFu
 #define LANE_PENDING 0xFFFEu
 #define OWNER_NONE 0xFFu
-#define NIL 0xFFFF
+#define NIL 0x7FFF              /* list terminator (15-bit slot ids; bit 15 of a head = lane has a moving vehicle) */
 #define HALT_SPEED 0.1f
 #define STOP_OFFSET 1.0f
 #define ARR_NONE 65535
@@ -102,6 +102,7 @@ struct KParams {
     int32_t n_ticks;        // ticks to simulate in this launch (0: observe only)
     int32_t do_fsm;         // apply prep_phase / set_phase around the ticks
     int32_t n_envs;
+    unsigned long long *prof;   // optional [16] per-phase cycle accumulators (rs_phase_profile), NULL = off
 };
 
 // ------------------------------------------------------------------------------------------------ device math
@@ -205,15 +206,22 @@ struct KTab {
     const int32_t *tls_nphase, *tls_ngreen, *tls_nlinks, *tls_state_off, *tls_dur_off, *tls_yel_off, *tls_dur, *tls_yellow;
     const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_dur;
     const int32_t *obs_sig, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx, *pr_out_start, *pr_out_idx;
-    int32_t n_lanes, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr;
+    int32_t n_lanes, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
 };
 
 // ------------------------------------------------------------------------------------------------ LDS view
+struct __attribute__((aligned(8))) Node {
+    float pos;
+    uint16_t trip;      // 0xFFFF: free slot
+    uint16_t nxt;       // next vehicle on the same lane (unordered), NIL terminated
+};
 struct Lds {
-    float *pos, *speed, *vnx, *vtp;
-    uint16_t *lane, *nxt, *trip, *rq, *swait, *nlink, *head;
+    struct Node *node;          // {pos, trip, next-in-lane}: one 8-byte LDS read per list step
+    float *speed, *vnx, *tloss, *vtp;
+    uint16_t *lane, *rq, *swait, *nlink;
+    uint16_t *head;             // per-lane list heads (bit 15: the lane holds a moving vehicle)
     uint8_t *vt;
-    int32_t *arr;
+    int32_t *arr, *dep;         // link approach registers / departure-lane insertion candidates
     int32_t *agg_q, *agg_a, *agg_w, *agg_m;
     uint32_t *agg_s;
     int32_t *phase, *left, *nextp, *tbase;
@@ -228,32 +236,43 @@ struct Lds {
 #define SC_STATS 6
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t lds_bytes_for(int C, int n_lanes, int n_arr, int n_obs, int S, int n_vt) {
+__host__ __device__ inline size_t lds_scratch_bytes(int C, int n_obs) {       // vnx, later reused by the aggregates
+    size_t a = (size_t)C * 4, b = align16((size_t)n_obs * 4) * 5;
+    return a > b ? a : b;
+}
+__host__ __device__ inline size_t lds_bytes_for(int C, int n_lanes, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
     size_t o = 0;
-    o += align16((size_t)C * 4) * 3;                 // pos speed vnx
+    o += align16((size_t)C * 8);                     // node {pos, trip, nxt}
+    o += align16((size_t)C * 4) * 2;                 // speed tloss
+    o += align16(lds_scratch_bytes(C, n_obs));       // vnx | aggregates
     o += align16((size_t)n_vt * VT_COLS * 4);        // vtype table
-    o += align16((size_t)C * 2) * 6;                 // lane nxt trip rq swait nlink
+    o += align16((size_t)C * 2) * 4;                 // lane rq swait nlink
     o += align16((size_t)(n_lanes + 2) * 2);         // head (u16, CAS on the containing dword)
     o += align16((size_t)C);                         // vt
-    o += align16((size_t)n_arr * 4);                 // approach / insertion registers
-    o += align16((size_t)n_obs * 4) * 5;             // aggregates
+    o += align16((size_t)n_arr * 4);                 // approach registers
+    o += align16((size_t)n_dep * 4);                 // insertion candidates
     o += align16((size_t)S * 4) * 4;                 // tls
     o += align16((size_t)(SC_STATS + ST_N) * 4);
     return o;
 }
-__device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_lanes, int n_arr, int n_obs, int S, int n_vt) {
+__device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_lanes, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
     size_t o = 0;
 #define CARVE(field, type, bytes) L.field = (type *)(base + o); o += align16(bytes);
-    CARVE(pos, float, (size_t)C * 4) CARVE(speed, float, (size_t)C * 4) CARVE(vnx, float, (size_t)C * 4)
+    CARVE(node, Node, (size_t)C * 8) CARVE(speed, float, (size_t)C * 4) CARVE(tloss, float, (size_t)C * 4)
+    {   // the per-lane aggregates of the observe phase live where vnx was (dead by then)
+        char *sb = base + o;
+        L.vnx = (float *)sb;
+        const size_t ab = align16((size_t)n_obs * 4);
+        L.agg_q = (int32_t *)sb; L.agg_a = (int32_t *)(sb + ab); L.agg_w = (int32_t *)(sb + 2 * ab);
+        L.agg_m = (int32_t *)(sb + 3 * ab); L.agg_s = (uint32_t *)(sb + 4 * ab);
+        o += align16(lds_scratch_bytes(C, n_obs));
+    }
     CARVE(vtp, float, (size_t)n_vt * VT_COLS * 4)
-    CARVE(lane, uint16_t, (size_t)C * 2) CARVE(nxt, uint16_t, (size_t)C * 2) CARVE(trip, uint16_t, (size_t)C * 2)
+    CARVE(lane, uint16_t, (size_t)C * 2)
     CARVE(rq, uint16_t, (size_t)C * 2) CARVE(swait, uint16_t, (size_t)C * 2) CARVE(nlink, uint16_t, (size_t)C * 2)
     CARVE(head, uint16_t, (size_t)(n_lanes + 2) * 2)
     CARVE(vt, uint8_t, (size_t)C)
-    CARVE(arr, int32_t, (size_t)n_arr * 4)
-    CARVE(agg_q, int32_t, (size_t)n_obs * 4) CARVE(agg_a, int32_t, (size_t)n_obs * 4)
-    CARVE(agg_w, int32_t, (size_t)n_obs * 4) CARVE(agg_m, int32_t, (size_t)n_obs * 4)
-    CARVE(agg_s, uint32_t, (size_t)n_obs * 4)
+    CARVE(arr, int32_t, (size_t)n_arr * 4) CARVE(dep, int32_t, (size_t)n_dep * 4)
     CARVE(phase, int32_t, (size_t)S * 4) CARVE(left, int32_t, (size_t)S * 4) CARVE(nextp, int32_t, (size_t)S * 4)
     CARVE(tbase, int32_t, (size_t)S * 4)
     CARVE(sc, int32_t, (size_t)(SC_STATS + ST_N) * 4)
@@ -277,15 +296,20 @@ __device__ __forceinline__ float speed_factor(const KParams &P, int env, int tri
 
 // push slot s on the list of `lane`; returns the previous head.  16-bit heads, exchanged with a CAS on the
 // containing dword (LDS has no 16-bit atomics; a dword holds the heads of two neighbouring lanes)
-__device__ __forceinline__ uint16_t list_push(Lds &L, int lane, int s) {
-    uint32_t *w = (uint32_t *)L.head + (lane >> 1);
+__device__ __forceinline__ uint16_t list_push(uint16_t *head, int lane, int s, bool mover) {
+    uint32_t *w = (uint32_t *)head + (lane >> 1);
     const int sh = (lane & 1) * 16;
+    const uint32_t flag = mover ? 0x8000u : 0u;
     uint32_t old = *w, assumed;
     do {
         assumed = old;
-        old = atomicCAS(w, assumed, (assumed & ~(0xFFFFu << sh)) | ((uint32_t)s << sh));
+        const uint32_t keep = (assumed >> sh) & 0x8000u;          // sticky mover flag of the lane
+        old = atomicCAS(w, assumed, (assumed & ~(0xFFFFu << sh)) | (((uint32_t)s | keep | flag) << sh));
     } while (old != assumed);
-    return (uint16_t)(old >> sh);
+    return (uint16_t)((old >> sh) & 0x7FFFu);
+}
+__device__ __forceinline__ void heads_clear(uint16_t *head, int n_lanes, int tid, int B) {
+    for (int i = tid; i < (n_lanes + 2) / 2; i += B) ((uint32_t *)head)[i] = 0x7FFF7FFFu;
 }
 
 // the link a vehicle on `lane` (record LR) takes at route step rq; -1: none (last edge / wrong lane)
@@ -312,46 +336,45 @@ __device__ __forceinline__ int tls_state(const KTab &T, const Lds &L, const KPar
     return tab[L.tbase[tls] + pos];
 }
 
-__device__ __forceinline__ int rearmost(const Lds &L, int lane) {
+__device__ __forceinline__ int rearmost(const Lds &L, const uint16_t *head, int lane) {
     int best = NIL, bk = 0;
     float bp = 0.0f;
-    for (int s = L.head[lane]; s != NIL; s = L.nxt[s]) {
-        int k = L.trip[s];
-        float p = L.pos[s];
+    for (int s = head[lane] & 0x7FFF; s != NIL;) {
+        const Node nd = L.node[s];
+        const int k = nd.trip;
+        const float p = nd.pos;
         if (best == NIL || p < bp || (p == bp && k > bk)) { best = s; bk = k; bp = p; }
+        s = nd.nxt;
     }
     return best;
 }
 
-__device__ __forceinline__ void neighbours(const Lds &L, int lane, float pos, int k, int self, int &lead, int &foll) {
+__device__ __forceinline__ void neighbours(const Lds &L, const uint16_t *head, int lane, float pos, int k, int self, int &lead, int &foll) {
     int Ld = NIL, Fd = NIL, Lk = 0, Fk = 0;
     float Lp = 0.0f, Fp = 0.0f;
-    for (int s = L.head[lane]; s != NIL; s = L.nxt[s]) {
-        if (s == self) continue;
-        int ks = L.trip[s];
-        float ps = L.pos[s];
+    for (int s = head[lane] & 0x7FFF; s != NIL;) {
+        const Node nd = L.node[s];
+        const int cur = s;
+        s = nd.nxt;
+        if (cur == self) continue;
+        const int ks = nd.trip;
+        const float ps = nd.pos;
         if (ahead_of(ps, ks, pos, k)) {
-            if (Ld == NIL || ahead_of(Lp, Lk, ps, ks)) { Ld = s; Lk = ks; Lp = ps; }
+            if (Ld == NIL || ahead_of(Lp, Lk, ps, ks)) { Ld = cur; Lk = ks; Lp = ps; }
         } else {
-            if (Fd == NIL || ahead_of(ps, ks, Fp, Fk)) { Fd = s; Fk = ks; Fp = ps; }
+            if (Fd == NIL || ahead_of(ps, ks, Fp, Fk)) { Fd = cur; Fk = ks; Fp = ps; }
         }
     }
     lead = Ld; foll = Fd;
 }
 
-__device__ __forceinline__ bool lane_has_mover(const Lds &L, int lane) {
-    for (int s = L.head[lane]; s != NIL; s = L.nxt[s])
-        if (L.speed[s] > HALT_SPEED) return true;
-    return false;
-}
-
-__device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const KParams &P, const LinkRec &K) {
+__device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const uint16_t *head, const KParams &P, const LinkRec &K) {
     for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
         const FoeRec F = T.foes[i];
         if (F.tls != 0xFF && tls_state(T, L, P, F.tls, F.tls_pos) == TLS_R) continue;
         if (F.arr_idx >= 0 && L.arr[F.arr_idx] < FOE_GAP_Q) return true;
-        if (F.via1 != 0xFFFF && lane_has_mover(L, F.via1)) return true;
-        if (F.via2 != 0xFFFF && lane_has_mover(L, F.via2)) return true;
+        if (F.via1 != 0xFFFF && (head[F.via1] & 0x8000)) return true;      // a moving vehicle on the foe's junction lanes
+        if (F.via2 != 0xFFFF && (head[F.via2] & 0x8000)) return true;
     }
     return false;
 }
@@ -364,9 +387,9 @@ __device__ __forceinline__ void set_phase(const KTab &T, Lds &L, const KParams &
 }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
-// grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 512).
-// __launch_bounds__(512, 8): <= 64 VGPRs so that four 512-thread workgroups (32 waves) share a CU.
-extern "C" __global__ void __launch_bounds__(512, 8)
+// grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 1024).
+// __launch_bounds__(1024, 8): <= 64 VGPRs so that 32 waves (e.g. two 1024-thread workgroups) share a CU.
+extern "C" __global__ void __launch_bounds__(1024, 8)
 rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int env = blockIdx.x;
@@ -375,14 +398,21 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     const int C = T.capacity, S = T.n_signals, NO = T.n_obs;
     const int genv = P.env_base + env;
     Lds L;
-    lds_carve(L, smem, C, T.n_lanes, T.n_arr, NO, S, T.n_vtypes);
+    lds_carve(L, smem, C, T.n_lanes, T.n_arr, T.n_dep, NO, S, T.n_vtypes);
+    unsigned long long pt_ = 0;
+#define PROF_START() if (P.prof && tid == 0) pt_ = wall_clock64();
+#define PROF_MARK(i_) if (P.prof && tid == 0) { unsigned long long n_ = wall_clock64(); atomicAdd(&P.prof[i_], n_ - pt_); pt_ = n_; }
+    PROF_START()
     const size_t eo = (size_t)env * C;
+    uint16_t *const hc = L.head;    // per-lane vehicle lists of the current state
+    uint16_t *const hn = L.head;    // (one buffer: cleared between plan and move, rebuilt by the move)
 
     // ---- load the environment slab (once per env-step)
     if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 3 ? G.env[env * 4 + tid] : 0;
     for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.vtype_params[i];
-    for (int i = tid; i < (T.n_lanes + 2) / 2; i += B) ((uint32_t *)L.head)[i] = 0xFFFFFFFFu;
+    heads_clear(L.head, T.n_lanes, tid, B);
     for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
+    for (int i = tid; i < T.n_dep; i += B) L.dep[i] = ARR_NONE;
     for (int i = tid; i < S; i += B) {
         int ph = G.tls[(env * S + i) * 3 + 0];
         L.phase[i] = ph;
@@ -397,20 +427,73 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         for (int s = tid; s < C; s += B) {
             uint16_t ln = LANE_NONE, tr = 0xFFFF;
             if (s < hw0) { ln = G.lane[eo + s]; tr = G.trip[eo + s]; }
-            L.lane[s] = ln; L.trip[s] = tr;
+            L.lane[s] = ln; L.node[s].trip = tr;
             if (ln != LANE_NONE) {
-                L.pos[s] = G.pos[eo + s]; L.speed[s] = G.speed[eo + s]; L.swait[s] = G.swait[eo + s];
+                const float sp = G.speed[eo + s];
+                L.node[s].pos = G.pos[eo + s]; L.speed[s] = sp; L.swait[s] = G.swait[eo + s]; L.tloss[s] = G.tloss[eo + s];
                 const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor[eo + s];
                 L.rq[s] = (uint16_t)rq;
                 L.vt[s] = T.trip_vtype[tr];
                 int nl = -1;
-                if (ln != LANE_PENDING) nl = choose_link(T, T.lanes[ln], rq); else npend += 1;
+                if (ln != LANE_PENDING) {
+                    nl = choose_link(T, T.lanes[ln], rq);
+                    L.node[s].nxt = list_push(hc, ln, s, sp > HALT_SPEED);
+                } else npend += 1;
                 L.nlink[s] = (uint16_t)nl;
             }
         }
         if (npend) atomicAdd(&L.sc[SC_NPEND], npend);
     }
-    // ---- Signal.prep_phase for every signal (traffic_signal.py:176-184)
+    __syncthreads();
+    PROF_MARK(0)
+
+// TLS switch events at the beginning of a tick (P0), preceded by Signal.set_phase when the yellow ticks are over
+#define TLS_BEGIN_OF_TICK(tick_)                                                                                   \
+    for (int s_ = tid; s_ < S; s_ += B) {                                                                          \
+        if (P.do_fsm && !P.fixed_program && (tick_) == T.yellow_length) set_phase(T, L, P, s_, L.nextp[s_]);       \
+        int left_ = L.left[s_];                                                                                    \
+        if (left_ == 0) {                                                                                          \
+            const int32_t *dur_ = P.fixed_program ? T.fix_dur + T.fix_dur_off[s_] : T.tls_dur + T.tls_dur_off[s_]; \
+            const int Pn_ = P.fixed_program ? T.fix_nphase[s_] : T.tls_nphase[s_];                                 \
+            const int ph_ = (L.phase[s_] + 1) % Pn_;                                                               \
+            left_ = dur_[ph_];                                                                                     \
+            L.phase[s_] = ph_;                                                                                     \
+            L.tbase[s_] = (P.fixed_program ? T.fix_state_off[s_] : T.tls_state_off[s_]) + ph_ * T.tls_nlinks[s_];  \
+        }                                                                                                          \
+        L.left[s_] = left_ - 1;                                                                                    \
+    }
+
+// P2a for tick t_: departed trips take the lowest free slots in trip order (wave 0 only; base_hw_ = current hw)
+#define ALLOCATE_SLOTS(t_)                                                                                         \
+    if (tid < 64) {                                                                                                \
+        const int hz_ = (t_) - 1 <= T.horizon ? (t_) - 1 : T.horizon;                                              \
+        const int due_ = (t_) >= 1 ? T.trips_cum[hz_] : 0;                                                         \
+        const int nt_ = L.sc[SC_NEXT];                                                                             \
+        const int m_ = due_ - nt_;                                                                                 \
+        if (m_ > 0) {                                                                                              \
+            int base_ = 0;                                                                                         \
+            for (int c0 = 0; c0 < C && base_ < m_; c0 += 64) {                                                     \
+                const int s_ = c0 + tid;                                                                           \
+                const bool fr_ = L.lane[s_] == LANE_NONE;                                                          \
+                const unsigned long long mask_ = __ballot(fr_);                                                    \
+                const int rank_ = __popcll(mask_ & ((1ull << tid) - 1ull));                                        \
+                if (fr_ && base_ + rank_ < m_) {                                                                   \
+                    const int k_ = nt_ + base_ + rank_;                                                            \
+                    const int v_ = T.trip_vtype[k_];                                                               \
+                    L.node[s_].trip = (uint16_t)k_; L.lane[s_] = LANE_PENDING;                                          \
+                    L.node[s_].pos = 0.0f; L.speed[s_] = 0.0f; L.swait[s_] = 0; L.nlink[s_] = 0xFFFF; L.tloss[s_] = 0.0f; \
+                    L.vt[s_] = (uint8_t)v_; L.rq[s_] = (uint16_t)T.routes[T.trip_route[k_]].start;                 \
+                    G.sf[eo + s_] = speed_factor(P, genv, k_, T.vtype_params + v_ * VT_COLS);                      \
+                    G.rwait[eo + s_] = 0; G.owner[eo + s_] = OWNER_NONE; G.depart[eo + s_] = 0; G.accel[eo + s_] = 0.0f; \
+                    atomicMax(&L.sc[SC_HW], s_ + 1);                                                               \
+                }                                                                                                  \
+                base_ += __popcll(mask_);                                                                          \
+            }                                                                                                      \
+            if (tid == 0) { const int got_ = base_ < m_ ? base_ : m_; L.sc[SC_NEXT] = nt_ + got_; L.sc[SC_NPEND] += got_; } \
+        }                                                                                                          \
+    }
+
+    // ---- Signal.prep_phase for every signal (traffic_signal.py:176-184), then the preparation of tick 0
     if (P.do_fsm && !P.fixed_program) {
         for (int s = tid; s < S; s += B) {
             int a = actions[env * S + s], cur = L.phase[s], Gn = T.tls_ngreen[s];
@@ -422,108 +505,23 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             }
         }
     }
-    __syncthreads();
-    for (int s = tid; s < L.sc[SC_HW]; s += B) {
-        int ln = L.lane[s];
-        if (ln < LANE_PENDING) L.nxt[s] = list_push(L, ln, s);
+    if (P.n_ticks > 0) {
+        TLS_BEGIN_OF_TICK(0)
+        ALLOCATE_SLOTS(L.sc[SC_T])
     }
     __syncthreads();
+    PROF_MARK(1)
 
     for (int tick = 0; tick < P.n_ticks; ++tick) {
         const int t = L.sc[SC_T];
-        // ---- Signal.set_phase after the yellow ticks (traffic_signal.py:186-187)
-        if (P.do_fsm && !P.fixed_program && tick == T.yellow_length) {
-            for (int s = tid; s < S; s += B) set_phase(T, L, P, s, L.nextp[s]);
-            __syncthreads();
-        }
-        // ---- P0: TLS switch events at the beginning of the tick
-        for (int s = tid; s < S; s += B) {
-            int left = L.left[s];
-            if (left == 0) {
-                const int32_t *dur = P.fixed_program ? T.fix_dur + T.fix_dur_off[s] : T.tls_dur + T.tls_dur_off[s];
-                const int Pn = P.fixed_program ? T.fix_nphase[s] : T.tls_nphase[s];
-                const int ph = (L.phase[s] + 1) % Pn;
-                left = dur[ph];
-                L.phase[s] = ph;
-                L.tbase[s] = (P.fixed_program ? T.fix_state_off[s] : T.tls_state_off[s]) + ph * T.tls_nlinks[s];
-            }
-            L.left[s] = left - 1;
-        }
-        // ---- P2a: departed trips take the lowest free slots in trip order (wave 0 only)
-        {
-            const int hz = t - 1 <= T.horizon ? t - 1 : T.horizon;
-            const int due = t >= 1 ? T.trips_cum[hz] : 0;
-            const int nt = L.sc[SC_NEXT];
-            const int m = due - nt;
-            if (m > 0 && tid < 64) {
-                int base = 0;
-                for (int c0 = 0; c0 < C && base < m; c0 += 64) {
-                    const int s = c0 + tid;
-                    const bool fr = L.lane[s] == LANE_NONE;
-                    const unsigned long long mask = __ballot(fr);
-                    const int rank = __popcll(mask & ((1ull << tid) - 1ull));
-                    if (fr && base + rank < m) {
-                        const int k = nt + base + rank;
-                        const int v = T.trip_vtype[k];
-                        L.trip[s] = (uint16_t)k; L.lane[s] = LANE_PENDING;
-                        L.pos[s] = 0.0f; L.speed[s] = 0.0f; L.swait[s] = 0; L.nlink[s] = 0xFFFF;
-                        L.vt[s] = (uint8_t)v; L.rq[s] = (uint16_t)T.routes[T.trip_route[k]].start;
-                        G.sf[eo + s] = speed_factor(P, genv, k, T.vtype_params + v * VT_COLS);
-                        G.tloss[eo + s] = 0.0f;
-                        G.rwait[eo + s] = 0; G.owner[eo + s] = OWNER_NONE; G.depart[eo + s] = 0; G.accel[eo + s] = 0.0f;
-                        atomicMax(&L.sc[SC_HW], s + 1);
-                    }
-                    base += __popcll(mask);
-                }
-                if (tid == 0) { const int got = base < m ? base : m; L.sc[SC_NEXT] = nt + got; L.sc[SC_NPEND] += got; }
-            }
-        }
-        __syncthreads();
-        int hw = L.sc[SC_HW];
-        if (L.sc[SC_NPEND] > 0) {       // block-uniform: the insertion phases only run while something is pending
-            // ---- P2b: lowest pending trip per departure lane is the insertion candidate
+        const int hw = L.sc[SC_HW];
+        const bool pending = L.sc[SC_NPEND] > 0;       // block-uniform
+        // ---- A: insertion candidates (lowest pending trip per departure lane) and approach registration
+        if (pending)
             for (int s = tid; s < hw; s += B)
-                if (L.lane[s] == LANE_PENDING) atomicMin(&L.arr[T.routes[T.trip_route[L.trip[s]]].depart_arr], (int)L.trip[s]);
-            __syncthreads();
-            // ---- P2c: candidates check the space on their lane
-            for (int s = tid; s < hw; s += B) {
-                if (L.lane[s] != LANE_PENDING) continue;
-                const int k = L.trip[s];
-                const RouteRec RR = T.routes[T.trip_route[k]];
-                bool ins = false;
-                float mypos = 0.0f;
-                if (L.arr[RR.depart_arr] == k) {
-                    const float *vt = L.vtp + L.vt[s] * VT_COLS;
-                    const float ll = T.lanes[RR.depart_lane].len;
-                    mypos = vt[VT_LENGTH] < ll ? vt[VT_LENGTH] : ll;
-                    ins = true;
-                    for (int o = L.head[RR.depart_lane]; o != NIL; o = L.nxt[o]) {
-                        float back = L.pos[o] - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
-                        if (back - mypos - vt[VT_MINGAP] < 0.0f) ins = false;
-                    }
-                }
-                L.vnx[s] = ins ? mypos : -1.0f;
-            }
-            __syncthreads();
-            // ---- P2d: apply insertions, reset the candidate registers
-            for (int s = tid; s < hw; s += B) {
-                if (L.lane[s] != LANE_PENDING) continue;
-                const int k = L.trip[s];
-                const RouteRec RR = T.routes[T.trip_route[k]];
-                L.arr[RR.depart_arr] = ARR_NONE;
-                if (L.vnx[s] < 0.0f) continue;
-                const int dl = RR.depart_lane;
-                L.lane[s] = (uint16_t)dl; L.pos[s] = L.vnx[s]; L.speed[s] = 0.0f;
-                L.nlink[s] = (uint16_t)choose_link(T, T.lanes[dl], RR.start);
-                G.depart[eo + s] = (uint16_t)t;
-                L.nxt[s] = list_push(L, dl, s);
-                atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
-                atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.trip_depart[k]);
-                atomicSub(&L.sc[SC_NPEND], 1);
-            }
-            __syncthreads();
-        }
-        // ---- P3: vehicles that will pass a link somebody may have to yield to register their arrival time
+                if (L.lane[s] == LANE_PENDING) atomicMin(&L.dep[T.routes[T.trip_route[L.node[s].trip]].depart_arr], (int)L.node[s].trip);
+        if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_NLC] = 0; }
+        // P3: vehicles that will pass a link somebody may have to yield to register their arrival time
         for (int s = tid; s < hw; s += B) {
             const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
@@ -532,44 +530,75 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             const float v = L.speed[s];
             if (v <= HALT_SPEED) continue;
             const LinkRec K = T.links[link];
-            if (K.arr_idx < 0) continue;
+            const int ai = K.arr_idx;
+            if (ai < 0) continue;
             const int st = tls_state(T, L, P, K.tls, K.tls_pos);
             if (st == TLS_R) continue;
-            const float dist = T.lanes[lane].len - L.pos[s];
+            const float dist = T.lanes[lane].len - L.node[s].pos;
             if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) continue;
             const float ta = dist / (v > 1.0f ? v : 1.0f);
             const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
-            atomicMin(&L.arr[K.arr_idx], q);
+            atomicMin(&L.arr[ai], q);
         }
         __syncthreads();
-        // ---- P4: plan (Krauss car-following + links)
+        PROF_MARK(2)
+        // ---- B: the candidate of each departure lane checks the space and inserts itself (P2c + P2d)
+        if (pending) {
+            for (int s = tid; s < hw; s += B) {
+                if (L.lane[s] != LANE_PENDING) continue;
+                const int k = L.node[s].trip;
+                const RouteRec RR = T.routes[T.trip_route[k]];
+                if (L.dep[RR.depart_arr] != k) continue;        // lost (or the winner already cleared the register)
+                const int dl = RR.depart_lane;
+                const float *vt = L.vtp + L.vt[s] * VT_COLS;
+                const float ll = T.lanes[dl].len;
+                const float mypos = vt[VT_LENGTH] < ll ? vt[VT_LENGTH] : ll;
+                bool ins = true;
+                for (int o = hc[dl] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
+                    float back = L.node[o].pos - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
+                    if (back - mypos - vt[VT_MINGAP] < 0.0f) ins = false;
+                }
+                L.dep[RR.depart_arr] = ARR_NONE;
+                if (!ins) continue;
+                L.lane[s] = (uint16_t)dl; L.node[s].pos = mypos; L.speed[s] = 0.0f;
+                L.nlink[s] = (uint16_t)choose_link(T, T.lanes[dl], RR.start);
+                G.depart[eo + s] = (uint16_t)t;
+                L.node[s].nxt = list_push(hc, dl, s, false);
+                atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
+                atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.trip_depart[k]);
+                atomicSub(&L.sc[SC_NPEND], 1);
+            }
+            __syncthreads();
+            PROF_MARK(3)
+        }
+        // ---- C: plan (Krauss car-following + links)
         for (int s = tid; s < hw; s += B) {
             const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
-            const int k = L.trip[s];
+            const int k = L.node[s].trip;
             const float *vt = L.vtp + L.vt[s] * VT_COLS;
             const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
-            const float v = L.speed[s], x = L.pos[s];
+            const float v = L.speed[s], x = L.node[s].pos;
             const float sf = G.sf[eo + s];
             LaneRec LR = T.lanes[lane];
+            int link = (int)L.nlink[s];
             float vfree = v + a;
             const float vl = LR.vmax * sf;
             if (vl < vfree) vfree = vl;
             if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
             float vsafe = BIGF;
             int lead, foll;
-            neighbours(L, lane, x, k, s, lead, foll);
+            neighbours(L, hc, lane, x, k, s, lead, foll);
             bool found = false;
             if (lead != NIL) {
                 const float *vo = L.vtp + L.vt[lead] * VT_COLS;
-                float gap = L.pos[lead] - vo[VT_LENGTH] - x - mingap;
+                float gap = L.node[lead].pos - vo[VT_LENGTH] - x - mingap;
                 vsafe = d_follow_speed(gap, L.speed[lead], b, vo[VT_DECEL], tau);
                 found = true;
             }
             const float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
             float seen = LR.len - x;
             int rq = L.rq[s];
-            int link = (int)L.nlink[s];
             if (link == 0xFFFF) link = -1;
             for (int hop = 0; hop < MAX_HOPS && !found && seen < look; ++hop) {
                 const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
@@ -589,7 +618,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     if (seen >= d_brake_gap(v, b)) stop_here = true;
                 }
                 if (!stop_here && !(K.flags & KF_CONT) && K.foe_cnt > 0 && ((K.flags & KF_MINOR) || (K.tls != 0xFF && st == TLS_g))) {
-                    if (foe_blocked(T, L, P, K)) stop_here = true;
+                    if (foe_blocked(T, L, hc, P, K)) stop_here = true;
                 }
                 if (stop_here) {
                     float g = seen - STOP_OFFSET;
@@ -606,10 +635,10 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                         if (vs < vsafe) vsafe = vs;
                     }
                 }
-                const int o = rearmost(L, nl);
+                const int o = rearmost(L, hc, nl);
                 if (o != NIL) {
                     const float *vo = L.vtp + L.vt[o] * VT_COLS;
-                    float gap = seen + L.pos[o] - vo[VT_LENGTH] - mingap;
+                    float gap = seen + L.node[o].pos - vo[VT_LENGTH] - mingap;
                     float vs = d_follow_speed(gap, L.speed[o], b, vo[VT_DECEL], tau);
                     if (vs < vsafe) vsafe = vs;
                     found = true;
@@ -634,10 +663,11 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             L.vnx[s] = vd > vmin ? vd : vmin;
         }
         __syncthreads();
-        // ---- P5: move; drop this tick's approach registrations; clear the list heads (nobody reads them here)
-        if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_NLC] = 0; }
-        for (int i = tid; i < (T.n_lanes + 2) / 2; i += B) ((uint32_t *)L.head)[i] = 0xFFFFFFFFu;
+        PROF_MARK(4)
+        heads_clear(L.head, T.n_lanes, tid, B);     // nobody reads the lists between plan and move
         __syncthreads();
+        PROF_MARK(5)
+        // ---- D: move; drop this tick's approach registrations; build the lists of the moved state
         {
             int active = 0, halted = 0, top = 0;
             for (int s = tid; s < hw; s += B) {
@@ -646,17 +676,18 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 if (lane == LANE_PENDING) { top = s + 1; continue; }
                 int link = (int)L.nlink[s];
                 if (link == 0xFFFF) link = -1;
-                if (link >= 0) { const int ai = T.links[link].arr_idx; if (ai >= 0) L.arr[ai] = ARR_NONE; }
                 LaneRec LR = T.lanes[lane];
+                const float sfv = G.sf[eo + s];
+                if (link >= 0) { const int ai = T.links[link].arr_idx; if (ai >= 0) L.arr[ai] = ARR_NONE; }
                 const float vn = L.vnx[s];
-                const float vref = LR.vmax * G.sf[eo + s];
+                const float vref = LR.vmax * sfv;
                 if (tick == P.n_ticks - 1) G.accel[eo + s] = vn - L.speed[s];
                 L.speed[s] = vn;
                 if (vn <= HALT_SPEED) { int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1); halted += 1; }
                 else L.swait[s] = 0;
-                float tl = G.tloss[eo + s];
-                if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss[eo + s] = tl; }
-                float x = L.pos[s] + vn;
+                float tl = L.tloss[s];
+                if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; L.tloss[s] = tl; }
+                float x = L.node[s].pos + vn;
                 int rq = L.rq[s];
                 bool arrived = false, moved = false;
                 for (int it = 0; it < 16; ++it) {
@@ -674,20 +705,20 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     moved = true;
                 }
                 if (arrived) {
-                    L.lane[s] = LANE_NONE; L.trip[s] = 0xFFFF;
+                    L.lane[s] = LANE_NONE; L.node[s].trip = 0xFFFF;
                     G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0;
                     atomicAdd(&L.sc[SC_STATS + ST_ARRIVED], 1);
                     atomicAdd(&L.sc[SC_STATS + ST_DURATION], t + 1 - (int)G.depart[eo + s]);
                     atomicAdd(&L.sc[SC_STATS + ST_TLOSS], (int)(tl * 1024.0f + 0.5f));
                 } else {
-                    L.pos[s] = x;
+                    L.node[s].pos = x;
                     if (moved) {
                         L.lane[s] = (uint16_t)lane; L.rq[s] = (uint16_t)rq;
                         L.nlink[s] = (uint16_t)choose_link(T, LR, rq);
                     }
                     active += 1;
                     top = s + 1;
-                    L.nxt[s] = list_push(L, lane, s);        // P6 fused: the heads were cleared before the barrier
+                    L.node[s].nxt = list_push(hn, lane, s, vn > HALT_SPEED);
                 }
             }
             if (active) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
@@ -695,7 +726,9 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (top) atomicMax(&L.sc[SC_HWNEW], top);
         }
         __syncthreads();
-        // ---- P7a: lane-change decisions (all changes of a tick go the same way: left on even ticks)
+        PROF_MARK(6)
+        // ---- E: lane-change decisions on the moved state (all changes of a tick go the same way: left on even
+        //         ticks); the next tick's TLS events and slot allocation are prepared in the same phase
         const int hw2 = L.sc[SC_HWNEW];
         const int dir_allowed = (t & 1) ? -1 : +1;
         for (int s = tid; s < hw2; s += B) {
@@ -708,11 +741,12 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 const int kk = lane - l0;
                 const int tk = kk + dir_allowed;
                 if (!(LR.flags & LF_INTERNAL) && n >= 2 && tk >= 0 && tk < n) {
-                    const int k = L.trip[s];
+                    const int k = L.node[s].trip;
                     const uint32_t m2 = T.route_mask2[L.rq[s]];
                     const float *vt = L.vtp + L.vt[s] * VT_COLS;
-                    const float x = L.pos[s], v = L.speed[s];
+                    const float x = L.node[s].pos, v = L.speed[s];
                     const int tl = l0 + tk;
+                    const float lane_len = LR.len;
                     int want = 0;
                     int lead_t = NIL, foll_t = NIL;
                     if (!((m2 >> kk) & 1u)) {
@@ -722,31 +756,31 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                         int dir = 0;
                         if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
                         want = (dir == dir_allowed) ? 2 : 0;
-                        if (want) neighbours(L, tl, x, k, s, lead_t, foll_t);
-                    } else if ((m2 >> tk) & 1u) {
+                        if (want) neighbours(L, hn, tl, x, k, s, lead_t, foll_t);
+                    } else if (((m2 >> tk) & 1u) && ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) == 0u) {
                         int lead_c, foll_c;
-                        neighbours(L, lane, x, k, s, lead_c, foll_c);
+                        neighbours(L, hn, lane, x, k, s, lead_c, foll_c);
                         if (lead_c != NIL) {
-                            neighbours(L, tl, x, k, s, lead_t, foll_t);
-                            float gcur = L.pos[lead_c] - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
+                            neighbours(L, hn, tl, x, k, s, lead_t, foll_t);
+                            float gcur = L.node[lead_c].pos - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
                             float gtgt = BIGF;
-                            if (lead_t != NIL) gtgt = L.pos[lead_t] - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
+                            if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
                             if (gcur < v * 3.0f + 15.0f && gtgt > gcur + SG_ADVANTAGE) want = 1;
                         }
                     }
                     if (want) {
-                        const bool urgent = want == 2 && (LR.len - x) <= URGENT_DIST;
+                        const bool urgent = want == 2 && (lane_len - x) <= URGENT_DIST;
                         bool safe = true;
                         if (lead_t != NIL) {
                             const float *vo = L.vtp + L.vt[lead_t] * VT_COLS;
-                            float gap = L.pos[lead_t] - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
+                            float gap = L.node[lead_t].pos - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
                             float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
                             float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
                             if (gap < 0.0f || vb > d_follow_speed(gap, L.speed[lead_t], vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
                         }
                         if (safe && foll_t != NIL) {
                             const float *vo = L.vtp + L.vt[foll_t] * VT_COLS;
-                            float gap = x - vt[VT_LENGTH] - L.pos[foll_t] - (urgent ? 0.0f : vo[VT_MINGAP]);
+                            float gap = x - vt[VT_LENGTH] - L.node[foll_t].pos - (urgent ? 0.0f : vo[VT_MINGAP]);
                             float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
                             float vb = L.speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
                             if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
@@ -759,10 +793,15 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (target >= 0) L.sc[SC_NLC] = 1;
         }
         if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
+        if (tick + 1 < P.n_ticks) {
+            TLS_BEGIN_OF_TICK(tick + 1)
+            ALLOCATE_SLOTS(t + 1)       // wave 0; tid 0 has just published hw2 (same wave, program order)
+        }
         __syncthreads();
-        // ---- P7b: only when somebody changes lane: apply, rebuild the lists
+        PROF_MARK(7)
+        // ---- F: only when somebody changes lane: apply, rebuild the lists
         if (L.sc[SC_NLC]) {
-            for (int i = tid; i < (T.n_lanes + 2) / 2; i += B) ((uint32_t *)L.head)[i] = 0xFFFFFFFFu;
+            heads_clear(hn, T.n_lanes, tid, B);
             for (int s = tid; s < hw2; s += B) {
                 const int target = __float_as_int(L.vnx[s]);
                 if (L.lane[s] < LANE_PENDING && target >= 0) {
@@ -773,11 +812,14 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             __syncthreads();
             for (int s = tid; s < hw2; s += B) {
                 const int ln = L.lane[s];
-                if (ln < LANE_PENDING) L.nxt[s] = list_push(L, ln, s);
+                if (ln < LANE_PENDING) L.node[s].nxt = list_push(hn, ln, s, L.speed[s] > HALT_SPEED);
             }
             __syncthreads();
+            PROF_MARK(8)
         }
     }
+#undef TLS_BEGIN_OF_TICK
+#undef ALLOCATE_SLOTS
 
     // ---- Signal.observe for every signal (traffic_signal.py:189-247)
     for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
@@ -789,19 +831,19 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         int act = 0, pend = 0;
         for (int s = tid; s < top; s += B) {
             const int lane = L.lane[s];
-            G.lane[eo + s] = (uint16_t)lane; G.trip[eo + s] = L.trip[s];
+            G.lane[eo + s] = (uint16_t)lane; G.trip[eo + s] = L.node[s].trip;
             if (lane == LANE_NONE) continue;
             // store the slab back (once per env-step)
             const int rq = L.rq[s];
-            G.pos[eo + s] = L.pos[s]; G.speed[eo + s] = L.speed[s]; G.swait[eo + s] = L.swait[s];
-            G.cursor[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.trip[s]]].start);
+            G.pos[eo + s] = L.node[s].pos; G.speed[eo + s] = L.speed[s]; G.swait[eo + s] = L.swait[s]; G.tloss[eo + s] = L.tloss[s];
+            G.cursor[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.node[s].trip]].start);
             if (lane == LANE_PENDING) { pend += 1; continue; }
             act += 1;
             const LaneRec LR = T.lanes[lane];
             const int oi = LR.obs;
             bool detect = false;
             if (oi >= 0) {
-                float d = (LR.len - L.pos[s]) + T.rsteps[rq].tlsdist;
+                float d = (LR.len - L.node[s].pos) + T.rsteps[rq].tlsdist;
                 detect = d <= P.max_distance;
             }
             if (!detect) { G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0; continue; }
@@ -820,6 +862,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         if (pend) atomicAdd(&L.sc[SC_STATS + ST_PENDING], pend);
     }
     __syncthreads();
+    PROF_MARK(9)
     // per observed lane rows
     for (int oi = tid; oi < NO; oi += B) {
         const int sg = T.obs_sig[oi];
@@ -835,7 +878,20 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         __half *dh = O.drq_f16 + (((size_t)env * S + sg) * T.lmax + (oi - o0)) * 5;
         dh[0] = __float2half(d0); dh[1] = __float2half(d1); dh[2] = __float2half(d2); dh[3] = __float2half(d3); dh[4] = __float2half(d4);
     }
-    // per signal: state vectors and rewards
+    // states.mplight / states.wave: one thread per (signal, movement)
+    for (int i = tid; i < S * 12; i += B) {
+        const int sg = i / 12, m = i - sg * 12;
+        int q = 0, wv = 0;
+        for (int j = T.mv_in_start[i]; j < T.mv_in_start[i + 1]; ++j) {
+            const int oi = T.mv_in_idx[j];
+            q += L.agg_q[oi]; wv += L.agg_q[oi] + L.agg_a[oi];
+        }
+        for (int j = T.mv_out_start[i]; j < T.mv_out_start[i + 1]; ++j) q -= L.agg_q[T.mv_out_idx[j]];
+        const size_t so = (size_t)env * S + sg;
+        O.mplight[so * 13 + 1 + m] = q;
+        O.wave[so * 12 + m] = wv;
+    }
+    // per signal: phase, rewards, metrics
     for (int sg = tid; sg < S; sg += B) {
         const int ph = L.phase[sg];
         const int o0 = T.sig_obs_start[sg], o1 = T.sig_obs_start[sg + 1];
@@ -850,21 +906,12 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         for (int i = T.pr_out_start[sg]; i < T.pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.pr_out_idx[i]];
         O.pressure[so] = -pr;
         O.mplight[so * 13] = ph;
-        for (int m = 0; m < 12; ++m) {
-            int q = 0, wv = 0;
-            for (int i = T.mv_in_start[sg * 12 + m]; i < T.mv_in_start[sg * 12 + m + 1]; ++i) {
-                const int oi = T.mv_in_idx[i];
-                q += L.agg_q[oi]; wv += L.agg_q[oi] + L.agg_a[oi];
-            }
-            for (int i = T.mv_out_start[sg * 12 + m]; i < T.mv_out_start[sg * 12 + m + 1]; ++i) q -= L.agg_q[T.mv_out_idx[i]];
-            O.mplight[so * 13 + 1 + m] = q;
-            O.wave[so * 12 + m] = wv;
-        }
         G.tls[(env * S + sg) * 3 + 0] = ph;
         G.tls[(env * S + sg) * 3 + 1] = L.left[sg];
         G.tls[(env * S + sg) * 3 + 2] = L.nextp[sg];
     }
     __syncthreads();
+    PROF_MARK(10)
     if (tid < 3) G.env[env * 4 + tid] = L.sc[tid];
     if (tid < ST_N) {
         long long *st = G.stats + (size_t)env * ST_N;
@@ -938,6 +985,7 @@ struct rs_sim {
     KParams P{};
     int32_t *actions = nullptr;
     int32_t *pairs = nullptr, *valid = nullptr, *order = nullptr;
+    unsigned long long *prof = nullptr;
     int n_pairs = 0;
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
@@ -1001,7 +1049,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { h->err = "no HIP device visible (this library has no CPU fallback)"; return fail(RS_EHIP); }
     if (hipSetDevice(device_id) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(RS_EHIP); }
     const int C = sc->capacity;
-    if (C < 64 || (C & (C - 1)) || C > 32768) { h->err = "capacity must be a power of two in [64, 32768]"; return fail(RS_ELIMIT); }
+    if (C < 64 || (C & (C - 1)) || C > 16384) { h->err = "capacity must be a power of two in [64, 16384]"; return fail(RS_ELIMIT); }
     if (sc->n_lanes >= 0xFFFE || sc->n_trips >= 0xFFFF || sc->n_routes > 0xFFFF || sc->n_vtypes > 255 || sc->n_signals > 254) {
         h->err = "scenario exceeds id widths (lanes/trips/routes u16, vtypes/signals u8)"; return fail(RS_ELIMIT);
     }
@@ -1120,8 +1168,8 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         K.mv_out_start = T.mv_out_start; K.mv_out_idx = T.mv_out_idx; K.pr_out_start = T.pr_out_start; K.pr_out_idx = T.pr_out_idx;
         K.n_lanes = sc->n_lanes; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
         K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = lmax;
-        K.n_arr = n_foe_targets > n_dep ? n_foe_targets : n_dep;
-        if (K.n_arr < 1) K.n_arr = 1;
+        K.n_arr = n_foe_targets > 0 ? n_foe_targets : 1;
+        K.n_dep = n_dep > 0 ? n_dep : 1;
         T.n_arr = K.n_arr;
     }
 
@@ -1173,12 +1221,12 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_DRQ_NORM_F16, O.drq_f16, RS_F16, 4, n, s, lmax, 5);
     set_buf(h, RS_BUF_VEH_SF, G.sf, RS_F32, 2, n, c);
 
-    h->lds = lds_bytes_for(C, sc->n_lanes, T.n_arr, sc->n_obs, sc->n_signals, sc->n_vtypes);
+    h->lds = lds_bytes_for(C, sc->n_lanes, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
     if (block_threads <= 0) {
         block_threads = C >= 512 ? 512 : (C >= 256 ? 256 : (C >= 128 ? 128 : 64));
     }
-    if (block_threads % 64 || block_threads > 512 || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 512]"; return fail(RS_EINVAL); }
+    if (block_threads % 64 || block_threads > 1024 || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024]"; return fail(RS_EINVAL); }
     h->block = block_threads;
     if (hipFuncSetAttribute((const void *)rs_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
         h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
@@ -1203,7 +1251,7 @@ extern "C" const char *rs_last_error(rs_handle h) { return h ? h->err.c_str() : 
 
 static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
     KParams P = h->P;
-    P.n_ticks = n_ticks; P.do_fsm = do_fsm;
+    P.n_ticks = n_ticks; P.do_fsm = do_fsm; P.prof = h->prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         if (h->ev_used == h->events.size()) {
@@ -1368,6 +1416,17 @@ extern "C" int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches) {
     if (total_ms) *total_ms = tot;
     if (launches) *launches = (int32_t)h->ev_used;
     h->ev_used = 0;
+    return RS_OK;
+}
+
+extern "C" int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->prof && host_out16) HIPCHK(h, hipMemcpy(host_out16, h->prof, 16 * 8, hipMemcpyDeviceToHost));
+    if (enable && !h->prof) { int rc = dev_alloc(h, &h->prof, 16); if (rc) return rc; }
+    if (h->prof) HIPCHK(h, hipMemset(h->prof, 0, 16 * 8));
+    if (!enable) h->prof = nullptr;     // the allocation stays on the handle's free list
     return RS_OK;
 }
 

@@ -26,7 +26,7 @@ STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_wai
 # every symbol include/resco_sim.h declares
 ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
-               'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_info']
+               'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_phase_profile', 'rs_info']
 
 _lib = None
 
@@ -61,6 +61,7 @@ def load_library():
     L.rs_timing.argtypes = [vp, i32]
     L.rs_timing_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
     L.rs_set_seed.argtypes = [vp, C.c_uint32]
+    L.rs_phase_profile.argtypes = [vp, i32, vp]
     L.rs_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
@@ -201,6 +202,12 @@ class BatchedSim:
 
     def free_snapshot(self, snap):
         self._lib.rs_snapshot_free(self._h, snap)
+
+    def phase_profile(self, enable):
+        """Enable/disable the in-kernel phase timers; returns the 16 accumulators collected so far."""
+        out = (C.c_uint64 * 16)()
+        self._check(self._lib.rs_phase_profile(self._h, 1 if enable else 0, out))
+        return [int(x) for x in out]
 
     def timing(self, enable):
         self._check(self._lib.rs_timing(self._h, 1 if enable else 0))
