@@ -45,6 +45,19 @@ def algorithmic_bytes_per_env_step(sc, mean_active):
     return mean_active * per_vehicle + S * per_signal + O * 40 + S * lmax * 10 + 24 + 80
 
 
+def pmc_traffic_bytes_per_launch():
+    """HBM bytes per launch of rs_step_kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
+    this same workload, profiles/r01_v3_pmc_summary.json): 2 x FETCH_SIZE (the gfx950 half-count correction of
+    MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both reported in KiB.  None when no summary is committed."""
+    path = os.path.join(ROOT, 'profiles', 'r01_v3_pmc_summary.json')
+    try:
+        with open(path) as f:
+            c = json.load(f)['counters']
+        return (2.0 * c['FETCH_SIZE']['per_launch_avg'] + c['WRITE_SIZE']['per_launch_avg']) * 1024.0
+    except Exception:
+        return None
+
+
 def run_timed(sim, steps, warmup, barrier, sync, reduce_max):
     """W untimed steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks."""
     k = 0
@@ -184,7 +197,11 @@ def main():
                    'block_threads': info['block_threads'], 'lds_bytes_per_env': info['lds_bytes'],
                    'parallelism': 'env-batch split x%d, no collective on the data path' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBS,
+                     'traffic': pmc_traffic_bytes_per_launch() if (args.map == 'ingolstadt21' and n_local == 4096) else None,
+                     'traffic_note': 'bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload '
+                                     '(profiles/r01_v3_pmc_summary.json, steps 60..160 of the episode); algorithmic bytes per '
+                                     'launch = algorithmic_bytes_per_env_step x env_steps_per_launch',
                      'kernel': 'rs_step_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
                      'algorithmic_bytes_per_env_step': b_alg, 'env_steps_per_launch': n_local,
                      'note': 'state is Infinity-Cache resident and the kernel is issue/latency bound: the HBM '
