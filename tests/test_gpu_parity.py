@@ -285,3 +285,34 @@ def test_zero_copy_tensors_at_the_agent_boundary():
     np.testing.assert_array_equal(rew['pressure'].cpu().numpy(), env.sim.read('pressure'))
     assert float(rew['wait'].min()) < 0
     env.close()
+
+
+def test_idqn_rollout_on_fp16_observations():
+    """BASELINE config 5 interface: the batched IDQN consumes drq_norm_f16 directly; actions stay on device."""
+    import torch
+    from resco_amd.agents.idqn_rollout import BatchedIDQN
+    from resco_amd.multi_signal import VecMultiSignal
+    env = VecMultiSignal('ingolstadt21', 256, states=('drq_norm_f16', 'drq_norm'), rewards=('wait_norm',), seed=4)
+    net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float16, device='cuda')
+    mods = net.init_like_reference(seed=1)
+    stream = torch.cuda.current_stream().cuda_stream
+    obs = env.reset(stream)
+    for k in range(25):
+        a = net.act(obs['drq_norm_f16'], epsilon=0.2)
+        assert a.dtype == torch.int32 and a.is_cuda
+        obs, rew, done, _ = env.step(a, stream)
+    torch.cuda.synchronize()
+    # the fp16 padded tensor is the fp32 drq_norm re-laid out per signal
+    sc = env.scenario
+    h = obs['drq_norm_f16'].float().cpu().numpy()
+    f = obs['drq_norm'].cpu().numpy()
+    for s in (0, 13, 20):
+        o0, o1 = sc.sig_obs_start[s], sc.sig_obs_start[s + 1]
+        np.testing.assert_allclose(h[:, s, :o1 - o0], f[:, o0:o1], rtol=2e-3, atol=2e-3)
+    # Q-values of the batched fp16 network vs the per-signal fp32 reference-architecture modules
+    q = net(obs['drq_norm_f16']).float().cpu()
+    s, L, A = 13, net.lanes[13], net.actions[13]
+    ref = mods[s](torch.from_numpy(h[:, s, :L]).unsqueeze(1))
+    np.testing.assert_allclose(q[:, s, :A].detach().numpy(), ref.detach().numpy(), rtol=5e-2, atol=5e-2)
+    assert float(rew['wait_norm'].min()) >= -4.0
+    env.close()
