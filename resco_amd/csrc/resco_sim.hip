@@ -161,7 +161,7 @@ struct __attribute__((aligned(16))) LaneRec {
     uint16_t link_start;
     uint8_t link_cnt;
     uint8_t flags;          // bit0 junction-internal; bits 2..7 number of lanes of the edge
-    int16_t obs;            // observed-lane index or -1
+    uint16_t cell0;         // first list cell of this lane (cells of CELL_LEN metres, floor(len/CELL_LEN)+1 per lane)
     uint16_t edge_lane0;
 };
 struct __attribute__((aligned(16))) LinkRec {
@@ -171,11 +171,14 @@ struct __attribute__((aligned(16))) LinkRec {
     uint8_t foe_cnt, flags;                         // flags bit0 minor, bit1 cont, bit2 to_lane is internal (= via1)
     uint8_t dest_k, pad;                            // lane index of the destination lane inside to_edge
 };
-struct __attribute__((aligned(8))) FoeRec {
+struct __attribute__((aligned(16))) FoeRec {
     int16_t arr_idx;
     uint8_t tls, tls_pos;
-    uint16_t via1, via2;
+    uint16_t via1_cell0, via2_cell0;    // first cell of the foe's junction lanes (0xFFFF: none)
+    uint8_t via1_nc, via2_nc, pad[6];   // number of cells of those lanes
 };
+#define CELL_LEN 64.0f
+#define CELL_INV (1.0f / 64.0f)
 struct __attribute__((aligned(16))) RStep {
     uint16_t edge, next_edge;       // next_edge 0xFFFF: last edge of the route
     uint32_t next_mask2, next_mask1;
@@ -205,8 +208,9 @@ struct KTab {
     const uint8_t *tls8, *fix8;
     const int32_t *tls_nphase, *tls_ngreen, *tls_nlinks, *tls_state_off, *tls_dur_off, *tls_yel_off, *tls_dur, *tls_yellow;
     const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_dur;
+    const int16_t *lane_obs;
     const int32_t *obs_sig, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx, *pr_out_start, *pr_out_idx;
-    int32_t n_lanes, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
+    int32_t n_lanes, n_cells, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
 };
 
 // ------------------------------------------------------------------------------------------------ LDS view
@@ -240,14 +244,14 @@ __host__ __device__ inline size_t lds_scratch_bytes(int C, int n_obs) {       //
     size_t a = (size_t)C * 4, b = align16((size_t)n_obs * 4) * 5;
     return a > b ? a : b;
 }
-__host__ __device__ inline size_t lds_bytes_for(int C, int n_lanes, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
+__host__ __device__ inline size_t lds_bytes_for(int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
     size_t o = 0;
     o += align16((size_t)C * 8);                     // node {pos, trip, nxt}
     o += align16((size_t)C * 4) * 2;                 // speed tloss
     o += align16(lds_scratch_bytes(C, n_obs));       // vnx | aggregates
     o += align16((size_t)n_vt * VT_COLS * 4);        // vtype table
     o += align16((size_t)C * 2) * 4;                 // lane rq swait nlink
-    o += align16((size_t)(n_lanes + 2) * 2);         // head (u16, CAS on the containing dword)
+    o += align16((size_t)(n_cells + 2) * 2);         // head per list cell (u16, CAS on the containing dword)
     o += align16((size_t)C);                         // vt
     o += align16((size_t)n_arr * 4);                 // approach registers
     o += align16((size_t)n_dep * 4);                 // insertion candidates
@@ -255,7 +259,7 @@ __host__ __device__ inline size_t lds_bytes_for(int C, int n_lanes, int n_arr, i
     o += align16((size_t)(SC_STATS + ST_N) * 4);
     return o;
 }
-__device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_lanes, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
+__device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
     size_t o = 0;
 #define CARVE(field, type, bytes) L.field = (type *)(base + o); o += align16(bytes);
     CARVE(node, Node, (size_t)C * 8) CARVE(speed, float, (size_t)C * 4) CARVE(tloss, float, (size_t)C * 4)
@@ -270,7 +274,7 @@ __device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_lanes
     CARVE(vtp, float, (size_t)n_vt * VT_COLS * 4)
     CARVE(lane, uint16_t, (size_t)C * 2)
     CARVE(rq, uint16_t, (size_t)C * 2) CARVE(swait, uint16_t, (size_t)C * 2) CARVE(nlink, uint16_t, (size_t)C * 2)
-    CARVE(head, uint16_t, (size_t)(n_lanes + 2) * 2)
+    CARVE(head, uint16_t, (size_t)(n_cells + 2) * 2)
     CARVE(vt, uint8_t, (size_t)C)
     CARVE(arr, int32_t, (size_t)n_arr * 4) CARVE(dep, int32_t, (size_t)n_dep * 4)
     CARVE(phase, int32_t, (size_t)S * 4) CARVE(left, int32_t, (size_t)S * 4) CARVE(nextp, int32_t, (size_t)S * 4)
@@ -336,23 +340,56 @@ __device__ __forceinline__ int tls_state(const KTab &T, const Lds &L, const KPar
     return tab[L.tbase[tls] + pos];
 }
 
-__device__ __forceinline__ int rearmost(const Lds &L, const uint16_t *head, int lane) {
-    int best = NIL, bk = 0;
-    float bp = 0.0f;
-    for (int s = head[lane] & 0x7FFF; s != NIL;) {
-        const Node nd = L.node[s];
-        const int k = nd.trip;
-        const float p = nd.pos;
-        if (best == NIL || p < bp || (p == bp && k > bk)) { best = s; bk = k; bp = p; }
-        s = nd.nxt;
+__device__ __forceinline__ int lane_cells(const LaneRec &LR) { return (int)(LR.len * CELL_INV) + 1; }
+__device__ __forceinline__ int cell_of(float pos, int ncell) { const int c = (int)(pos * CELL_INV); return c < ncell ? c : ncell - 1; }
+
+// rear-most vehicle of a lane (min pos, ties -> larger trip index): the first non-empty cell holds it
+__device__ __forceinline__ int rearmost(const Lds &L, const uint16_t *head, int cell0, int ncell) {
+    for (int c = 0; c < ncell; ++c) {
+        int s = head[cell0 + c] & 0x7FFF;
+        if (s == NIL) continue;
+        int best = NIL, bk = 0;
+        float bp = 0.0f;
+        while (s != NIL) {
+            const Node nd = L.node[s];
+            const int k = nd.trip;
+            const float p = nd.pos;
+            if (best == NIL || p < bp || (p == bp && k > bk)) { best = s; bk = k; bp = p; }
+            s = nd.nxt;
+        }
+        return best;
     }
-    return best;
+    return NIL;
 }
 
-__device__ __forceinline__ void neighbours(const Lds &L, const uint16_t *head, int lane, float pos, int k, int self, int &lead, int &foll) {
+// nearest vehicle ahead of (pos, k) on the lane: my own cell first, then the first non-empty cell further on
+__device__ __forceinline__ int leader_of(const Lds &L, const uint16_t *head, int cell0, int ncell, float pos, int k, int self) {
+    int Ld = NIL, Lk = 0;
+    float Lp = 0.0f;
+    int c = cell_of(pos, ncell);
+    for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
+        const Node nd = L.node[s];
+        const int cur = s;
+        s = nd.nxt;
+        if (cur == self) continue;
+        if (ahead_of(nd.pos, nd.trip, pos, k) && (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip))) { Ld = cur; Lk = nd.trip; Lp = nd.pos; }
+    }
+    for (c += 1; Ld == NIL && c < ncell; ++c) {
+        for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
+            const Node nd = L.node[s];
+            if (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip)) { Ld = s; Lk = nd.trip; Lp = nd.pos; }
+            s = nd.nxt;
+        }
+    }
+    return Ld;
+}
+
+// nearest vehicles ahead of and behind (pos, k) on the lane
+__device__ __forceinline__ void neighbours(const Lds &L, const uint16_t *head, int cell0, int ncell, float pos, int k, int self, int &lead, int &foll) {
     int Ld = NIL, Fd = NIL, Lk = 0, Fk = 0;
     float Lp = 0.0f, Fp = 0.0f;
-    for (int s = head[lane] & 0x7FFF; s != NIL;) {
+    const int c0 = cell_of(pos, ncell);
+    for (int s = head[cell0 + c0] & 0x7FFF; s != NIL;) {
         const Node nd = L.node[s];
         const int cur = s;
         s = nd.nxt;
@@ -365,7 +402,24 @@ __device__ __forceinline__ void neighbours(const Lds &L, const uint16_t *head, i
             if (Fd == NIL || ahead_of(ps, ks, Fp, Fk)) { Fd = cur; Fk = ks; Fp = ps; }
         }
     }
+    for (int c = c0 + 1; Ld == NIL && c < ncell; ++c)
+        for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
+            const Node nd = L.node[s];
+            if (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip)) { Ld = s; Lk = nd.trip; Lp = nd.pos; }
+            s = nd.nxt;
+        }
+    for (int c = c0 - 1; Fd == NIL && c >= 0; --c)
+        for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
+            const Node nd = L.node[s];
+            if (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk)) { Fd = s; Fk = nd.trip; Fp = nd.pos; }
+            s = nd.nxt;
+        }
     lead = Ld; foll = Fd;
+}
+
+__device__ __forceinline__ bool cells_have_mover(const uint16_t *head, int cell0, int nc) {
+    for (int c = 0; c < nc; ++c) if (head[cell0 + c] & 0x8000) return true;
+    return false;
 }
 
 __device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const uint16_t *head, const KParams &P, const LinkRec &K) {
@@ -373,8 +427,8 @@ __device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const u
         const FoeRec F = T.foes[i];
         if (F.tls != 0xFF && tls_state(T, L, P, F.tls, F.tls_pos) == TLS_R) continue;
         if (F.arr_idx >= 0 && L.arr[F.arr_idx] < FOE_GAP_Q) return true;
-        if (F.via1 != 0xFFFF && (head[F.via1] & 0x8000)) return true;      // a moving vehicle on the foe's junction lanes
-        if (F.via2 != 0xFFFF && (head[F.via2] & 0x8000)) return true;
+        if (F.via1_cell0 != 0xFFFF && cells_have_mover(head, F.via1_cell0, F.via1_nc)) return true;   // a moving vehicle on
+        if (F.via2_cell0 != 0xFFFF && cells_have_mover(head, F.via2_cell0, F.via2_nc)) return true;   // the foe's junction lanes
     }
     return false;
 }
@@ -398,7 +452,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     const int C = T.capacity, S = T.n_signals, NO = T.n_obs;
     const int genv = P.env_base + env;
     Lds L;
-    lds_carve(L, smem, C, T.n_lanes, T.n_arr, T.n_dep, NO, S, T.n_vtypes);
+    lds_carve(L, smem, C, T.n_cells, T.n_arr, T.n_dep, NO, S, T.n_vtypes);
     unsigned long long pt_ = 0;
 #define PROF_START() if (P.prof && tid == 0) pt_ = wall_clock64();
 #define PROF_MARK(i_) if (P.prof && tid == 0) { unsigned long long n_ = wall_clock64(); atomicAdd(&P.prof[i_], n_ - pt_); pt_ = n_; }
@@ -410,7 +464,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     // ---- load the environment slab (once per env-step)
     if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 3 ? G.env[env * 4 + tid] : 0;
     for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.vtype_params[i];
-    heads_clear(L.head, T.n_lanes, tid, B);
+    heads_clear(L.head, T.n_cells, tid, B);
     for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
     for (int i = tid; i < T.n_dep; i += B) L.dep[i] = ARR_NONE;
     for (int i = tid; i < S; i += B) {
@@ -436,8 +490,9 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 L.vt[s] = T.trip_vtype[tr];
                 int nl = -1;
                 if (ln != LANE_PENDING) {
-                    nl = choose_link(T, T.lanes[ln], rq);
-                    L.node[s].nxt = list_push(hc, ln, s, sp > HALT_SPEED);
+                    const LaneRec LR0 = T.lanes[ln];
+                    nl = choose_link(T, LR0, rq);
+                    L.node[s].nxt = list_push(hc, LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0)), s, sp > HALT_SPEED);
                 } else npend += 1;
                 L.nlink[s] = (uint16_t)nl;
             }
@@ -551,19 +606,21 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 if (L.dep[RR.depart_arr] != k) continue;        // lost (or the winner already cleared the register)
                 const int dl = RR.depart_lane;
                 const float *vt = L.vtp + L.vt[s] * VT_COLS;
-                const float ll = T.lanes[dl].len;
+                const LaneRec LRd = T.lanes[dl];
+                const float ll = LRd.len;
                 const float mypos = vt[VT_LENGTH] < ll ? vt[VT_LENGTH] : ll;
                 bool ins = true;
-                for (int o = hc[dl] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
+                // only vehicles with pos < mypos + minGap + length can be in the way: they all sit in cell 0
+                for (int o = hc[LRd.cell0] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
                     float back = L.node[o].pos - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
                     if (back - mypos - vt[VT_MINGAP] < 0.0f) ins = false;
                 }
                 L.dep[RR.depart_arr] = ARR_NONE;
                 if (!ins) continue;
                 L.lane[s] = (uint16_t)dl; L.node[s].pos = mypos; L.speed[s] = 0.0f;
-                L.nlink[s] = (uint16_t)choose_link(T, T.lanes[dl], RR.start);
+                L.nlink[s] = (uint16_t)choose_link(T, LRd, RR.start);
                 G.depart[eo + s] = (uint16_t)t;
-                L.node[s].nxt = list_push(hc, dl, s, false);
+                L.node[s].nxt = list_push(hc, LRd.cell0 + cell_of(mypos, lane_cells(LRd)), s, false);
                 atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
                 atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.trip_depart[k]);
                 atomicSub(&L.sc[SC_NPEND], 1);
@@ -587,8 +644,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (vl < vfree) vfree = vl;
             if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
             float vsafe = BIGF;
-            int lead, foll;
-            neighbours(L, hc, lane, x, k, s, lead, foll);
+            const int lead = leader_of(L, hc, LR.cell0, lane_cells(LR), x, k, s);
             bool found = false;
             if (lead != NIL) {
                 const float *vo = L.vtp + L.vt[lead] * VT_COLS;
@@ -635,7 +691,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                         if (vs < vsafe) vsafe = vs;
                     }
                 }
-                const int o = rearmost(L, hc, nl);
+                const int o = rearmost(L, hc, LR.cell0, lane_cells(LR));
                 if (o != NIL) {
                     const float *vo = L.vtp + L.vt[o] * VT_COLS;
                     float gap = seen + L.node[o].pos - vo[VT_LENGTH] - mingap;
@@ -664,7 +720,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         }
         __syncthreads();
         PROF_MARK(4)
-        heads_clear(L.head, T.n_lanes, tid, B);     // nobody reads the lists between plan and move
+        heads_clear(L.head, T.n_cells, tid, B);     // nobody reads the lists between plan and move
         __syncthreads();
         PROF_MARK(5)
         // ---- D: move; drop this tick's approach registrations; build the lists of the moved state
@@ -718,7 +774,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     }
                     active += 1;
                     top = s + 1;
-                    L.node[s].nxt = list_push(hn, lane, s, vn > HALT_SPEED);
+                    L.node[s].nxt = list_push(hn, LR.cell0 + cell_of(x, lane_cells(LR)), s, vn > HALT_SPEED);
                 }
             }
             if (active) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
@@ -747,6 +803,8 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     const float x = L.node[s].pos, v = L.speed[s];
                     const int tl = l0 + tk;
                     const float lane_len = LR.len;
+                    const int nc = lane_cells(LR);
+                    const int tcell0 = (int)LR.cell0 + dir_allowed * nc;     // lanes of an edge own consecutive cell blocks
                     int want = 0;
                     int lead_t = NIL, foll_t = NIL;
                     if (!((m2 >> kk) & 1u)) {
@@ -756,12 +814,11 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                         int dir = 0;
                         if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
                         want = (dir == dir_allowed) ? 2 : 0;
-                        if (want) neighbours(L, hn, tl, x, k, s, lead_t, foll_t);
+                        if (want) neighbours(L, hn, tcell0, nc, x, k, s, lead_t, foll_t);
                     } else if (((m2 >> tk) & 1u) && ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) == 0u) {
-                        int lead_c, foll_c;
-                        neighbours(L, hn, lane, x, k, s, lead_c, foll_c);
+                        const int lead_c = leader_of(L, hn, LR.cell0, nc, x, k, s);
                         if (lead_c != NIL) {
-                            neighbours(L, hn, tl, x, k, s, lead_t, foll_t);
+                            neighbours(L, hn, tcell0, nc, x, k, s, lead_t, foll_t);
                             float gcur = L.node[lead_c].pos - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
                             float gtgt = BIGF;
                             if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
@@ -801,7 +858,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         PROF_MARK(7)
         // ---- F: only when somebody changes lane: apply, rebuild the lists
         if (L.sc[SC_NLC]) {
-            heads_clear(hn, T.n_lanes, tid, B);
+            heads_clear(hn, T.n_cells, tid, B);
             for (int s = tid; s < hw2; s += B) {
                 const int target = __float_as_int(L.vnx[s]);
                 if (L.lane[s] < LANE_PENDING && target >= 0) {
@@ -812,7 +869,10 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             __syncthreads();
             for (int s = tid; s < hw2; s += B) {
                 const int ln = L.lane[s];
-                if (ln < LANE_PENDING) L.node[s].nxt = list_push(hn, ln, s, L.speed[s] > HALT_SPEED);
+                if (ln < LANE_PENDING) {
+                    const LaneRec LRn = T.lanes[ln];
+                    L.node[s].nxt = list_push(hn, LRn.cell0 + cell_of(L.node[s].pos, lane_cells(LRn)), s, L.speed[s] > HALT_SPEED);
+                }
             }
             __syncthreads();
             PROF_MARK(8)
@@ -840,7 +900,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (lane == LANE_PENDING) { pend += 1; continue; }
             act += 1;
             const LaneRec LR = T.lanes[lane];
-            const int oi = LR.obs;
+            const int oi = T.lane_obs[lane];
             bool detect = false;
             if (oi >= 0) {
                 float d = (LR.len - L.node[s].pos) + T.rsteps[rq].tlsdist;
@@ -1094,9 +1154,33 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
             int e = sc->lane_edge[l];
             int nl = e >= 0 ? sc->edge_nlanes[e] : 0;
             R.flags = (uint8_t)((sc->lane_internal[l] ? LF_INTERNAL : 0u) | ((unsigned)nl << 2));
-            R.obs = (int16_t)sc->lane_obs[l];
+            R.cell0 = 0;        // filled below
             R.edge_lane0 = (uint16_t)(e >= 0 ? sc->edge_lane0[e] : 0);
         }
+        // list cells: floor(len / CELL_LEN) + 1 per lane, lanes in index order (lanes of one edge are consecutive
+        // and equally long, so their cell blocks are consecutive and equally sized -- relied on by the lane change)
+        int n_cells = 0;
+        std::vector<int> lane_nc((size_t)sc->n_lanes);
+        for (int l = 0; l < sc->n_lanes; ++l) {
+            lane_nc[l] = (int)(sc->lane_len[l] * CELL_INV) + 1;
+            lanes[l].cell0 = (uint16_t)n_cells;
+            n_cells += lane_nc[l];
+        }
+        if (n_cells >= 0x7FFF) { h->err = "too many list cells"; return fail(RS_ELIMIT); }
+        for (int e = 0; e < sc->n_edges; ++e)
+            for (int j = 1; j < sc->edge_nlanes[e]; ++j)
+                if (lane_nc[sc->edge_lane0[e] + j] != lane_nc[sc->edge_lane0[e]]) { h->err = "lanes of one edge differ in length"; return fail(RS_ELIMIT); }
+        {
+            float max_len = 0.0f, max_gap = 0.0f;
+            for (int v = 0; v < sc->n_vtypes; ++v) {
+                if (sc->vtype_params[v * VT_COLS + VT_LENGTH] > max_len) max_len = sc->vtype_params[v * VT_COLS + VT_LENGTH];
+                if (sc->vtype_params[v * VT_COLS + VT_MINGAP] > max_gap) max_gap = sc->vtype_params[v * VT_COLS + VT_MINGAP];
+            }
+            // the insertion check scans cell 0 only: everything that can be in the way must sit there
+            if (2.0f * max_len + max_gap >= CELL_LEN) { h->err = "vehicle length + minGap + length must stay below the list cell size"; return fail(RS_ELIMIT); }
+        }
+        std::vector<int16_t> lane_obs16((size_t)sc->n_lanes);
+        for (int l = 0; l < sc->n_lanes; ++l) lane_obs16[l] = (int16_t)sc->lane_obs[l];
         std::vector<LinkRec> links((size_t)sc->n_links);
         for (int l = 0; l < sc->n_links; ++l) {
             LinkRec &R = links[l];
@@ -1119,8 +1203,12 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
             R.arr_idx = link_arr[f];
             R.tls = sc->link_tls[f] >= 0 ? (uint8_t)sc->link_tls[f] : (uint8_t)0xFF;
             R.tls_pos = sc->link_tls[f] >= 0 ? (uint8_t)sc->link_tls_pos[f] : (uint8_t)0;
-            R.via1 = sc->link_via1[f] >= 0 ? (uint16_t)sc->link_via1[f] : (uint16_t)0xFFFF;
-            R.via2 = sc->link_via2[f] >= 0 ? (uint16_t)sc->link_via2[f] : (uint16_t)0xFFFF;
+            const int v1 = sc->link_via1[f], v2 = sc->link_via2[f];
+            R.via1_cell0 = v1 >= 0 ? lanes[v1].cell0 : (uint16_t)0xFFFF;
+            R.via2_cell0 = v2 >= 0 ? lanes[v2].cell0 : (uint16_t)0xFFFF;
+            R.via1_nc = v1 >= 0 ? (uint8_t)lane_nc[v1] : (uint8_t)0;
+            R.via2_nc = v2 >= 0 ? (uint8_t)lane_nc[v2] : (uint8_t)0;
+            memset(R.pad, 0, sizeof(R.pad));
         }
         std::vector<RStep> rsteps((size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1));
         std::vector<RouteRec> routes((size_t)sc->n_routes);
@@ -1158,6 +1246,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
             (rc = dev_upload<RouteRec>(h, &K.routes, routes.data(), routes.size())) ||
             (rc = dev_upload<uint16_t>(h, &K.trip_route, trip_route.data(), trip_route.size())) ||
             (rc = dev_upload<uint8_t>(h, &K.trip_vtype, trip_vtype.data(), trip_vtype.size())) ||
+            (rc = dev_upload<int16_t>(h, &K.lane_obs, lane_obs16.data(), lane_obs16.size())) ||
             (rc = dev_upload<uint8_t>(h, &K.tls8, tls8.data(), tls8.size())) || (rc = dev_upload<uint8_t>(h, &K.fix8, fix8.data(), fix8.size())))
             return fail(rc);
         K.route_mask2 = T.route_mask2; K.trip_depart = T.trip_depart; K.trips_cum = T.trips_cum; K.vtype_params = T.vtype_params;
@@ -1166,7 +1255,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         K.fix_nphase = T.fix_nphase; K.fix_state_off = T.fix_state_off; K.fix_dur_off = T.fix_dur_off; K.fix_dur = T.fix_dur;
         K.obs_sig = T.obs_sig; K.sig_obs_start = T.sig_obs_start; K.mv_in_start = T.mv_in_start; K.mv_in_idx = T.mv_in_idx;
         K.mv_out_start = T.mv_out_start; K.mv_out_idx = T.mv_out_idx; K.pr_out_start = T.pr_out_start; K.pr_out_idx = T.pr_out_idx;
-        K.n_lanes = sc->n_lanes; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
+        K.n_lanes = sc->n_lanes; K.n_cells = n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
         K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = lmax;
         K.n_arr = n_foe_targets > 0 ? n_foe_targets : 1;
         K.n_dep = n_dep > 0 ? n_dep : 1;
@@ -1221,7 +1310,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_DRQ_NORM_F16, O.drq_f16, RS_F16, 4, n, s, lmax, 5);
     set_buf(h, RS_BUF_VEH_SF, G.sf, RS_F32, 2, n, c);
 
-    h->lds = lds_bytes_for(C, sc->n_lanes, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes);
+    h->lds = lds_bytes_for(C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
     if (block_threads <= 0) {
         block_threads = C >= 512 ? 512 : (C >= 256 ? 256 : (C >= 128 ? 128 : 64));
