@@ -2,9 +2,7 @@
 which state / reward functions and detector range each one is run with.  Learner hyper-parameters
 (IDQN, IPPO, MPLight, FMA2C) are out of scope of the simulator build."""
 from .. import rewards, states
-from ..agents.maxpressure import MAXPRESSURE
-from ..agents.maxwave import MAXWAVE
-from ..agents.stochastic import STOCHASTIC
+from ..agents.static_agents import MAXPRESSURE, MAXWAVE, STOCHASTIC
 
 agent_configs = {
     'STOCHASTIC': {'agent': STOCHASTIC, 'state': states.mplight, 'reward': rewards.wait, 'max_distance': 1},

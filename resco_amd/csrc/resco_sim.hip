@@ -334,6 +334,15 @@ __device__ __forceinline__ int choose_link(const KTab &T, const LaneRec &LR, int
     return best >= 0 ? best : any;
 }
 
+// value cached in L.nlink: the link index (0x7FFF: none) with bit 15 set when the link owns an approach register
+#define NLINK_NONE 0x7FFF
+#define NLINK_ARR 0x8000
+__device__ __forceinline__ uint16_t cache_link(const KTab &T, const LaneRec &LR, int rq) {
+    const int link = choose_link(T, LR, rq);
+    if (link < 0) return NLINK_NONE;
+    return (uint16_t)(link | (T.links[link].arr_idx >= 0 ? NLINK_ARR : 0));
+}
+
 __device__ __forceinline__ int tls_state(const KTab &T, const Lds &L, const KParams &P, int tls, int pos) {
     if (tls == 0xFF) return TLS_G;
     const uint8_t *tab = P.fixed_program ? T.fix8 : T.tls8;
@@ -488,13 +497,13 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor[eo + s];
                 L.rq[s] = (uint16_t)rq;
                 L.vt[s] = T.trip_vtype[tr];
-                int nl = -1;
+                uint16_t nl = NLINK_NONE;
                 if (ln != LANE_PENDING) {
                     const LaneRec LR0 = T.lanes[ln];
-                    nl = choose_link(T, LR0, rq);
+                    nl = cache_link(T, LR0, rq);
                     L.node[s].nxt = list_push(hc, LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0)), s, sp > HALT_SPEED);
                 } else npend += 1;
-                L.nlink[s] = (uint16_t)nl;
+                L.nlink[s] = nl;
             }
         }
         if (npend) atomicAdd(&L.sc[SC_NPEND], npend);
@@ -536,7 +545,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     const int k_ = nt_ + base_ + rank_;                                                            \
                     const int v_ = T.trip_vtype[k_];                                                               \
                     L.node[s_].trip = (uint16_t)k_; L.lane[s_] = LANE_PENDING;                                          \
-                    L.node[s_].pos = 0.0f; L.speed[s_] = 0.0f; L.swait[s_] = 0; L.nlink[s_] = 0xFFFF; L.tloss[s_] = 0.0f; \
+                    L.node[s_].pos = 0.0f; L.speed[s_] = 0.0f; L.swait[s_] = 0; L.nlink[s_] = NLINK_NONE; L.tloss[s_] = 0.0f; \
                     L.vt[s_] = (uint8_t)v_; L.rq[s_] = (uint16_t)T.routes[T.trip_route[k_]].start;                 \
                     G.sf[eo + s_] = speed_factor(P, genv, k_, T.vtype_params + v_ * VT_COLS);                      \
                     G.rwait[eo + s_] = 0; G.owner[eo + s_] = OWNER_NONE; G.depart[eo + s_] = 0; G.accel[eo + s_] = 0.0f; \
@@ -580,13 +589,12 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         for (int s = tid; s < hw; s += B) {
             const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
-            const int link = L.nlink[s];
-            if (link == 0xFFFF) continue;
+            const int nlk = L.nlink[s];
+            if (!(nlk & NLINK_ARR)) continue;       // nobody yields to my next link (or I have none)
             const float v = L.speed[s];
             if (v <= HALT_SPEED) continue;
-            const LinkRec K = T.links[link];
+            const LinkRec K = T.links[nlk & 0x7FFF];
             const int ai = K.arr_idx;
-            if (ai < 0) continue;
             const int st = tls_state(T, L, P, K.tls, K.tls_pos);
             if (st == TLS_R) continue;
             const float dist = T.lanes[lane].len - L.node[s].pos;
@@ -618,7 +626,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 L.dep[RR.depart_arr] = ARR_NONE;
                 if (!ins) continue;
                 L.lane[s] = (uint16_t)dl; L.node[s].pos = mypos; L.speed[s] = 0.0f;
-                L.nlink[s] = (uint16_t)choose_link(T, LRd, RR.start);
+                L.nlink[s] = cache_link(T, LRd, RR.start);
                 G.depart[eo + s] = (uint16_t)t;
                 L.node[s].nxt = list_push(hc, LRd.cell0 + cell_of(mypos, lane_cells(LRd)), s, false);
                 atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
@@ -638,7 +646,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             const float v = L.speed[s], x = L.node[s].pos;
             const float sf = G.sf[eo + s];
             LaneRec LR = T.lanes[lane];
-            int link = (int)L.nlink[s];
+            int link = (int)(L.nlink[s] & 0x7FFF);
             float vfree = v + a;
             const float vl = LR.vmax * sf;
             if (vl < vfree) vfree = vl;
@@ -655,7 +663,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             const float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
             float seen = LR.len - x;
             int rq = L.rq[s];
-            if (link == 0xFFFF) link = -1;
+            if (link == NLINK_NONE) link = -1;
             for (int hop = 0; hop < MAX_HOPS && !found && seen < look; ++hop) {
                 const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
                 if (hop > 0) link = choose_link(T, LR, rq);
@@ -721,6 +729,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         __syncthreads();
         PROF_MARK(4)
         heads_clear(L.head, T.n_cells, tid, B);     // nobody reads the lists between plan and move
+        for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;     // ... nor this tick's approach registrations
         __syncthreads();
         PROF_MARK(5)
         // ---- D: move; drop this tick's approach registrations; build the lists of the moved state
@@ -730,11 +739,10 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 int lane = L.lane[s];
                 if (lane == LANE_NONE) continue;
                 if (lane == LANE_PENDING) { top = s + 1; continue; }
-                int link = (int)L.nlink[s];
-                if (link == 0xFFFF) link = -1;
+                int link = (int)(L.nlink[s] & 0x7FFF);
+                if (link == NLINK_NONE) link = -1;
                 LaneRec LR = T.lanes[lane];
                 const float sfv = G.sf[eo + s];
-                if (link >= 0) { const int ai = T.links[link].arr_idx; if (ai >= 0) L.arr[ai] = ARR_NONE; }
                 const float vn = L.vnx[s];
                 const float vref = LR.vmax * sfv;
                 if (tick == P.n_ticks - 1) G.accel[eo + s] = vn - L.speed[s];
@@ -770,7 +778,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     L.node[s].pos = x;
                     if (moved) {
                         L.lane[s] = (uint16_t)lane; L.rq[s] = (uint16_t)rq;
-                        L.nlink[s] = (uint16_t)choose_link(T, LR, rq);
+                        L.nlink[s] = cache_link(T, LR, rq);
                     }
                     active += 1;
                     top = s + 1;
@@ -863,7 +871,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 const int target = __float_as_int(L.vnx[s]);
                 if (L.lane[s] < LANE_PENDING && target >= 0) {
                     L.lane[s] = (uint16_t)target;
-                    L.nlink[s] = (uint16_t)choose_link(T, T.lanes[target], L.rq[s]);
+                    L.nlink[s] = cache_link(T, T.lanes[target], L.rq[s]);
                 }
             }
             __syncthreads();

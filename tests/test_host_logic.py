@@ -7,8 +7,7 @@ import pytest
 
 from conftest import HOT_CASES, load_golden
 from resco_amd import rewards, states
-from resco_amd.agents.maxpressure import MAXPRESSURE
-from resco_amd.agents.maxwave import MAXWAVE
+from resco_amd.agents.static_agents import MAXPRESSURE, MAXWAVE, STOCHASTIC
 from resco_amd.config.map_config import map_configs
 from resco_amd.config.signal_config import signal_configs
 
@@ -63,6 +62,13 @@ def test_static_agents_match_reference(tag):
         a2 = mw.act(states.wave(sigs))
         assert [int(a1[s]) for s in ids] == g['act_maxpressure'][k].tolist()
         assert [int(a2[s]) for s in ids] == g['act_maxwave'][k].tolist()
+
+
+def test_stochastic_agent_range():
+    ag = STOCHASTIC({'seed': 1}, {'a': [(13,), 3], 'b': [(13,), 2]}, 'cologne8', 0)
+    for _ in range(50):
+        act = ag.act({'a': None, 'b': None})
+        assert 0 <= act['a'] < 3 and 0 <= act['b'] < 2
 
 
 def test_config_surface():
