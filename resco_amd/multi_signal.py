@@ -107,8 +107,8 @@ class MultiSignal(_EnvBase):
             self.obs_shape[ts] = shape
             self.ts_order.append(ts)
             self.observation_space.append(_Box(low=-np.inf, high=np.inf, shape=shape))
-            if ts == 'top_mgr' or ts == 'bot_mgr':
-                continue
+            if ts not in self.phases:       # FMA2C manager keys are not traffic signals (the reference tests only
+                continue                    # 'top_mgr' / 'bot_mgr' and raises KeyError on ingolstadt21's managers)
             self.action_space.append(_Discrete(len(self.phases[ts])))
         self.n_agents = self.ts_starter
         self.run = 0

@@ -49,6 +49,21 @@ def run_case(map_name, steps, max_distance):
     ref_harness.install_stubs(factory)
     ref = ref_harness.import_reference()
     states, rewards = ref['states'], ref['rewards']
+    # FMA2C family: the reference's driver (main.py:48-72) replaces mdp_configs[agent] by the map's entry and
+    # adds the derived 'supervisors' map before anything is evaluated
+    import copy
+    from resco_benchmark.config import mdp_config as ref_mdp
+    if not hasattr(ref_mdp, '_pristine'):
+        ref_mdp._pristine = copy.deepcopy(ref_mdp.mdp_configs)
+    fma = []
+    for agent in ('FMA2C', 'FMA2CFull'):
+        per_map = ref_mdp._pristine[agent].get(map_name)
+        if per_map is None:
+            continue
+        cfg = copy.deepcopy(per_map)
+        cfg['supervisors'] = {w: m for m, ws in cfg['management'].items() for w in ws}
+        ref_mdp.mdp_configs[agent] = cfg
+        fma.append(agent)
     tmp = tempfile.mkdtemp() + os.sep
     env = ref['MultiSignal']('golden', map_name, 'x.sumocfg', states.mplight, rewards.wait, step_length=mc['step_length'],
                              yellow_length=mc['yellow_length'], end_time=mc['end_time'], max_distance=max_distance,
@@ -62,6 +77,8 @@ def run_case(map_name, steps, max_distance):
 
     rec = {k: [] for k in STATE_FNS + REWARD_FNS + ['agg', 'phase', 'act_maxpressure', 'act_maxwave', 'time', 'done',
                                                     'queue_sum', 'queue_max']}
+
+    fma_keys, fma_shapes = {}, {}
 
     def snapshot():
         for fn in STATE_FNS:
@@ -84,6 +101,15 @@ def run_case(map_name, steps, max_distance):
         rec['act_maxpressure'].append(np.asarray([int(a1[ts]) for ts in ids]))
         rec['act_maxwave'].append(np.asarray([int(a2[ts]) for ts in ids]))
         rec['time'].append(env.sumo.simulation.getTime())
+        for agent in fma:
+            fn = 'fma2c' if agent == 'FMA2C' else 'fma2c_full'
+            so = getattr(states, fn)(env.signals)
+            ro = getattr(rewards, fn)(env.signals)
+            fma_keys[fn] = list(so.keys())
+            assert list(ro.keys()) == list(so.keys())
+            rec.setdefault('state_' + fn, []).append(np.concatenate([np.asarray(so[k], dtype=np.float64).reshape(-1) for k in so]))
+            rec.setdefault('reward_' + fn, []).append(np.asarray([float(ro[k]) for k in ro]))
+            fma_shapes[fn] = {k: list(np.asarray(so[k]).shape) for k in so}
 
     obs0 = env.reset()
     assert list(obs0.keys()) == ids
@@ -116,7 +142,7 @@ def run_case(map_name, steps, max_distance):
     meta = dict(map=map_name, steps=steps, max_distance=max_distance, base_seed=BASE_SEED, seed=episode_seed(1),
                 all_ts_ids=ids, ts_order=list(env.ts_order), obs_shape={ts: list(env.obs_shape[ts]) for ts in ids},
                 n_green=n_green, connection_name=env.connection_name, metrics_csv=csv_text,
-                oracle_stats=orc_stats, signals={})
+                oracle_stats=orc_stats, signals={}, fma2c_keys=fma_keys, fma2c_shapes=fma_shapes)
     for ts in ids:
         sig = env.signals[ts]
         meta['signals'][ts] = dict(

@@ -160,6 +160,37 @@ def test_device_agents_match_reference(tag):
     sim.close()
 
 
+@pytest.mark.parametrize('tag', ['cologne8_d200', 'ingolstadt21_d200'])
+def test_fma2c_through_signal_views(tag):
+    """FMA2C state + reward (arrivals / departures sets, manager keys) through MultiSignal's Signal views vs the
+    reference's own functions (golden)."""
+    from resco_amd import rewards, states
+    from resco_amd.config.map_config import map_configs
+    from resco_amd.config.mdp_config import activate
+    from resco_amd.multi_signal import MultiSignal
+    meta, g = load_golden(tag)
+    mc = map_configs[meta['map']]
+    activate('FMA2C', meta['map'])
+    env = MultiSignal('golden', meta['map'], mc['net'], states.fma2c, rewards.fma2c, yellow_length=3,
+                      end_time=mc['end_time'], max_distance=meta['max_distance'], lights=mc['lights'],
+                      log_dir=tempfile.mkdtemp() + os.sep, seed=meta['base_seed'])
+    keys = meta['fma2c_keys']['fma2c']
+    assert list(env.obs_shape.keys()) == keys and env.ts_order == keys
+    assert len(env.action_space) == len(meta['all_ts_ids'])          # managers have no action space
+    obs = env.reset()
+
+    def flat(d):
+        return np.concatenate([np.asarray(d[k_], dtype=np.float64).reshape(-1) for k_ in keys])
+
+    np.testing.assert_allclose(flat(obs), g['state_fma2c'][0], rtol=1e-6, atol=1e-6)
+    for k in range(meta['steps']):
+        act = {t: int(a) for t, a in zip(meta['all_ts_ids'], g['actions'][k])}
+        obs, rew, done, info = env.step(act)
+        np.testing.assert_allclose(flat(obs), g['state_fma2c'][k + 1], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose([float(rew[k_]) for k_ in keys], g['reward_fma2c'][k + 1], rtol=1e-6, atol=1e-6)
+    env.close()
+
+
 def test_gymma_list_api_and_custom_state_fn():
     from resco_amd import rewards, states
     from resco_amd.multi_signal import MultiSignal

@@ -64,6 +64,27 @@ def test_static_agents_match_reference(tag):
         assert [int(a2[s]) for s in ids] == g['act_maxwave'][k].tolist()
 
 
+@pytest.mark.parametrize('tag', ['cologne1_d200', 'cologne8_d200', 'ingolstadt21_d200'])
+def test_fma2c_states_match_reference(tag):
+    """states.fma2c / fma2c_full (worker + manager observations) from the golden lane aggregates."""
+    from resco_amd.config.mdp_config import activate
+    meta, g = load_golden(tag)
+    for fn, agent in (('fma2c', 'FMA2C'), ('fma2c_full', 'FMA2CFull')):
+        if fn not in meta['fma2c_keys']:
+            continue
+        activate(agent, meta['map'])
+        for k in range(0, meta['steps'] + 1, 4):
+            sigs = signals_from_golden(meta, g['agg'][k], g['phase'][k])
+            for sid, sg in sigs.items():
+                sg.downstream = meta['signals'][sid]['downstream']
+                sg.inbounds_fr_direction = meta['signals'][sid]['inbounds_fr_direction']
+            out = getattr(states, fn)(sigs)
+            assert list(out.keys()) == meta['fma2c_keys'][fn]
+            assert {k_: list(v.shape) for k_, v in out.items()} == meta['fma2c_shapes'][fn]
+            flat = np.concatenate([np.asarray(out[k_], dtype=np.float64).reshape(-1) for k_ in out])
+            np.testing.assert_allclose(flat, g['state_' + fn][k], rtol=1e-9, atol=1e-9)
+
+
 def test_stochastic_agent_range():
     ag = STOCHASTIC({'seed': 1}, {'a': [(13,), 3], 'b': [(13,), 2]}, 'cologne8', 0)
     for _ in range(50):

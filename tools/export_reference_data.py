@@ -3,6 +3,7 @@
 
 Runs only where /root/reference exists (never on the GPU box).  Produces
   resco_amd/config/signal_configs.json   the per-map signal_configs dict (data; hot maps)
+  resco_amd/config/mdp_configs.json      the FMA2C normalisation constants / manager hierarchy (data)
   resco_amd/scenarios/<map>.npz          compiled flat tables (resco_amd.scenario.compile_scenario)
 
 No reference source text is copied: signal_config.py is *executed* as data and its dict is
@@ -42,6 +43,12 @@ def main():
         out[m] = enc
     with open(os.path.join(ROOT, 'resco_amd', 'config', 'signal_configs.json'), 'w') as f:
         json.dump(out, f, separators=(',', ':'))
+    md_mod = load_ref_module('resco_benchmark/config/mdp_config.py', '_ref_mdp_config')
+    mdp = {}
+    for agent, per_map in md_mod.mdp_configs.items():
+        mdp[agent] = {m: per_map[m] for m in MAPS if m in per_map}
+    with open(os.path.join(ROOT, 'resco_amd', 'config', 'mdp_configs.json'), 'w') as f:
+        json.dump(mdp, f, separators=(',', ':'))
     for m in MAPS:
         mc = mc_mod.map_configs[m]
         cfgpath = os.path.join(REF, 'resco_benchmark', mc['net'])
