@@ -469,6 +469,9 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
     vtype_ids = []
     dropped = 0
     for (tid, vt, depart, frm, to, explicit) in trips_xml:
+        if depart < begin:       # [SUMO-K] vehicles that departed before the simulation begin are not loaded
+            dropped += 1
+            continue
         if explicit is not None:
             path = [e for e in explicit if e in cost]
             key = tuple(path)

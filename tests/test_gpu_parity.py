@@ -51,6 +51,9 @@ def assert_env_equal(sim, orcs, step):
     ('cologne1', 2, 30, -1.0, 1, 1),         # FIXED programme (BASELINE config 1 plumbing)
     ('cologne8', 3, 40, -1.0, 1, 0),
     ('ingolstadt21', 2, 45, -1.0, 1, 0),
+    ('cologne3', 2, 40, -1.0, 1, 0),         # <vehicle><route> demand, explicit routes
+    ('ingolstadt1', 2, 40, -1.0, 1, 1),
+    ('ingolstadt7', 2, 40, -1.0, 1, 0),
 ])
 def test_gpu_equals_oracle_bit_exact(name, n_envs, steps, sigma, speed_dev, fixed):
     from oracle.pyoracle import OracleEnv

@@ -6,7 +6,8 @@ from conftest import load_scenario
 from oracle.pyoracle import OracleEnv
 
 
-@pytest.mark.parametrize('name,fixed,steps', [('cologne1', 0, 120), ('cologne8', 1, 90), ('ingolstadt21', 0, 40)])
+@pytest.mark.parametrize('name,fixed,steps', [('cologne1', 0, 120), ('cologne8', 1, 90), ('ingolstadt21', 0, 40),
+                                              ('cologne3', 0, 60), ('ingolstadt1', 1, 60), ('ingolstadt7', 0, 50)])
 def test_invariants(name, fixed, steps):
     sc = load_scenario(name)
     A = sc.arrays
