@@ -80,6 +80,7 @@ typedef struct rs_params {
     float sigma;              /* <0: the vType's Krauss sigma; 0: deterministic parity mode */
     int32_t speed_dev;        /* 1: per-vehicle speedFactor ~ clip(N(mean, dev), 0.2, 2) */
     int32_t fixed_program;    /* 1: run the net's own tlLogic and ignore actions */
+    int32_t trip_log;         /* 1: keep a per-trip record (RS_BUF_TRIP_LOG) for tripinfo output; costs N x n_trips x 16 B */
 } rs_params;
 
 typedef struct rs_sim *rs_handle;
@@ -138,6 +139,9 @@ enum rs_buffer {
     RS_BUF_STATS,          /* i64 [N][10] see rs_stats */
     RS_BUF_DRQ_NORM_F16,   /* f16 [N][S][Lmax][5] zero padded states.drq_norm (IDQN rollout layout) */
     RS_BUF_VEH_SF,         /* f32 [N][C]  per-vehicle speedFactor */
+    RS_BUF_VEH_WTOT,       /* u16 [N][C]  total halted seconds of the trip so far (maintained only with trip_log) */
+    RS_BUF_TRIP_LOG,       /* i32 [N][n_trips][4] depart tick, arrival tick (0: not arrived), timeLoss (1/1024 s), waiting (s);
+                              [N][0][4] when trip_log is off */
     RS_BUF_COUNT
 };
 enum rs_dtype { RS_F32 = 0, RS_I32 = 1, RS_U16 = 2, RS_U8 = 3, RS_F16 = 4, RS_I64 = 5 };

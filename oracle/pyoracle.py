@@ -55,6 +55,10 @@ def lib():
         L.orc_get_vehicles.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_trip_log.argtypes = [C.c_void_p]
+        L.orc_trip_log.restype = C.POINTER(C.c_int32)
+        L.orc_wtot.argtypes = [C.c_void_p]
+        L.orc_wtot.restype = C.POINTER(C.c_uint16)
         L.orc_stop_speed.restype = C.c_float
         L.orc_stop_speed.argtypes = [C.c_float] * 3
         L.orc_brake_gap.restype = C.c_float
@@ -73,10 +77,11 @@ class OracleEnv:
     """One environment instance of the CPU oracle."""
 
     def __init__(self, scenario, env_index=0, seed=0, max_distance=200.0, sigma=0.0, speed_dev=0,
-                 fixed_program=0, step_length=10, yellow_length=None):
+                 fixed_program=0, step_length=10, yellow_length=None, trip_log=0):
         self.sc = scenario
         self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
-        self._p = ParamsStruct(seed, max_distance, sigma, speed_dev, fixed_program)
+        self._p = ParamsStruct(seed, max_distance, sigma, speed_dev, fixed_program, trip_log)
+        self._trip_log = trip_log
         self._h = lib().orc_create(C.byref(self._st), C.byref(self._p), env_index)
         self.S, self.O = scenario.n_signals, scenario.n_obs
 
@@ -131,6 +136,13 @@ class OracleEnv:
                      'depart', 'owner'):
             out[name] = np.ctypeslib.as_array(getattr(v, name), shape=(cap,)).copy()
         return out
+
+    def trip_log(self):
+        assert self._trip_log
+        return np.ctypeslib.as_array(lib().orc_trip_log(self._h), shape=(self.sc.n_trips, 4)).copy()
+
+    def wtot(self):
+        return np.ctypeslib.as_array(lib().orc_wtot(self._h), shape=(self.sc.capacity,)).copy()
 
     def debug(self):
         r, b = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()

@@ -44,6 +44,8 @@ struct orc_env {
     uint8_t *owner;
     float *pos, *speed, *accel, *time_loss, *vnext;
     int32_t *lc_target;
+    uint16_t *wtot;
+    int32_t *trip_log;
     int32_t *dbg_reason, *dbg_block;   /* why the last plan() limited each vehicle (debug aid) */
     /* lane lists */
     int32_t *lane_head, *next_in_lane;
@@ -207,7 +209,8 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     int32_t C = sc->capacity, S = sc->n_signals, O = sc->n_obs;
     ALLOC(e->lane, C); ALLOC(e->cursor, C); ALLOC(e->sumo_wait, C); ALLOC(e->resco_wait, C); ALLOC(e->depart, C);
     ALLOC(e->owner, C); ALLOC(e->pos, C); ALLOC(e->speed, C); ALLOC(e->accel, C); ALLOC(e->time_loss, C);
-    ALLOC(e->vnext, C); ALLOC(e->lc_target, C); ALLOC(e->trip, C); ALLOC(e->dbg_reason, C); ALLOC(e->dbg_block, C);
+    ALLOC(e->vnext, C); ALLOC(e->lc_target, C); ALLOC(e->trip, C); ALLOC(e->dbg_reason, C); ALLOC(e->dbg_block, C); ALLOC(e->wtot, C);
+    if (p->trip_log) ALLOC(e->trip_log, (size_t)sc->n_trips * 4);
     ALLOC(e->lane_head, sc->n_lanes); ALLOC(e->next_in_lane, C); ALLOC(e->link_arr, sc->n_links);
     ALLOC(e->lane_ins, sc->n_lanes);
     ALLOC(e->phase, S); ALLOC(e->left, S); ALLOC(e->next_phase, S);
@@ -221,7 +224,7 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
 void orc_destroy(orc_env *e) {
     if (!e) return;
     free(e->lane); free(e->cursor); free(e->sumo_wait); free(e->resco_wait); free(e->depart); free(e->owner);
-    free(e->pos); free(e->speed); free(e->accel); free(e->time_loss); free(e->vnext); free(e->lc_target); free(e->trip); free(e->dbg_reason); free(e->dbg_block);
+    free(e->pos); free(e->speed); free(e->accel); free(e->time_loss); free(e->vnext); free(e->lc_target); free(e->trip); free(e->dbg_reason); free(e->dbg_block); free(e->wtot); free(e->trip_log);
     free(e->lane_head); free(e->next_in_lane); free(e->link_arr); free(e->lane_ins);
     free(e->phase); free(e->left); free(e->next_phase);
     free(e->lane_agg); free(e->drq_norm); free(e->wait); free(e->wait_norm);
@@ -250,6 +253,7 @@ void orc_reset(orc_env *e) {
         e->next_phase[s] = 0;       /* Signal.__init__: self.next_phase = 0 (traffic_signal.py:32) */
     }
     memset(e->stats, 0, sizeof(e->stats));
+    if (e->trip_log) memset(e->trip_log, 0, (size_t)sc->n_trips * 4 * sizeof(int32_t));
     build_lists(e);
 }
 int32_t orc_time(const orc_env *e) { return e->t; }
@@ -285,7 +289,7 @@ static void insertion(orc_env *e) {
         e->trip[s] = e->next_trip++;
         e->lane[s] = LANE_PENDING;
         e->pos[s] = 0; e->speed[s] = 0; e->accel[s] = 0; e->time_loss[s] = 0; e->cursor[s] = 0;
-        e->sumo_wait[s] = 0; e->resco_wait[s] = 0; e->owner[s] = OWNER_NONE; e->depart[s] = 0;
+        e->sumo_wait[s] = 0; e->resco_wait[s] = 0; e->owner[s] = OWNER_NONE; e->depart[s] = 0; e->wtot[s] = 0;
         if (s + 1 > e->hw) e->hw = s + 1;
     }
     /* lowest pending trip per departure lane is the candidate */
@@ -489,7 +493,7 @@ static void move(orc_env *e) {
         float vref = sc->lane_vmax[e->lane[s]] * sf;
         e->accel[s] = vn - e->speed[s];
         e->speed[s] = vn;
-        if (vn <= HALT_SPEED) { if (e->sumo_wait[s] < 65535) e->sumo_wait[s] += 1; e->stats[4] += 1; }
+        if (vn <= HALT_SPEED) { if (e->sumo_wait[s] < 65535) e->sumo_wait[s] += 1; e->stats[4] += 1; if (e->p.trip_log && e->wtot[s] < 65535) e->wtot[s] += 1; }
         else e->sumo_wait[s] = 0;
         if (vref > 0.0f && vn < vref) e->time_loss[s] += (vref - vn) / vref;
         float x = e->pos[s] + vn;
@@ -510,6 +514,10 @@ static void move(orc_env *e) {
             e->stats[1] += 1;
             e->stats[2] += e->t + 1 - e->depart[s];
             e->stats[5] += (int64_t)(e->time_loss[s] * 1024.0f + 0.5f);
+            if (e->trip_log) {
+                int32_t *r = e->trip_log + (size_t)k * 4;
+                r[0] = e->depart[s]; r[1] = e->t + 1; r[2] = (int32_t)(e->time_loss[s] * 1024.0f + 0.5f); r[3] = e->wtot[s];
+            }
         } else {
             e->lane[s] = (uint16_t)lane; e->cursor[s] = (uint16_t)cursor; e->pos[s] = x;
             active += 1;
@@ -718,6 +726,8 @@ void orc_get_vehicles(const orc_env *e, orc_vehicles *o) {
     o->accel = e->accel; o->time_loss = e->time_loss; o->cursor = e->cursor; o->sumo_wait = e->sumo_wait;
     o->resco_wait = e->resco_wait; o->depart = e->depart; o->owner = e->owner;
 }
+const int32_t *orc_trip_log(const orc_env *e) { return e->trip_log; }
+const uint16_t *orc_wtot(const orc_env *e) { return e->wtot; }
 void orc_debug(const orc_env *e, const int32_t **reason, const int32_t **block) { *reason = e->dbg_reason; *block = e->dbg_block; }
 void orc_stats(const orc_env *e, int64_t out[10]) {
     memcpy(out, e->stats, sizeof(e->stats));

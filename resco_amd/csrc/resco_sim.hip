@@ -81,8 +81,9 @@ struct Tab {
 
 struct State {      // env-major SoA in HBM
     float *pos, *speed, *accel, *tloss, *sf;
-    uint16_t *lane, *trip, *cursor, *swait, *rwait, *depart;
+    uint16_t *lane, *trip, *cursor, *swait, *rwait, *depart, *wtot;
     uint8_t *owner;
+    int32_t *trip_log;  // [N][n_trips][4] or NULL
     int32_t *env;       // [N][4] t, next_trip, hw, reserved
     int32_t *tls;       // [N][S][3] phase, left, next_phase
     long long *stats;   // [N][10]
@@ -210,6 +211,7 @@ struct KTab {
     const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_dur;
     const int16_t *lane_obs;
     const int32_t *obs_sig, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx, *pr_out_start, *pr_out_idx;
+    int32_t n_trips;
     int32_t n_lanes, n_cells, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
 };
 
@@ -548,7 +550,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     L.node[s_].pos = 0.0f; L.speed[s_] = 0.0f; L.swait[s_] = 0; L.nlink[s_] = NLINK_NONE; L.tloss[s_] = 0.0f; \
                     L.vt[s_] = (uint8_t)v_; L.rq[s_] = (uint16_t)T.routes[T.trip_route[k_]].start;                 \
                     G.sf[eo + s_] = speed_factor(P, genv, k_, T.vtype_params + v_ * VT_COLS);                      \
-                    G.rwait[eo + s_] = 0; G.owner[eo + s_] = OWNER_NONE; G.depart[eo + s_] = 0; G.accel[eo + s_] = 0.0f; \
+                    G.rwait[eo + s_] = 0; G.owner[eo + s_] = OWNER_NONE; G.depart[eo + s_] = 0; G.accel[eo + s_] = 0.0f; G.wtot[eo + s_] = 0; \
                     atomicMax(&L.sc[SC_HW], s_ + 1);                                                               \
                 }                                                                                                  \
                 base_ += __popcll(mask_);                                                                          \
@@ -747,8 +749,10 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 const float vref = LR.vmax * sfv;
                 if (tick == P.n_ticks - 1) G.accel[eo + s] = vn - L.speed[s];
                 L.speed[s] = vn;
-                if (vn <= HALT_SPEED) { int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1); halted += 1; }
-                else L.swait[s] = 0;
+                if (vn <= HALT_SPEED) {
+                    int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1); halted += 1;
+                    if (G.trip_log) { const int wt = G.wtot[eo + s]; if (wt < 65535) G.wtot[eo + s] = (uint16_t)(wt + 1); }
+                } else L.swait[s] = 0;
                 float tl = L.tloss[s];
                 if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; L.tloss[s] = tl; }
                 float x = L.node[s].pos + vn;
@@ -769,11 +773,16 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     moved = true;
                 }
                 if (arrived) {
+                    const int ktrip = L.node[s].trip;
                     L.lane[s] = LANE_NONE; L.node[s].trip = 0xFFFF;
                     G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0;
                     atomicAdd(&L.sc[SC_STATS + ST_ARRIVED], 1);
                     atomicAdd(&L.sc[SC_STATS + ST_DURATION], t + 1 - (int)G.depart[eo + s]);
                     atomicAdd(&L.sc[SC_STATS + ST_TLOSS], (int)(tl * 1024.0f + 0.5f));
+                    if (G.trip_log) {
+                        int32_t *r = G.trip_log + ((size_t)env * T.n_trips + ktrip) * 4;
+                        r[0] = (int)G.depart[eo + s]; r[1] = t + 1; r[2] = (int)(tl * 1024.0f + 0.5f); r[3] = (int)G.wtot[eo + s];
+                    }
                 } else {
                     L.node[s].pos = x;
                     if (moved) {
@@ -995,7 +1004,7 @@ extern "C" __global__ void rs_reset_kernel(Tab T, State G, KParams P) {
     const size_t eo = (size_t)env * C;
     for (int s = threadIdx.x; s < C; s += blockDim.x) {
         G.lane[eo + s] = LANE_NONE; G.trip[eo + s] = 0xFFFF; G.owner[eo + s] = OWNER_NONE;
-        G.rwait[eo + s] = 0; G.swait[eo + s] = 0; G.cursor[eo + s] = 0; G.depart[eo + s] = 0;
+        G.rwait[eo + s] = 0; G.swait[eo + s] = 0; G.cursor[eo + s] = 0; G.depart[eo + s] = 0; G.wtot[eo + s] = 0;
         G.pos[eo + s] = 0.0f; G.speed[eo + s] = 0.0f; G.accel[eo + s] = 0.0f; G.tloss[eo + s] = 0.0f; G.sf[eo + s] = 1.0f;
     }
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
@@ -1006,6 +1015,8 @@ extern "C" __global__ void rs_reset_kernel(Tab T, State G, KParams P) {
     }
     if (threadIdx.x < 4) G.env[env * 4 + threadIdx.x] = 0;
     if (threadIdx.x < ST_N) G.stats[(size_t)env * ST_N + threadIdx.x] = 0;
+    if (G.trip_log)
+        for (int i = threadIdx.x; i < T.n_trips * 4; i += blockDim.x) G.trip_log[(size_t)env * T.n_trips * 4 + i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ static agents
@@ -1263,6 +1274,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         K.fix_nphase = T.fix_nphase; K.fix_state_off = T.fix_state_off; K.fix_dur_off = T.fix_dur_off; K.fix_dur = T.fix_dur;
         K.obs_sig = T.obs_sig; K.sig_obs_start = T.sig_obs_start; K.mv_in_start = T.mv_in_start; K.mv_in_idx = T.mv_in_idx;
         K.mv_out_start = T.mv_out_start; K.mv_out_idx = T.mv_out_idx; K.pr_out_start = T.pr_out_start; K.pr_out_idx = T.pr_out_idx;
+        K.n_trips = sc->n_trips;
         K.n_lanes = sc->n_lanes; K.n_cells = n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
         K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = lmax;
         K.n_arr = n_foe_targets > 0 ? n_foe_targets : 1;
@@ -1280,7 +1292,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     if ((rc = dev_alloc(h, &G.pos, NC)) || (rc = dev_alloc(h, &G.speed, NC)) || (rc = dev_alloc(h, &G.accel, NC)) ||
         (rc = dev_alloc(h, &G.tloss, NC)) || (rc = dev_alloc(h, &G.sf, NC)) || (rc = dev_alloc(h, &G.lane, NC)) || (rc = dev_alloc(h, &G.trip, NC)) ||
         (rc = dev_alloc(h, &G.cursor, NC)) || (rc = dev_alloc(h, &G.swait, NC)) || (rc = dev_alloc(h, &G.rwait, NC)) ||
-        (rc = dev_alloc(h, &G.depart, NC)) || (rc = dev_alloc(h, &G.owner, NC)) || (rc = dev_alloc(h, &G.env, N * 4)) ||
+        (rc = dev_alloc(h, &G.depart, NC)) || (rc = dev_alloc(h, &G.wtot, NC)) || (rc = dev_alloc(h, &G.owner, NC)) || (rc = dev_alloc(h, &G.env, N * 4)) ||
         (rc = dev_alloc(h, &G.tls, N * S * 3)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
         (rc = dev_alloc(h, &O.lane_agg, N * NO * 5)) || (rc = dev_alloc(h, &O.drq_norm, N * NO * 5)) ||
         (rc = dev_alloc(h, &O.wait, N * S)) || (rc = dev_alloc(h, &O.wait_norm, N * S)) ||
@@ -1317,6 +1329,10 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_STATS, G.stats, RS_I64, 2, n, ST_N);
     set_buf(h, RS_BUF_DRQ_NORM_F16, O.drq_f16, RS_F16, 4, n, s, lmax, 5);
     set_buf(h, RS_BUF_VEH_SF, G.sf, RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_WTOT, G.wtot, RS_U16, 2, n, c);
+    G.trip_log = nullptr;
+    if (p->trip_log && (rc = dev_alloc(h, &G.trip_log, N * (size_t)sc->n_trips * 4))) return fail(rc);
+    set_buf(h, RS_BUF_TRIP_LOG, G.trip_log, RS_I32, 3, n, p->trip_log ? sc->n_trips : 0, 4);
 
     h->lds = lds_bytes_for(C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
@@ -1464,7 +1480,7 @@ static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, 
                                 RS_BUF_WAIT_NORM, RS_BUF_PRESSURE, RS_BUF_QUEUE_SUM, RS_BUF_QUEUE_MAX, RS_BUF_DRQ_NORM_F16,
                                 RS_BUF_ENV, RS_BUF_TLS, RS_BUF_VEH_POS, RS_BUF_VEH_SPEED, RS_BUF_VEH_ACCEL, RS_BUF_VEH_TLOSS,
                                 RS_BUF_VEH_LANE, RS_BUF_VEH_TRIP, RS_BUF_VEH_CURSOR, RS_BUF_VEH_SWAIT, RS_BUF_VEH_RWAIT,
-                                RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_VEH_SF, RS_BUF_STATS};
+                                RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_VEH_SF, RS_BUF_VEH_WTOT, RS_BUF_TRIP_LOG, RS_BUF_STATS};
 extern "C" int rs_snapshot(rs_handle h, void **snap) {
     if (!h || !snap) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1472,6 +1488,7 @@ extern "C" int rs_snapshot(rs_handle h, void **snap) {
     Snapshot *S = new Snapshot();
     for (int b : kSnapBufs) {
         void *d = nullptr;
+        if (h->bufs[b].bytes == 0) { S->ptrs.push_back(nullptr); continue; }
         if (hipMalloc(&d, h->bufs[b].bytes) != hipSuccess) { h->err = "rs_snapshot: hipMalloc failed"; rs_snapshot_free(h, S); return RS_ENOMEM; }
         S->ptrs.push_back(d);
         HIPCHK(h, hipMemcpy(d, h->bufs[b].ptr, h->bufs[b].bytes, hipMemcpyDeviceToDevice));
@@ -1485,7 +1502,7 @@ extern "C" int rs_restore(rs_handle h, const void *snap) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const Snapshot *S = (const Snapshot *)snap;
     size_t i = 0;
-    for (int b : kSnapBufs) { HIPCHK(h, hipMemcpy(h->bufs[b].ptr, S->ptrs[i], h->bufs[b].bytes, hipMemcpyDeviceToDevice)); ++i; }
+    for (int b : kSnapBufs) { if (h->bufs[b].bytes) HIPCHK(h, hipMemcpy(h->bufs[b].ptr, S->ptrs[i], h->bufs[b].bytes, hipMemcpyDeviceToDevice)); ++i; }
     return RS_OK;
 }
 extern "C" void rs_snapshot_free(rs_handle h, void *snap) {

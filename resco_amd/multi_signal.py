@@ -64,7 +64,7 @@ class MultiSignal(_EnvBase):
     def __init__(self, run_name, map_name, net, state_fn, reward_fn, route=None, gui=False, end_time=3600,
                  step_length=10, yellow_length=4, step_ratio=1, max_distance=200, lights=(), log_dir='/',
                  libsumo=False, warmup=0, gymma=False, *, device=0, seed=None, sigma=-1.0, speed_dev=1,
-                 fixed_program=False, scenario=None, use_fast_path=True):
+                 fixed_program=False, scenario=None, use_fast_path=True, tripinfo=True):
         if step_ratio != 1:
             raise NotImplementedError('step_ratio != 1 (sub-second SUMO steps) is not supported')
         self.libsumo, self.gymma, self.gui = libsumo, gymma, gui
@@ -82,7 +82,8 @@ class MultiSignal(_EnvBase):
         self._base_seed = int.from_bytes(os.urandom(4), 'little') if seed is None else int(seed)
         self.sim = BatchedSim(sc, 1, device=device, seed=self._base_seed, max_distance=max_distance, sigma=sigma,
                               speed_dev=speed_dev, fixed_program=1 if fixed_program else 0,
-                              step_length=step_length, yellow_length=yellow_length)
+                              step_length=step_length, yellow_length=yellow_length, trip_log=1 if tripinfo else 0)
+        self.tripinfo = tripinfo
         self.view_env = 0
         self._version = 0
         self._cache = {}
@@ -170,6 +171,7 @@ class MultiSignal(_EnvBase):
     def reset(self):
         if self.run != 0:
             self.save_metrics()
+            self.save_tripinfo()
         self.metrics = []
         self.run += 1
         # the reference restarts SUMO with --random (multi_signal.py:127): a new seed per episode
@@ -224,6 +226,52 @@ class MultiSignal(_EnvBase):
         except OSError:
             pass
 
+    def tripinfo_records(self):
+        """Per-trip records of the running episode, finished trips first then the ones still in the network
+        (SUMO's --tripinfo-output with --tripinfo-output.write-unfinished, multi_signal.py:127-129)."""
+        if not self.tripinfo:
+            return []
+        sc, e = self.scenario, self.view_env
+        log = self.sim.read('trip_log')[e]
+        now = int(self.sim.read('env')[e, 0])
+        recs = []
+        sched = sc.trip_depart
+
+        def rec(k, depart_tick, arrival_tick, tloss, waiting, sf):
+            depart = depart_tick - 1            # inserted at the end of the previous simulation second
+            return {'id': sc.trip_ids[k], 'depart': float(sc.begin + depart), 'departDelay': float(depart - int(sched[k])),
+                    'arrival': float(sc.begin + arrival_tick) if arrival_tick > 0 else -1.0,
+                    'duration': float((arrival_tick if arrival_tick > 0 else now) - depart_tick),
+                    'waitingTime': float(waiting), 'timeLoss': float(tloss),
+                    'vType': sc.vtype_ids[int(sc.trip_vtype[k])], 'speedFactor': float(sf)}
+
+        done = np.nonzero(log[:, 1] > 0)[0]
+        for k in done[np.argsort(log[done, 1], kind='stable')]:
+            recs.append(rec(int(k), int(log[k, 0]), int(log[k, 1]), log[k, 2] / 1024.0, int(log[k, 3]), 1.0))
+        lane, trip = self.sim.read('veh_lane')[e], self.sim.read('veh_trip')[e]
+        dep, tl = self.sim.read('veh_depart')[e], self.sim.read('veh_tloss')[e]
+        wt, sf = self.sim.read('veh_wtot')[e], self.sim.read('veh_sf')[e]
+        for s_ in np.nonzero(lane < 0xFFFE)[0]:
+            recs.append(rec(int(trip[s_]), int(dep[s_]), 0, float(tl[s_]), int(wt[s_]), float(sf[s_])))
+        return recs
+
+    def save_tripinfo(self):
+        if not self.tripinfo:
+            return
+        path = os.path.join(self.log_dir, self.connection_name, 'tripinfo_' + str(self.run) + '.xml')
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, 'w') as f:
+                f.write('<?xml version="1.0" encoding="UTF-8"?>\n<tripinfos>\n')
+                for r in self.tripinfo_records():
+                    f.write('    <tripinfo id="%s" depart="%.2f" departDelay="%.2f" arrival="%.2f" duration="%.2f" '
+                            'waitingTime="%.2f" timeLoss="%.2f" vType="%s" speedFactor="%.2f"/>\n'
+                            % (r['id'], r['depart'], r['departDelay'], r['arrival'], r['duration'], r['waitingTime'],
+                               r['timeLoss'], r['vType'], r['speedFactor']))
+                f.write('</tripinfos>\n')
+        except OSError:
+            pass
+
     def trip_stats(self):
         """tripinfo-style episode aggregates of this environment (avg duration / timeLoss / departDelay)."""
         st = {k: int(v[self.view_env]) for k, v in self.sim.stats().items()}
@@ -238,6 +286,7 @@ class MultiSignal(_EnvBase):
 
     def close(self):
         self.save_metrics()
+        self.save_tripinfo()
         self.sim.close()
 
 

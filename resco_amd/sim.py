@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libresco_sim.so')
 BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure', 'queue_sum',
            'queue_max', 'actions', 'env', 'tls', 'veh_pos', 'veh_speed', 'veh_accel', 'veh_tloss', 'veh_lane',
            'veh_trip', 'veh_cursor', 'veh_swait', 'veh_rwait', 'veh_depart', 'veh_owner', 'stats', 'drq_norm_f16',
-           'veh_sf']
+           'veh_sf', 'veh_wtot', 'trip_log']
 BUF_ID = {n: i for i, n in enumerate(BUFFERS)}
 _NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64]
 _TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8']
@@ -80,14 +80,14 @@ class BatchedSim:
     """N lock-step environments of one scenario on one GPU (one rs_handle)."""
 
     def __init__(self, scenario, n_envs, device=0, seed=0, max_distance=200.0, sigma=-1.0, speed_dev=1,
-                 fixed_program=0, env_base=0, step_length=10, yellow_length=None, block_threads=0):
+                 fixed_program=0, env_base=0, step_length=10, yellow_length=None, block_threads=0, trip_log=0):
         self.sc = scenario
         self.n_envs = int(n_envs)
         self.device = int(device)
         self._lib = load_library()
         self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
         self._p = ParamsStruct(int(seed) & 0xFFFFFFFF, float(max_distance), float(sigma), int(speed_dev),
-                               int(fixed_program))
+                               int(fixed_program), int(trip_log))
         self._h = C.c_void_p()
         rc = self._lib.rs_create(C.byref(self._st), C.byref(self._p), self.n_envs, int(env_base), self.device,
                                  int(block_threads), C.byref(self._h))
@@ -168,6 +168,8 @@ class BatchedSim:
         """Synchronous host copy of a buffer as a numpy array."""
         ptr, shape, dt = self._meta[name]
         out = np.empty(shape, _NP_DTYPES[dt])
+        if out.nbytes == 0:
+            return out
         self._check(self._lib.rs_read_buffer(self._h, BUF_ID[name], out.ctypes.data, out.nbytes))
         return out
 

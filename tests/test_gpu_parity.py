@@ -194,6 +194,51 @@ def test_fma2c_through_signal_views(tag):
     env.close()
 
 
+def test_trip_log_and_tripinfo_output():
+    """per-trip records (f-4): HIP == oracle, and the tripinfo XML MultiSignal writes is what the reference's
+    utils/readXML.py reads (timeLoss + departDelay per trip, unfinished trips included)."""
+    import xml.etree.ElementTree as ET
+    from oracle.pyoracle import OracleEnv
+    from resco_amd import rewards, states
+    from resco_amd.multi_signal import MultiSignal
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('cologne1')
+    sim = BatchedSim(sc, 3, seed=8, trip_log=1)
+    orcs = [OracleEnv(sc, env_index=e, seed=8, sigma=-1.0, speed_dev=1, trip_log=1) for e in range(3)]
+    rng = np.random.default_rng(1)
+    for k in range(60):
+        a = rng.integers(0, 4, (3, 1)).astype(np.int32)
+        sim.step(a)
+        for e, o in enumerate(orcs):
+            o.step(a[e])
+    log = sim.read('trip_log')
+    wt = sim.read('veh_wtot')
+    for e, o in enumerate(orcs):
+        np.testing.assert_array_equal(log[e], o.trip_log())
+        v = o.vehicles()
+        act = v['lane'][:v['hw']] < 0xFFFE
+        np.testing.assert_array_equal(wt[e][:v['hw']][act], o.wtot()[:v['hw']][act])
+    assert (log[:, :, 1] > 0).sum() == sim.stats()['arrived'].sum()
+    sim.close()
+
+    tmp = tempfile.mkdtemp() + os.sep
+    env = MultiSignal('t', 'cologne1', None, states.mplight, rewards.wait, yellow_length=3, end_time=28800, log_dir=tmp, seed=2)
+    env.reset()
+    for k in range(80):
+        env.step({env.all_ts_ids[0]: k % 4})
+    ts = env.trip_stats()
+    env.reset()                                   # closes episode 1: writes metrics_1.csv and tripinfo_1.xml
+    root = ET.parse(os.path.join(tmp, env.connection_name, 'tripinfo_1.xml')).getroot()
+    trips = list(root)
+    assert len(trips) == ts['inserted'] and sum(1 for t in trips if float(t.get('arrival')) > 0) == ts['arrived']
+    fin = [t for t in trips if float(t.get('arrival')) > 0]
+    assert abs(sum(float(t.get('timeLoss')) for t in fin) - ts['sum_time_loss_q10'] / 1024.0) < 0.01 * len(fin) + 1
+    assert sum(float(t.get('duration')) for t in fin) == ts['sum_duration']
+    assert sum(float(t.get('departDelay')) for t in trips) == ts['sum_depart_delay']
+    assert all(float(t.get('depart')) >= 25200 for t in trips)
+    env.close()
+
+
 def test_gymma_list_api_and_custom_state_fn():
     from resco_amd import rewards, states
     from resco_amd.multi_signal import MultiSignal
