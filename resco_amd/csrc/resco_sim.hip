@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1341,8 +1342,19 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     }
     if (block_threads % 64 || block_threads > 1024 || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024]"; return fail(RS_EINVAL); }
     h->block = block_threads;
-    if (hipFuncSetAttribute((const void *)rs_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
-        h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
+    {
+        // the dynamic-LDS ceiling is an attribute of the kernel (per device), not of a launch: only ever raise it,
+        // or a handle created earlier for a larger scenario could no longer launch
+        static std::mutex mu;
+        static size_t max_lds[64] = {0};
+        std::lock_guard<std::mutex> lock(mu);
+        size_t &cur = max_lds[device_id & 63];
+        if (h->lds > cur) {
+            if (hipFuncSetAttribute((const void *)rs_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+                h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
+            }
+            cur = h->lds;
+        }
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(RS_EHIP); }
     *out = h;

@@ -347,6 +347,19 @@ def test_device_random_policy_matches_its_definition():
     sim.close()
 
 
+def test_handles_of_different_scenarios_coexist():
+    """the dynamic-LDS attribute of the step kernel is shared by all handles of a process"""
+    from resco_amd.sim import BatchedSim
+    big = BatchedSim(load_scenario('ingolstadt21'), 8, seed=1)
+    small = BatchedSim(load_scenario('cologne1'), 8, seed=1)
+    for k in range(5):
+        small.act_random(k); small.step(None)
+        big.act_random(k); big.step(None)
+    big.sync(); small.sync()
+    assert (big.read('env')[:, 0] == 50).all() and (small.read('env')[:, 0] == 50).all()
+    big.close(); small.close()
+
+
 def test_zero_copy_tensors_at_the_agent_boundary():
     import torch
     from resco_amd.multi_signal import VecMultiSignal
