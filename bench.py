@@ -90,11 +90,29 @@ def run_timed(sim, steps, warmup, barrier, sync, reduce_max):
     return elapsed, kernel_ms, launches, st0, st1
 
 
+def effective_cores():
+    """host cores this process may really use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(sc, seed, budget_s=15.0):
     """C oracle on the host cores: `cores` processes, each running whole 360-step episodes of one
     environment with the same random-policy hash the device uses."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     from oracle.pyoracle import build
     build()
     t0 = time.perf_counter()
@@ -108,9 +126,9 @@ def cpu_baseline(sc, seed, budget_s=15.0):
     wall = time.perf_counter() - t0
     total = sum(done)
     return dict(value=total / wall, unit='env-steps/s', cores=cores, kind='port',
-                sample='C oracle (oracle/resco_oracle.c, gcc -O2, scalar): %d processes x %d env-steps of '
-                       'ingolstadt21 from episode start, same hashed random policy, %.1f s wall'
-                       % (cores, per_worker, wall))
+                sample='C oracle (oracle/resco_oracle.c, gcc -O2, scalar): %d processes (affinity %d, cgroup quota applied) x %d '
+                       'env-steps of ingolstadt21 from episode start, same hashed random policy, %.1f s wall'
+                       % (cores, len(os.sched_getaffinity(0)), per_worker, wall))
 
 
 def _cpu_worker(job):
@@ -150,7 +168,7 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('RESCO_BENCH_FORCE_DIST') == '1':      # the env var exercises the RCCL path at N=1
         import torch.distributed as dist
         dist.init_process_group('nccl', rank=rank, world_size=world)      # RCCL: barrier + one MAX only
 
