@@ -47,9 +47,9 @@ def algorithmic_bytes_per_env_step(sc, mean_active):
 
 def pmc_traffic_bytes_per_launch():
     """HBM bytes per launch of rs_step_kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
-    this same workload, profiles/r01_v3_pmc_summary.json): 2 x FETCH_SIZE (the gfx950 half-count correction of
+    this same workload, profiles/r01_final_pmc_summary.json): 2 x FETCH_SIZE (the gfx950 half-count correction of
     MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both reported in KiB.  None when no summary is committed."""
-    path = os.path.join(ROOT, 'profiles', 'r01_v3_pmc_summary.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_final_pmc_summary.json')
     try:
         with open(path) as f:
             c = json.load(f)['counters']
@@ -218,7 +218,7 @@ def main():
                      'frac': achieved / HBM_PEAK_GBS,
                      'traffic': pmc_traffic_bytes_per_launch() if (args.map == 'ingolstadt21' and n_local == 4096) else None,
                      'traffic_note': 'bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload '
-                                     '(profiles/r01_v3_pmc_summary.json, steps 60..160 of the episode); algorithmic bytes per '
+                                     '(profiles/r01_final_pmc_summary.json, steps 60..160 of the episode); algorithmic bytes per '
                                      'launch = algorithmic_bytes_per_env_step x env_steps_per_launch',
                      'kernel': 'rs_step_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
                      'algorithmic_bytes_per_env_step': b_alg, 'env_steps_per_launch': n_local,

@@ -941,20 +941,34 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     }
     __syncthreads();
     PROF_MARK(9)
-    // per observed lane rows
-    for (int oi = tid; oi < NO; oi += B) {
+    // per observed lane rows, written as flat coalesced streams (element i of [n_obs][5] / [S][Lmax][5])
+    for (int i = tid; i < NO * 5; i += B) {
+        const int oi = i / 5, c = i - oi * 5;
         const int sg = T.obs_sig[oi];
-        const int o0 = T.sig_obs_start[sg];
-        const int ph = L.phase[sg];
         const float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
-        const float q = (float)L.agg_q[oi], ap = (float)L.agg_a[oi], w = (float)L.agg_w[oi];
-        float *la = O.lane_agg + ((size_t)env * NO + oi) * 5;
-        la[0] = q; la[1] = ap; la[2] = w; la[3] = (float)L.agg_m[oi]; la[4] = sp;
-        const float d0 = (oi - o0) == ph ? 1.0f : 0.0f, d1 = ap / 28.0f, d2 = w / 28.0f, d3 = q / 28.0f, d4 = sp / 20.0f / 28.0f;
-        float *dn = O.drq_norm + ((size_t)env * NO + oi) * 5;
-        dn[0] = d0; dn[1] = d1; dn[2] = d2; dn[3] = d3; dn[4] = d4;
-        __half *dh = O.drq_f16 + (((size_t)env * S + sg) * T.lmax + (oi - o0)) * 5;
-        dh[0] = __float2half(d0); dh[1] = __float2half(d1); dh[2] = __float2half(d2); dh[3] = __float2half(d3); dh[4] = __float2half(d4);
+        float raw, nrm;
+        if (c == 0) { raw = (float)L.agg_q[oi]; nrm = (oi - T.sig_obs_start[sg]) == L.phase[sg] ? 1.0f : 0.0f; }
+        else if (c == 1) { raw = (float)L.agg_a[oi]; nrm = raw / 28.0f; }
+        else if (c == 2) { raw = (float)L.agg_w[oi]; nrm = raw / 28.0f; }
+        else if (c == 3) { raw = (float)L.agg_m[oi]; nrm = (float)L.agg_q[oi] / 28.0f; }
+        else { raw = sp; nrm = sp / 20.0f / 28.0f; }
+        O.lane_agg[(size_t)env * NO * 5 + i] = raw;         // queue, approach, total_wait, max_wait, speed_sum
+        O.drq_norm[(size_t)env * NO * 5 + i] = nrm;         // one-hot(lane position == phase), approach, wait, queue, speed
+    }
+    for (int i = tid; i < S * T.lmax * 5; i += B) {
+        const int sg = i / (T.lmax * 5), r = i - sg * T.lmax * 5;
+        const int l = r / 5, c = r - l * 5;
+        const int o0 = T.sig_obs_start[sg];
+        float nrm = 0.0f;                                    // zero padding beyond the signal's lanes
+        if (l < T.sig_obs_start[sg + 1] - o0) {
+            const int oi = o0 + l;
+            if (c == 0) nrm = l == L.phase[sg] ? 1.0f : 0.0f;
+            else if (c == 1) nrm = (float)L.agg_a[oi] / 28.0f;
+            else if (c == 2) nrm = (float)L.agg_w[oi] / 28.0f;
+            else if (c == 3) nrm = (float)L.agg_q[oi] / 28.0f;
+            else nrm = (float)L.agg_s[oi] * (1.0f / 65536.0f) / 20.0f / 28.0f;
+        }
+        O.drq_f16[(size_t)env * S * T.lmax * 5 + i] = __float2half(nrm);
     }
     // states.mplight / states.wave: one thread per (signal, movement)
     for (int i = tid; i < S * 12; i += B) {

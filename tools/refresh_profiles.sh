@@ -14,7 +14,7 @@ python tools/idqn_rollout.py 1024 2>/dev/null | tail -1 > $OUT/idqn_rollout.json
 python tools/idqn_rollout.py 4096 2>/dev/null | tail -1 >> $OUT/idqn_rollout.jsonl
 python tools/policy_eval.py > $OUT/policy_eval.jsonl 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o final -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o final -- python $R/bench.py --steps 360 --warmup 0 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 cd $R && bash tools/pmc_passes.sh final/pmc 100 60 > $OUT/pmc_passes.log 2>&1
 cat $OUT/prof/final_kernel_stats.csv
