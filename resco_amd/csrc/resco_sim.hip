@@ -212,7 +212,7 @@ struct KTab {
     const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_dur;
     const int16_t *lane_obs;
     const int32_t *obs_sig, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx, *pr_out_start, *pr_out_idx;
-    int32_t n_trips;
+    int32_t n_trips, tls_maxl;
     int32_t n_lanes, n_cells, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
 };
 
@@ -231,7 +231,8 @@ struct Lds {
     int32_t *arr, *dep;         // link approach registers / departure-lane insertion candidates
     int32_t *agg_q, *agg_a, *agg_w, *agg_m;
     uint32_t *agg_s;
-    int32_t *phase, *left, *nextp, *tbase;
+    int32_t *phase, *left, *nextp;
+    uint8_t *tstate;            // current link states of every signal, [S][tls_maxl] (refreshed when a phase changes)
     int32_t *sc;        // scalars, see SC_*
 };
 #define SC_T 0
@@ -247,7 +248,7 @@ __host__ __device__ inline size_t lds_scratch_bytes(int C, int n_obs) {       //
     size_t a = (size_t)C * 4, b = align16((size_t)n_obs * 4) * 5;
     return a > b ? a : b;
 }
-__host__ __device__ inline size_t lds_bytes_for(int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
+__host__ __device__ inline size_t lds_bytes_for(int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
     o += align16((size_t)C * 8);                     // node {pos, trip, nxt}
     o += align16((size_t)C * 4) * 2;                 // speed tloss
@@ -258,11 +259,11 @@ __host__ __device__ inline size_t lds_bytes_for(int C, int n_cells, int n_arr, i
     o += align16((size_t)C);                         // vt
     o += align16((size_t)n_arr * 4);                 // approach registers
     o += align16((size_t)n_dep * 4);                 // insertion candidates
-    o += align16((size_t)S * 4) * 4;                 // tls
+    o += align16((size_t)S * 4) * 3 + align16((size_t)S * tls_maxl);   // tls phase/left/next + link states
     o += align16((size_t)(SC_STATS + ST_N) * 4);
     return o;
 }
-__device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt) {
+__device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
 #define CARVE(field, type, bytes) L.field = (type *)(base + o); o += align16(bytes);
     CARVE(node, Node, (size_t)C * 8) CARVE(speed, float, (size_t)C * 4) CARVE(tloss, float, (size_t)C * 4)
@@ -281,7 +282,7 @@ __device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_cells
     CARVE(vt, uint8_t, (size_t)C)
     CARVE(arr, int32_t, (size_t)n_arr * 4) CARVE(dep, int32_t, (size_t)n_dep * 4)
     CARVE(phase, int32_t, (size_t)S * 4) CARVE(left, int32_t, (size_t)S * 4) CARVE(nextp, int32_t, (size_t)S * 4)
-    CARVE(tbase, int32_t, (size_t)S * 4)
+    CARVE(tstate, uint8_t, (size_t)S * tls_maxl)
     CARVE(sc, int32_t, (size_t)(SC_STATS + ST_N) * 4)
 #undef CARVE
 }
@@ -348,8 +349,7 @@ __device__ __forceinline__ uint16_t cache_link(const KTab &T, const LaneRec &LR,
 
 __device__ __forceinline__ int tls_state(const KTab &T, const Lds &L, const KParams &P, int tls, int pos) {
     if (tls == 0xFF) return TLS_G;
-    const uint8_t *tab = P.fixed_program ? T.fix8 : T.tls8;
-    return tab[L.tbase[tls] + pos];
+    return L.tstate[tls * T.tls_maxl + pos];
 }
 
 __device__ __forceinline__ int lane_cells(const LaneRec &LR) { return (int)(LR.len * CELL_INV) + 1; }
@@ -445,11 +445,18 @@ __device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const u
     return false;
 }
 
+// copy the link states of signal s in phase ph into LDS (called by the thread that owns the signal)
+__device__ __forceinline__ void tls_refresh(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
+    const uint8_t *src = (P.fixed_program ? T.fix8 + T.fix_state_off[s] : T.tls8 + T.tls_state_off[s]) + ph * T.tls_nlinks[s];
+    const int n = T.tls_nlinks[s];
+    for (int i = 0; i < n; ++i) L.tstate[s * T.tls_maxl + i] = src[i];
+}
+
 __device__ __forceinline__ void set_phase(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
     if (ph < 0 || ph >= T.tls_nphase[s]) return;
     L.phase[s] = ph;
     L.left[s] = T.tls_dur[T.tls_dur_off[s] + ph];
-    L.tbase[s] = T.tls_state_off[s] + ph * T.tls_nlinks[s];
+    tls_refresh(T, L, P, s, ph);
 }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
@@ -464,7 +471,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     const int C = T.capacity, S = T.n_signals, NO = T.n_obs;
     const int genv = P.env_base + env;
     Lds L;
-    lds_carve(L, smem, C, T.n_cells, T.n_arr, T.n_dep, NO, S, T.n_vtypes);
+    lds_carve(L, smem, C, T.n_cells, T.n_arr, T.n_dep, NO, S, T.n_vtypes, T.tls_maxl);
     unsigned long long pt_ = 0;
 #define PROF_START() if (P.prof && tid == 0) pt_ = wall_clock64();
 #define PROF_MARK(i_) if (P.prof && tid == 0) { unsigned long long n_ = wall_clock64(); atomicAdd(&P.prof[i_], n_ - pt_); pt_ = n_; }
@@ -484,7 +491,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         L.phase[i] = ph;
         L.left[i] = G.tls[(env * S + i) * 3 + 1];
         L.nextp[i] = G.tls[(env * S + i) * 3 + 2];
-        L.tbase[i] = (P.fixed_program ? T.fix_state_off[i] : T.tls_state_off[i]) + ph * T.tls_nlinks[i];
+        tls_refresh(T, L, P, i, ph);
     }
     __syncthreads();
     {
@@ -525,7 +532,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             const int ph_ = (L.phase[s_] + 1) % Pn_;                                                               \
             left_ = dur_[ph_];                                                                                     \
             L.phase[s_] = ph_;                                                                                     \
-            L.tbase[s_] = (P.fixed_program ? T.fix_state_off[s_] : T.tls_state_off[s_]) + ph_ * T.tls_nlinks[s_];  \
+            tls_refresh(T, L, P, s_, ph_);                                                                          \
         }                                                                                                          \
         L.left[s_] = left_ - 1;                                                                                    \
     }
@@ -1166,6 +1173,8 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     T.lmax = lmax;
     if ((rc = dev_upload<int32_t>(h, &T.obs_sig, obs_sig.data(), obs_sig.size()))) return fail(rc);
     h->tls_ngreen.assign(sc->tls_ngreen, sc->tls_ngreen + sc->n_signals);
+    int tls_maxl = 1;
+    for (int s = 0; s < sc->n_signals; ++s) if (sc->tls_nlinks[s] > tls_maxl) tls_maxl = sc->tls_nlinks[s];
     // ---- packed 16-byte records for the step kernel
     {
         if (sc->n_route_steps >= 0xFFFF || sc->n_foes >= 0xFFFF || sc->n_links >= 0xFFFF || sc->n_edges >= 0xFFFF || sc->n_obs >= 0x7FFF) {
@@ -1289,7 +1298,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         K.fix_nphase = T.fix_nphase; K.fix_state_off = T.fix_state_off; K.fix_dur_off = T.fix_dur_off; K.fix_dur = T.fix_dur;
         K.obs_sig = T.obs_sig; K.sig_obs_start = T.sig_obs_start; K.mv_in_start = T.mv_in_start; K.mv_in_idx = T.mv_in_idx;
         K.mv_out_start = T.mv_out_start; K.mv_out_idx = T.mv_out_idx; K.pr_out_start = T.pr_out_start; K.pr_out_idx = T.pr_out_idx;
-        K.n_trips = sc->n_trips;
+        K.n_trips = sc->n_trips; K.tls_maxl = tls_maxl;
         K.n_lanes = sc->n_lanes; K.n_cells = n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
         K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = lmax;
         K.n_arr = n_foe_targets > 0 ? n_foe_targets : 1;
@@ -1349,7 +1358,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     if (p->trip_log && (rc = dev_alloc(h, &G.trip_log, N * (size_t)sc->n_trips * 4))) return fail(rc);
     set_buf(h, RS_BUF_TRIP_LOG, G.trip_log, RS_I32, 3, n, p->trip_log ? sc->n_trips : 0, 4);
 
-    h->lds = lds_bytes_for(C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes);
+    h->lds = lds_bytes_for(C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, tls_maxl);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
     if (block_threads <= 0) {
         block_threads = C >= 512 ? 512 : (C >= 256 ? 256 : (C >= 128 ? 128 : 64));
