@@ -80,20 +80,50 @@ struct Tab {
     int32_t horizon, capacity, step_length, yellow_length, lmax, n_arr;
 };
 
-struct State {      // env-major SoA in HBM
-    float *pos, *speed, *accel, *tloss, *sf;
-    uint16_t *lane, *trip, *cursor, *swait, *rwait, *depart, *wtot;
-    uint8_t *owner;
+// Kernel arguments are kept SMALL on purpose: every pointer passed by value costs two SGPRs for the whole
+// kernel, and beyond ~100 SGPRs the compiler spills them into VGPR lanes (v_writelane / v_readlane around every
+// table access).  The per-slot state and the outputs are therefore ONE allocation each, with field addresses
+// computed from (base, N*C) where they are used.
+struct State {      // env-major SoA in HBM: field[env][slot]
+    char *base;
+    size_t nc;          // N * C
     int32_t *trip_log;  // [N][n_trips][4] or NULL
     int32_t *env;       // [N][4] t, next_trip, hw, reserved
     int32_t *tls;       // [N][S][3] phase, left, next_phase
     long long *stats;   // [N][10]
+    __host__ __device__ float *pos() const { return (float *)base; }
+    __host__ __device__ float *speed() const { return (float *)(base + 4 * nc); }
+    __host__ __device__ float *accel() const { return (float *)(base + 8 * nc); }
+    __host__ __device__ float *tloss() const { return (float *)(base + 12 * nc); }
+    __host__ __device__ float *sf() const { return (float *)(base + 16 * nc); }
+    __host__ __device__ uint16_t *lane() const { return (uint16_t *)(base + 20 * nc); }
+    __host__ __device__ uint16_t *trip() const { return (uint16_t *)(base + 22 * nc); }
+    __host__ __device__ uint16_t *cursor() const { return (uint16_t *)(base + 24 * nc); }
+    __host__ __device__ uint16_t *swait() const { return (uint16_t *)(base + 26 * nc); }
+    __host__ __device__ uint16_t *rwait() const { return (uint16_t *)(base + 28 * nc); }
+    __host__ __device__ uint16_t *depart() const { return (uint16_t *)(base + 30 * nc); }
+    __host__ __device__ uint16_t *wtot() const { return (uint16_t *)(base + 32 * nc); }
+    __host__ __device__ uint8_t *owner() const { return (uint8_t *)(base + 34 * nc); }
+    static size_t bytes(size_t nc_) { return 35 * nc_; }
 };
 
-struct Out {
-    float *lane_agg, *drq_norm, *wait, *wait_norm;
-    int32_t *phase, *mplight, *wave, *pressure, *queue_sum, *queue_max;
-    __half *drq_f16;
+struct Out {        // one allocation; n = N, o = n_obs, s = n_signals, lm = lanes of the largest signal
+    char *base;
+    int32_t n, o, s, lm;
+    __host__ __device__ size_t a5() const { return (size_t)n * o * 5 * 4; }      // one [N][n_obs][5] f32 block
+    __host__ __device__ size_t ns() const { return (size_t)n * s * 4; }          // one [N][S] 4-byte block
+    __host__ __device__ float *lane_agg() const { return (float *)base; }
+    __host__ __device__ float *drq_norm() const { return (float *)(base + a5()); }
+    __host__ __device__ float *wait() const { return (float *)(base + 2 * a5()); }
+    __host__ __device__ float *wait_norm() const { return (float *)(base + 2 * a5() + ns()); }
+    __host__ __device__ int32_t *phase() const { return (int32_t *)(base + 2 * a5() + 2 * ns()); }
+    __host__ __device__ int32_t *pressure() const { return (int32_t *)(base + 2 * a5() + 3 * ns()); }
+    __host__ __device__ int32_t *queue_sum() const { return (int32_t *)(base + 2 * a5() + 4 * ns()); }
+    __host__ __device__ int32_t *queue_max() const { return (int32_t *)(base + 2 * a5() + 5 * ns()); }
+    __host__ __device__ int32_t *mplight() const { return (int32_t *)(base + 2 * a5() + 6 * ns()); }
+    __host__ __device__ int32_t *wave() const { return (int32_t *)(base + 2 * a5() + 19 * ns()); }
+    __host__ __device__ __half *drq_f16() const { return (__half *)(base + 2 * a5() + 31 * ns()); }
+    __host__ __device__ size_t bytes() const { return 2 * a5() + 31 * ns() + (size_t)n * s * lm * 5 * 2 + 64; }
 };
 
 struct KParams {
@@ -196,6 +226,17 @@ struct __attribute__((aligned(8))) RouteRec {
 #define KF_CONT 2u
 #define KF_VIA1 4u
 
+// tables used rarely (per signal, per tick by one wave, at load / observe): reached through one pointer
+struct KCold {
+    const int32_t *trip_depart, *trips_cum;
+    const float *vtype_params;
+    const uint8_t *tls8, *fix8;
+    const int32_t *tls_nphase, *tls_ngreen, *tls_nlinks, *tls_state_off, *tls_dur_off, *tls_yel_off, *tls_dur, *tls_yellow;
+    const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_dur;
+    const int16_t *lane_obs;
+    const int32_t *obs_sig, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx, *pr_out_start, *pr_out_idx;
+};
+// tables of the per-vehicle, per-tick path: by value (SGPRs)
 struct KTab {
     const LaneRec *lanes;
     const LinkRec *links;
@@ -205,13 +246,7 @@ struct KTab {
     const RouteRec *routes;
     const uint16_t *trip_route;
     const uint8_t *trip_vtype;
-    const int32_t *trip_depart, *trips_cum;
-    const float *vtype_params;
-    const uint8_t *tls8, *fix8;
-    const int32_t *tls_nphase, *tls_ngreen, *tls_nlinks, *tls_state_off, *tls_dur_off, *tls_yel_off, *tls_dur, *tls_yellow;
-    const int32_t *fix_nphase, *fix_state_off, *fix_dur_off, *fix_dur;
-    const int16_t *lane_obs;
-    const int32_t *obs_sig, *sig_obs_start, *mv_in_start, *mv_in_idx, *mv_out_start, *mv_out_idx, *pr_out_start, *pr_out_idx;
+    const KCold *cold;
     int32_t n_trips, tls_maxl;
     int32_t n_lanes, n_cells, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
 };
@@ -447,15 +482,15 @@ __device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const u
 
 // copy the link states of signal s in phase ph into LDS (called by the thread that owns the signal)
 __device__ __forceinline__ void tls_refresh(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
-    const uint8_t *src = (P.fixed_program ? T.fix8 + T.fix_state_off[s] : T.tls8 + T.tls_state_off[s]) + ph * T.tls_nlinks[s];
-    const int n = T.tls_nlinks[s];
+    const uint8_t *src = (P.fixed_program ? T.cold->fix8 + T.cold->fix_state_off[s] : T.cold->tls8 + T.cold->tls_state_off[s]) + ph * T.cold->tls_nlinks[s];
+    const int n = T.cold->tls_nlinks[s];
     for (int i = 0; i < n; ++i) L.tstate[s * T.tls_maxl + i] = src[i];
 }
 
 __device__ __forceinline__ void set_phase(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
-    if (ph < 0 || ph >= T.tls_nphase[s]) return;
+    if (ph < 0 || ph >= T.cold->tls_nphase[s]) return;
     L.phase[s] = ph;
-    L.left[s] = T.tls_dur[T.tls_dur_off[s] + ph];
+    L.left[s] = T.cold->tls_dur[T.cold->tls_dur_off[s] + ph];
     tls_refresh(T, L, P, s, ph);
 }
 
@@ -482,7 +517,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
 
     // ---- load the environment slab (once per env-step)
     if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 3 ? G.env[env * 4 + tid] : 0;
-    for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.vtype_params[i];
+    for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold->vtype_params[i];
     heads_clear(L.head, T.n_cells, tid, B);
     for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
     for (int i = tid; i < T.n_dep; i += B) L.dep[i] = ARR_NONE;
@@ -499,12 +534,12 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         int npend = 0;
         for (int s = tid; s < C; s += B) {
             uint16_t ln = LANE_NONE, tr = 0xFFFF;
-            if (s < hw0) { ln = G.lane[eo + s]; tr = G.trip[eo + s]; }
+            if (s < hw0) { ln = G.lane()[eo + s]; tr = G.trip()[eo + s]; }
             L.lane[s] = ln; L.node[s].trip = tr;
             if (ln != LANE_NONE) {
-                const float sp = G.speed[eo + s];
-                L.node[s].pos = G.pos[eo + s]; L.speed[s] = sp; L.swait[s] = G.swait[eo + s]; L.tloss[s] = G.tloss[eo + s];
-                const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor[eo + s];
+                const float sp = G.speed()[eo + s];
+                L.node[s].pos = G.pos()[eo + s]; L.speed[s] = sp; L.swait[s] = G.swait()[eo + s]; L.tloss[s] = G.tloss()[eo + s];
+                const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor()[eo + s];
                 L.rq[s] = (uint16_t)rq;
                 L.vt[s] = T.trip_vtype[tr];
                 uint16_t nl = NLINK_NONE;
@@ -527,8 +562,8 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         if (P.do_fsm && !P.fixed_program && (tick_) == T.yellow_length) set_phase(T, L, P, s_, L.nextp[s_]);       \
         int left_ = L.left[s_];                                                                                    \
         if (left_ == 0) {                                                                                          \
-            const int32_t *dur_ = P.fixed_program ? T.fix_dur + T.fix_dur_off[s_] : T.tls_dur + T.tls_dur_off[s_]; \
-            const int Pn_ = P.fixed_program ? T.fix_nphase[s_] : T.tls_nphase[s_];                                 \
+            const int32_t *dur_ = P.fixed_program ? T.cold->fix_dur + T.cold->fix_dur_off[s_] : T.cold->tls_dur + T.cold->tls_dur_off[s_]; \
+            const int Pn_ = P.fixed_program ? T.cold->fix_nphase[s_] : T.cold->tls_nphase[s_];                                 \
             const int ph_ = (L.phase[s_] + 1) % Pn_;                                                               \
             left_ = dur_[ph_];                                                                                     \
             L.phase[s_] = ph_;                                                                                     \
@@ -541,7 +576,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
 #define ALLOCATE_SLOTS(t_)                                                                                         \
     if (tid < 64) {                                                                                                \
         const int hz_ = (t_) - 1 <= T.horizon ? (t_) - 1 : T.horizon;                                              \
-        const int due_ = (t_) >= 1 ? T.trips_cum[hz_] : 0;                                                         \
+        const int due_ = (t_) >= 1 ? T.cold->trips_cum[hz_] : 0;                                                         \
         const int nt_ = L.sc[SC_NEXT];                                                                             \
         const int m_ = due_ - nt_;                                                                                 \
         if (m_ > 0) {                                                                                              \
@@ -557,8 +592,8 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     L.node[s_].trip = (uint16_t)k_; L.lane[s_] = LANE_PENDING;                                          \
                     L.node[s_].pos = 0.0f; L.speed[s_] = 0.0f; L.swait[s_] = 0; L.nlink[s_] = NLINK_NONE; L.tloss[s_] = 0.0f; \
                     L.vt[s_] = (uint8_t)v_; L.rq[s_] = (uint16_t)T.routes[T.trip_route[k_]].start;                 \
-                    G.sf[eo + s_] = speed_factor(P, genv, k_, T.vtype_params + v_ * VT_COLS);                      \
-                    G.rwait[eo + s_] = 0; G.owner[eo + s_] = OWNER_NONE; G.depart[eo + s_] = 0; G.accel[eo + s_] = 0.0f; G.wtot[eo + s_] = 0; \
+                    G.sf()[eo + s_] = speed_factor(P, genv, k_, T.cold->vtype_params + v_ * VT_COLS);                      \
+                    G.rwait()[eo + s_] = 0; G.owner()[eo + s_] = OWNER_NONE; G.depart()[eo + s_] = 0; G.accel()[eo + s_] = 0.0f; G.wtot()[eo + s_] = 0; \
                     atomicMax(&L.sc[SC_HW], s_ + 1);                                                               \
                 }                                                                                                  \
                 base_ += __popcll(mask_);                                                                          \
@@ -570,11 +605,11 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     // ---- Signal.prep_phase for every signal (traffic_signal.py:176-184), then the preparation of tick 0
     if (P.do_fsm && !P.fixed_program) {
         for (int s = tid; s < S; s += B) {
-            int a = actions[env * S + s], cur = L.phase[s], Gn = T.tls_ngreen[s];
-            if (a < 0 || a >= T.tls_nphase[s]) { L.nextp[s] = cur; continue; }
+            int a = actions[env * S + s], cur = L.phase[s], Gn = T.cold->tls_ngreen[s];
+            if (a < 0 || a >= T.cold->tls_nphase[s]) { L.nextp[s] = cur; continue; }
             L.nextp[s] = a;
             if (cur != a && cur < Gn && a < Gn) {
-                int y = T.tls_yellow[T.tls_yel_off[s] + cur * Gn + a];
+                int y = T.cold->tls_yellow[T.cold->tls_yel_off[s] + cur * Gn + a];
                 if (y >= 0) set_phase(T, L, P, s, y);
             }
         }
@@ -637,10 +672,10 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 if (!ins) continue;
                 L.lane[s] = (uint16_t)dl; L.node[s].pos = mypos; L.speed[s] = 0.0f;
                 L.nlink[s] = cache_link(T, LRd, RR.start);
-                G.depart[eo + s] = (uint16_t)t;
+                G.depart()[eo + s] = (uint16_t)t;
                 L.node[s].nxt = list_push(hc, LRd.cell0 + cell_of(mypos, lane_cells(LRd)), s, false);
                 atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
-                atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.trip_depart[k]);
+                atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.cold->trip_depart[k]);
                 atomicSub(&L.sc[SC_NPEND], 1);
             }
             __syncthreads();
@@ -654,7 +689,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             const float *vt = L.vtp + L.vt[s] * VT_COLS;
             const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
             const float v = L.speed[s], x = L.node[s].pos;
-            const float sf = G.sf[eo + s];
+            const float sf = G.sf()[eo + s];
             LaneRec LR = T.lanes[lane];
             int link = (int)(L.nlink[s] & 0x7FFF);
             float vfree = v + a;
@@ -752,14 +787,14 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 int link = (int)(L.nlink[s] & 0x7FFF);
                 if (link == NLINK_NONE) link = -1;
                 LaneRec LR = T.lanes[lane];
-                const float sfv = G.sf[eo + s];
+                const float sfv = G.sf()[eo + s];
                 const float vn = L.vnx[s];
                 const float vref = LR.vmax * sfv;
-                if (tick == P.n_ticks - 1) G.accel[eo + s] = vn - L.speed[s];
+                if (tick == P.n_ticks - 1) G.accel()[eo + s] = vn - L.speed[s];
                 L.speed[s] = vn;
                 if (vn <= HALT_SPEED) {
                     int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1); halted += 1;
-                    if (G.trip_log) { const int wt = G.wtot[eo + s]; if (wt < 65535) G.wtot[eo + s] = (uint16_t)(wt + 1); }
+                    if (G.trip_log) { const int wt = G.wtot()[eo + s]; if (wt < 65535) G.wtot()[eo + s] = (uint16_t)(wt + 1); }
                 } else L.swait[s] = 0;
                 float tl = L.tloss[s];
                 if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; L.tloss[s] = tl; }
@@ -783,13 +818,13 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 if (arrived) {
                     const int ktrip = L.node[s].trip;
                     L.lane[s] = LANE_NONE; L.node[s].trip = 0xFFFF;
-                    G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0;
+                    G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0;
                     atomicAdd(&L.sc[SC_STATS + ST_ARRIVED], 1);
-                    atomicAdd(&L.sc[SC_STATS + ST_DURATION], t + 1 - (int)G.depart[eo + s]);
+                    atomicAdd(&L.sc[SC_STATS + ST_DURATION], t + 1 - (int)G.depart()[eo + s]);
                     atomicAdd(&L.sc[SC_STATS + ST_TLOSS], (int)(tl * 1024.0f + 0.5f));
                     if (G.trip_log) {
                         int32_t *r = G.trip_log + ((size_t)env * T.n_trips + ktrip) * 4;
-                        r[0] = (int)G.depart[eo + s]; r[1] = t + 1; r[2] = (int)(tl * 1024.0f + 0.5f); r[3] = (int)G.wtot[eo + s];
+                        r[0] = (int)G.depart()[eo + s]; r[1] = t + 1; r[2] = (int)(tl * 1024.0f + 0.5f); r[3] = (int)G.wtot()[eo + s];
                     }
                 } else {
                     L.node[s].pos = x;
@@ -916,29 +951,29 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         int act = 0, pend = 0;
         for (int s = tid; s < top; s += B) {
             const int lane = L.lane[s];
-            G.lane[eo + s] = (uint16_t)lane; G.trip[eo + s] = L.node[s].trip;
+            G.lane()[eo + s] = (uint16_t)lane; G.trip()[eo + s] = L.node[s].trip;
             if (lane == LANE_NONE) continue;
             // store the slab back (once per env-step)
             const int rq = L.rq[s];
-            G.pos[eo + s] = L.node[s].pos; G.speed[eo + s] = L.speed[s]; G.swait[eo + s] = L.swait[s]; G.tloss[eo + s] = L.tloss[s];
-            G.cursor[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.node[s].trip]].start);
+            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.speed[s]; G.swait()[eo + s] = L.swait[s]; G.tloss()[eo + s] = L.tloss[s];
+            G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.node[s].trip]].start);
             if (lane == LANE_PENDING) { pend += 1; continue; }
             act += 1;
             const LaneRec LR = T.lanes[lane];
-            const int oi = T.lane_obs[lane];
+            const int oi = T.cold->lane_obs[lane];
             bool detect = false;
             if (oi >= 0) {
                 float d = (LR.len - L.node[s].pos) + T.rsteps[rq].tlsdist;
                 detect = d <= P.max_distance;
             }
-            if (!detect) { G.owner[eo + s] = OWNER_NONE; G.rwait[eo + s] = 0; continue; }
-            const int sig = T.obs_sig[oi];
-            int rw = G.rwait[eo + s];
-            if (G.owner[eo + s] != (uint8_t)sig) rw = 0;
+            if (!detect) { G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0; continue; }
+            const int sig = T.cold->obs_sig[oi];
+            int rw = G.rwait()[eo + s];
+            if (G.owner()[eo + s] != (uint8_t)sig) rw = 0;
             if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
             else if (L.swait[s] > 0) rw = L.swait[s];
-            G.rwait[eo + s] = (uint16_t)rw;
-            G.owner[eo + s] = (uint8_t)sig;
+            G.rwait()[eo + s] = (uint16_t)rw;
+            G.owner()[eo + s] = (uint8_t)sig;
             if (rw > 0) { atomicAdd(&L.agg_q[oi], 1); atomicAdd(&L.agg_w[oi], rw); atomicMax(&L.agg_m[oi], rw); }
             else atomicAdd(&L.agg_a[oi], 1);
             atomicAdd(&L.agg_s[oi], (uint32_t)(L.speed[s] * 65536.0f + 0.5f));
@@ -951,23 +986,23 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     // per observed lane rows, written as flat coalesced streams (element i of [n_obs][5] / [S][Lmax][5])
     for (int i = tid; i < NO * 5; i += B) {
         const int oi = i / 5, c = i - oi * 5;
-        const int sg = T.obs_sig[oi];
+        const int sg = T.cold->obs_sig[oi];
         const float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
         float raw, nrm;
-        if (c == 0) { raw = (float)L.agg_q[oi]; nrm = (oi - T.sig_obs_start[sg]) == L.phase[sg] ? 1.0f : 0.0f; }
+        if (c == 0) { raw = (float)L.agg_q[oi]; nrm = (oi - T.cold->sig_obs_start[sg]) == L.phase[sg] ? 1.0f : 0.0f; }
         else if (c == 1) { raw = (float)L.agg_a[oi]; nrm = raw / 28.0f; }
         else if (c == 2) { raw = (float)L.agg_w[oi]; nrm = raw / 28.0f; }
         else if (c == 3) { raw = (float)L.agg_m[oi]; nrm = (float)L.agg_q[oi] / 28.0f; }
         else { raw = sp; nrm = sp / 20.0f / 28.0f; }
-        O.lane_agg[(size_t)env * NO * 5 + i] = raw;         // queue, approach, total_wait, max_wait, speed_sum
-        O.drq_norm[(size_t)env * NO * 5 + i] = nrm;         // one-hot(lane position == phase), approach, wait, queue, speed
+        O.lane_agg()[(size_t)env * NO * 5 + i] = raw;         // queue, approach, total_wait, max_wait, speed_sum
+        O.drq_norm()[(size_t)env * NO * 5 + i] = nrm;         // one-hot(lane position == phase), approach, wait, queue, speed
     }
     for (int i = tid; i < S * T.lmax * 5; i += B) {
         const int sg = i / (T.lmax * 5), r = i - sg * T.lmax * 5;
         const int l = r / 5, c = r - l * 5;
-        const int o0 = T.sig_obs_start[sg];
+        const int o0 = T.cold->sig_obs_start[sg];
         float nrm = 0.0f;                                    // zero padding beyond the signal's lanes
-        if (l < T.sig_obs_start[sg + 1] - o0) {
+        if (l < T.cold->sig_obs_start[sg + 1] - o0) {
             const int oi = o0 + l;
             if (c == 0) nrm = l == L.phase[sg] ? 1.0f : 0.0f;
             else if (c == 1) nrm = (float)L.agg_a[oi] / 28.0f;
@@ -975,36 +1010,36 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             else if (c == 3) nrm = (float)L.agg_q[oi] / 28.0f;
             else nrm = (float)L.agg_s[oi] * (1.0f / 65536.0f) / 20.0f / 28.0f;
         }
-        O.drq_f16[(size_t)env * S * T.lmax * 5 + i] = __float2half(nrm);
+        O.drq_f16()[(size_t)env * S * T.lmax * 5 + i] = __float2half(nrm);
     }
     // states.mplight / states.wave: one thread per (signal, movement)
     for (int i = tid; i < S * 12; i += B) {
         const int sg = i / 12, m = i - sg * 12;
         int q = 0, wv = 0;
-        for (int j = T.mv_in_start[i]; j < T.mv_in_start[i + 1]; ++j) {
-            const int oi = T.mv_in_idx[j];
+        for (int j = T.cold->mv_in_start[i]; j < T.cold->mv_in_start[i + 1]; ++j) {
+            const int oi = T.cold->mv_in_idx[j];
             q += L.agg_q[oi]; wv += L.agg_q[oi] + L.agg_a[oi];
         }
-        for (int j = T.mv_out_start[i]; j < T.mv_out_start[i + 1]; ++j) q -= L.agg_q[T.mv_out_idx[j]];
+        for (int j = T.cold->mv_out_start[i]; j < T.cold->mv_out_start[i + 1]; ++j) q -= L.agg_q[T.cold->mv_out_idx[j]];
         const size_t so = (size_t)env * S + sg;
-        O.mplight[so * 13 + 1 + m] = q;
-        O.wave[so * 12 + m] = wv;
+        O.mplight()[so * 13 + 1 + m] = q;
+        O.wave()[so * 12 + m] = wv;
     }
     // per signal: phase, rewards, metrics
     for (int sg = tid; sg < S; sg += B) {
         const int ph = L.phase[sg];
-        const int o0 = T.sig_obs_start[sg], o1 = T.sig_obs_start[sg + 1];
+        const int o0 = T.cold->sig_obs_start[sg], o1 = T.cold->sig_obs_start[sg + 1];
         int tw = 0, tq = 0, mq = 0;
         for (int oi = o0; oi < o1; ++oi) { tw += L.agg_w[oi]; int qq = L.agg_q[oi]; tq += qq; if (qq > mq) mq = qq; }
         const size_t so = (size_t)env * S + sg;
-        O.phase[so] = ph; O.queue_sum[so] = tq; O.queue_max[so] = mq;
-        O.wait[so] = -(float)tw;
+        O.phase()[so] = ph; O.queue_sum()[so] = tq; O.queue_max()[so] = mq;
+        O.wait()[so] = -(float)tw;
         const float wn = -(float)tw / 224.0f;
-        O.wait_norm[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
+        O.wait_norm()[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
         int pr = tq;
-        for (int i = T.pr_out_start[sg]; i < T.pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.pr_out_idx[i]];
-        O.pressure[so] = -pr;
-        O.mplight[so * 13] = ph;
+        for (int i = T.cold->pr_out_start[sg]; i < T.cold->pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.cold->pr_out_idx[i]];
+        O.pressure()[so] = -pr;
+        O.mplight()[so * 13] = ph;
         G.tls[(env * S + sg) * 3 + 0] = ph;
         G.tls[(env * S + sg) * 3 + 1] = L.left[sg];
         G.tls[(env * S + sg) * 3 + 2] = L.nextp[sg];
@@ -1025,9 +1060,9 @@ extern "C" __global__ void rs_reset_kernel(Tab T, State G, KParams P) {
     const int C = T.capacity, S = T.n_signals;
     const size_t eo = (size_t)env * C;
     for (int s = threadIdx.x; s < C; s += blockDim.x) {
-        G.lane[eo + s] = LANE_NONE; G.trip[eo + s] = 0xFFFF; G.owner[eo + s] = OWNER_NONE;
-        G.rwait[eo + s] = 0; G.swait[eo + s] = 0; G.cursor[eo + s] = 0; G.depart[eo + s] = 0; G.wtot[eo + s] = 0;
-        G.pos[eo + s] = 0.0f; G.speed[eo + s] = 0.0f; G.accel[eo + s] = 0.0f; G.tloss[eo + s] = 0.0f; G.sf[eo + s] = 1.0f;
+        G.lane()[eo + s] = LANE_NONE; G.trip()[eo + s] = 0xFFFF; G.owner()[eo + s] = OWNER_NONE;
+        G.rwait()[eo + s] = 0; G.swait()[eo + s] = 0; G.cursor()[eo + s] = 0; G.depart()[eo + s] = 0; G.wtot()[eo + s] = 0;
+        G.pos()[eo + s] = 0.0f; G.speed()[eo + s] = 0.0f; G.accel()[eo + s] = 0.0f; G.tloss()[eo + s] = 0.0f; G.sf()[eo + s] = 1.0f;
     }
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         int ph, left;
@@ -1284,20 +1319,26 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         for (int i = 0; i < sc->n_tls_states; ++i) tls8[i] = (uint8_t)sc->tls_states[i];
         for (int i = 0; i < sc->n_fix_states; ++i) fix8[i] = (uint8_t)sc->fix_states[i];
         KTab &K = h->K;
+        const int16_t *lane_obs_dev = nullptr;
+        const uint8_t *tls8_dev = nullptr, *fix8_dev = nullptr;
         if ((rc = dev_upload<LaneRec>(h, &K.lanes, lanes.data(), lanes.size())) || (rc = dev_upload<LinkRec>(h, &K.links, links.data(), links.size())) ||
             (rc = dev_upload<FoeRec>(h, &K.foes, foes.data(), foes.size())) || (rc = dev_upload<RStep>(h, &K.rsteps, rsteps.data(), rsteps.size())) ||
             (rc = dev_upload<RouteRec>(h, &K.routes, routes.data(), routes.size())) ||
             (rc = dev_upload<uint16_t>(h, &K.trip_route, trip_route.data(), trip_route.size())) ||
             (rc = dev_upload<uint8_t>(h, &K.trip_vtype, trip_vtype.data(), trip_vtype.size())) ||
-            (rc = dev_upload<int16_t>(h, &K.lane_obs, lane_obs16.data(), lane_obs16.size())) ||
-            (rc = dev_upload<uint8_t>(h, &K.tls8, tls8.data(), tls8.size())) || (rc = dev_upload<uint8_t>(h, &K.fix8, fix8.data(), fix8.size())))
+            (rc = dev_upload<int16_t>(h, &lane_obs_dev, lane_obs16.data(), lane_obs16.size())) ||
+            (rc = dev_upload<uint8_t>(h, &tls8_dev, tls8.data(), tls8.size())) || (rc = dev_upload<uint8_t>(h, &fix8_dev, fix8.data(), fix8.size())))
             return fail(rc);
-        K.route_mask2 = T.route_mask2; K.trip_depart = T.trip_depart; K.trips_cum = T.trips_cum; K.vtype_params = T.vtype_params;
-        K.tls_nphase = T.tls_nphase; K.tls_ngreen = T.tls_ngreen; K.tls_nlinks = T.tls_nlinks; K.tls_state_off = T.tls_state_off;
-        K.tls_dur_off = T.tls_dur_off; K.tls_yel_off = T.tls_yel_off; K.tls_dur = T.tls_dur; K.tls_yellow = T.tls_yellow;
-        K.fix_nphase = T.fix_nphase; K.fix_state_off = T.fix_state_off; K.fix_dur_off = T.fix_dur_off; K.fix_dur = T.fix_dur;
-        K.obs_sig = T.obs_sig; K.sig_obs_start = T.sig_obs_start; K.mv_in_start = T.mv_in_start; K.mv_in_idx = T.mv_in_idx;
-        K.mv_out_start = T.mv_out_start; K.mv_out_idx = T.mv_out_idx; K.pr_out_start = T.pr_out_start; K.pr_out_idx = T.pr_out_idx;
+        K.route_mask2 = T.route_mask2;
+        KCold cold{};
+        cold.trip_depart = T.trip_depart; cold.trips_cum = T.trips_cum; cold.vtype_params = T.vtype_params;
+        cold.tls8 = tls8_dev; cold.fix8 = fix8_dev; cold.lane_obs = lane_obs_dev;
+        cold.tls_nphase = T.tls_nphase; cold.tls_ngreen = T.tls_ngreen; cold.tls_nlinks = T.tls_nlinks; cold.tls_state_off = T.tls_state_off;
+        cold.tls_dur_off = T.tls_dur_off; cold.tls_yel_off = T.tls_yel_off; cold.tls_dur = T.tls_dur; cold.tls_yellow = T.tls_yellow;
+        cold.fix_nphase = T.fix_nphase; cold.fix_state_off = T.fix_state_off; cold.fix_dur_off = T.fix_dur_off; cold.fix_dur = T.fix_dur;
+        cold.obs_sig = T.obs_sig; cold.sig_obs_start = T.sig_obs_start; cold.mv_in_start = T.mv_in_start; cold.mv_in_idx = T.mv_in_idx;
+        cold.mv_out_start = T.mv_out_start; cold.mv_out_idx = T.mv_out_idx; cold.pr_out_start = T.pr_out_start; cold.pr_out_idx = T.pr_out_idx;
+        if ((rc = dev_upload<KCold>(h, &K.cold, &cold, 1))) return fail(rc);
         K.n_trips = sc->n_trips; K.tls_maxl = tls_maxl;
         K.n_lanes = sc->n_lanes; K.n_cells = n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
         K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = lmax;
@@ -1313,47 +1354,46 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     const size_t N = (size_t)n_envs, NC = N * C, S = (size_t)sc->n_signals, NO = (size_t)sc->n_obs;
     State &G = h->G;
     Out &O = h->O;
-    if ((rc = dev_alloc(h, &G.pos, NC)) || (rc = dev_alloc(h, &G.speed, NC)) || (rc = dev_alloc(h, &G.accel, NC)) ||
-        (rc = dev_alloc(h, &G.tloss, NC)) || (rc = dev_alloc(h, &G.sf, NC)) || (rc = dev_alloc(h, &G.lane, NC)) || (rc = dev_alloc(h, &G.trip, NC)) ||
-        (rc = dev_alloc(h, &G.cursor, NC)) || (rc = dev_alloc(h, &G.swait, NC)) || (rc = dev_alloc(h, &G.rwait, NC)) ||
-        (rc = dev_alloc(h, &G.depart, NC)) || (rc = dev_alloc(h, &G.wtot, NC)) || (rc = dev_alloc(h, &G.owner, NC)) || (rc = dev_alloc(h, &G.env, N * 4)) ||
-        (rc = dev_alloc(h, &G.tls, N * S * 3)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
-        (rc = dev_alloc(h, &O.lane_agg, N * NO * 5)) || (rc = dev_alloc(h, &O.drq_norm, N * NO * 5)) ||
-        (rc = dev_alloc(h, &O.wait, N * S)) || (rc = dev_alloc(h, &O.wait_norm, N * S)) ||
-        (rc = dev_alloc(h, &O.phase, N * S)) || (rc = dev_alloc(h, &O.mplight, N * S * 13)) ||
-        (rc = dev_alloc(h, &O.wave, N * S * 12)) || (rc = dev_alloc(h, &O.pressure, N * S)) ||
-        (rc = dev_alloc(h, &O.queue_sum, N * S)) || (rc = dev_alloc(h, &O.queue_max, N * S)) ||
-        (rc = dev_alloc(h, &O.drq_f16, N * S * lmax * 5)) || (rc = dev_alloc(h, &h->actions, N * S)))
-        return fail(rc);
+    {
+        char *slab = nullptr, *outb = nullptr;
+        G.nc = NC;
+        O.n = n_envs; O.o = sc->n_obs; O.s = sc->n_signals; O.lm = lmax;
+        if ((rc = dev_alloc(h, &slab, State::bytes(NC))) || (rc = dev_alloc(h, &outb, O.bytes())) ||
+            (rc = dev_alloc(h, &G.env, N * 4)) || (rc = dev_alloc(h, &G.tls, N * S * 3)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
+            (rc = dev_alloc(h, &h->actions, N * S)))
+            return fail(rc);
+        G.base = slab; O.base = outb;
+        (void)NO;
+    }
     const int64_t n = n_envs, c = C, s = sc->n_signals, o = sc->n_obs;
-    set_buf(h, RS_BUF_LANE_AGG, O.lane_agg, RS_F32, 3, n, o, 5);
-    set_buf(h, RS_BUF_DRQ_NORM, O.drq_norm, RS_F32, 3, n, o, 5);
-    set_buf(h, RS_BUF_PHASE, O.phase, RS_I32, 2, n, s);
-    set_buf(h, RS_BUF_MPLIGHT, O.mplight, RS_I32, 3, n, s, 13);
-    set_buf(h, RS_BUF_WAVE, O.wave, RS_I32, 3, n, s, 12);
-    set_buf(h, RS_BUF_WAIT, O.wait, RS_F32, 2, n, s);
-    set_buf(h, RS_BUF_WAIT_NORM, O.wait_norm, RS_F32, 2, n, s);
-    set_buf(h, RS_BUF_PRESSURE, O.pressure, RS_I32, 2, n, s);
-    set_buf(h, RS_BUF_QUEUE_SUM, O.queue_sum, RS_I32, 2, n, s);
-    set_buf(h, RS_BUF_QUEUE_MAX, O.queue_max, RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_LANE_AGG, O.lane_agg(), RS_F32, 3, n, o, 5);
+    set_buf(h, RS_BUF_DRQ_NORM, O.drq_norm(), RS_F32, 3, n, o, 5);
+    set_buf(h, RS_BUF_PHASE, O.phase(), RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_MPLIGHT, O.mplight(), RS_I32, 3, n, s, 13);
+    set_buf(h, RS_BUF_WAVE, O.wave(), RS_I32, 3, n, s, 12);
+    set_buf(h, RS_BUF_WAIT, O.wait(), RS_F32, 2, n, s);
+    set_buf(h, RS_BUF_WAIT_NORM, O.wait_norm(), RS_F32, 2, n, s);
+    set_buf(h, RS_BUF_PRESSURE, O.pressure(), RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_QUEUE_SUM, O.queue_sum(), RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_QUEUE_MAX, O.queue_max(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_ACTIONS, h->actions, RS_I32, 2, n, s);
     set_buf(h, RS_BUF_ENV, G.env, RS_I32, 2, n, 4);
     set_buf(h, RS_BUF_TLS, G.tls, RS_I32, 3, n, s, 3);
-    set_buf(h, RS_BUF_VEH_POS, G.pos, RS_F32, 2, n, c);
-    set_buf(h, RS_BUF_VEH_SPEED, G.speed, RS_F32, 2, n, c);
-    set_buf(h, RS_BUF_VEH_ACCEL, G.accel, RS_F32, 2, n, c);
-    set_buf(h, RS_BUF_VEH_TLOSS, G.tloss, RS_F32, 2, n, c);
-    set_buf(h, RS_BUF_VEH_LANE, G.lane, RS_U16, 2, n, c);
-    set_buf(h, RS_BUF_VEH_TRIP, G.trip, RS_U16, 2, n, c);
-    set_buf(h, RS_BUF_VEH_CURSOR, G.cursor, RS_U16, 2, n, c);
-    set_buf(h, RS_BUF_VEH_SWAIT, G.swait, RS_U16, 2, n, c);
-    set_buf(h, RS_BUF_VEH_RWAIT, G.rwait, RS_U16, 2, n, c);
-    set_buf(h, RS_BUF_VEH_DEPART, G.depart, RS_U16, 2, n, c);
-    set_buf(h, RS_BUF_VEH_OWNER, G.owner, RS_U8, 2, n, c);
+    set_buf(h, RS_BUF_VEH_POS, G.pos(), RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_SPEED, G.speed(), RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_ACCEL, G.accel(), RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_TLOSS, G.tloss(), RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_LANE, G.lane(), RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_TRIP, G.trip(), RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_CURSOR, G.cursor(), RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_SWAIT, G.swait(), RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_RWAIT, G.rwait(), RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_DEPART, G.depart(), RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_VEH_OWNER, G.owner(), RS_U8, 2, n, c);
     set_buf(h, RS_BUF_STATS, G.stats, RS_I64, 2, n, ST_N);
-    set_buf(h, RS_BUF_DRQ_NORM_F16, O.drq_f16, RS_F16, 4, n, s, lmax, 5);
-    set_buf(h, RS_BUF_VEH_SF, G.sf, RS_F32, 2, n, c);
-    set_buf(h, RS_BUF_VEH_WTOT, G.wtot, RS_U16, 2, n, c);
+    set_buf(h, RS_BUF_DRQ_NORM_F16, O.drq_f16(), RS_F16, 4, n, s, lmax, 5);
+    set_buf(h, RS_BUF_VEH_SF, G.sf(), RS_F32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_WTOT, G.wtot(), RS_U16, 2, n, c);
     G.trip_log = nullptr;
     if (p->trip_log && (rc = dev_alloc(h, &G.trip_log, N * (size_t)sc->n_trips * 4))) return fail(rc);
     set_buf(h, RS_BUF_TRIP_LOG, G.trip_log, RS_I32, 3, n, p->trip_log ? sc->n_trips : 0, 4);
@@ -1478,8 +1518,8 @@ extern "C" int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n
     }
     int total = h->n_envs * h->T.n_signals;
     hipLaunchKernelGGL(rs_act_maxwave_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->T, h->P, (const int32_t *)h->pairs,
-                       h->n_pairs, (const int32_t *)h->valid, (const int32_t *)h->order, (int)use_pressure, (const int32_t *)h->O.mplight,
-                       (const int32_t *)h->O.wave, h->actions);
+                       h->n_pairs, (const int32_t *)h->valid, (const int32_t *)h->order, (int)use_pressure, (const int32_t *)h->O.mplight(),
+                       (const int32_t *)h->O.wave(), h->actions);
     HIPCHK(h, hipGetLastError());
     return RS_OK;
 }
