@@ -84,15 +84,18 @@ class BatchedIDQN(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, obs):
-        """obs [N, S, Lmax, 5] (zero padded) -> Q [N, S, Amax] (padded actions = -inf)."""
-        x = obs.to(self.conv_w.dtype)
-        # unfold the 2x2 patches: [N, S, H, 4, 4]
-        p = torch.stack((x[:, :, :-1, :-1], x[:, :, :-1, 1:], x[:, :, 1:, :-1], x[:, :, 1:, 1:]), dim=-1)
-        y = torch.einsum('nshwk,skc->nshwc', p, self.conv_w) + self.conv_b[None, :, None, None, :]
-        y = torch.relu(y).flatten(2)                                       # (h, w, c) order
-        y = torch.relu(torch.einsum('nsf,sfo->nso', y, self.fc1_w) + self.fc1_b)
-        y = torch.relu(torch.einsum('nsf,sfo->nso', y, self.fc2_w) + self.fc2_b)
-        q = torch.einsum('nsf,sfo->nso', y, self.fc3_w) + self.fc3_b
+        """obs [N, S, Lmax, 5] (zero padded) -> Q [N, S, Amax] (padded actions = -inf).
+
+        Signal-major batched GEMMs (rocBLAS strided-batched): the 2x2 convolution is a K=4 GEMM over unfolded
+        patches, the three linear layers are [S] x ([N, F] @ [F, O]) products."""
+        N, S = obs.shape[0], obs.shape[1]
+        x = obs.to(self.conv_w.dtype).transpose(0, 1)                       # [S, N, L, 5]
+        p = torch.stack((x[:, :, :-1, :-1], x[:, :, :-1, 1:], x[:, :, 1:, :-1], x[:, :, 1:, 1:]), dim=-1)   # [S, N, H, 4, 4]
+        y = torch.baddbmm(self.conv_b.unsqueeze(1), p.reshape(S, -1, 4), self.conv_w)     # [S, N*H*4, 64]
+        y = torch.relu_(y).reshape(S, N, -1)                                # features in (h, w, c) order
+        y = torch.relu_(torch.baddbmm(self.fc1_b.unsqueeze(1), y, self.fc1_w))
+        y = torch.relu_(torch.baddbmm(self.fc2_b.unsqueeze(1), y, self.fc2_w))
+        q = torch.baddbmm(self.fc3_b.unsqueeze(1), y, self.fc3_w).transpose(0, 1)         # [N, S, Amax]
         return q.masked_fill(~self.action_mask, float('-inf'))
 
     @torch.no_grad()
