@@ -50,3 +50,13 @@ def test_no_silent_cpu_fallback():
     sc = load_scenario('cologne1')
     with pytest.raises(RuntimeError, match='rs_create failed'):
         rsim.BatchedSim(sc, 2)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    """no HIP library -> RuntimeError, never a silent fallback"""
+    monkeypatch.setattr(rsim, '_lib', None)
+    monkeypatch.setattr(rsim, 'LIB_PATH', os.path.join(ROOT, 'resco_amd', 'csrc', 'does_not_exist.so'))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        rsim.load_library()
+    monkeypatch.undo()
+    rsim.load_library()

@@ -239,6 +239,31 @@ def test_trip_log_and_tripinfo_output():
     env.close()
 
 
+def test_full_episode_done_rule_and_metrics_file():
+    """360 steps of 10 s: done turns True exactly when simulation.getTime() reaches end_time
+    (multi_signal.py:190); metrics_<run>.csv gets one line per step at the next reset (multi_signal.py:107-111)."""
+    from resco_amd import rewards, states
+    from resco_amd.multi_signal import MultiSignal
+    tmp = tempfile.mkdtemp() + os.sep
+    env = MultiSignal('t', 'cologne1', None, states.wave, rewards.pressure, yellow_length=3, end_time=28800,
+                      max_distance=50, log_dir=tmp, seed=5)
+    for episode in (1, 2):
+        obs = env.reset()
+        steps, done = 0, False
+        while not done:
+            obs, rew, done, info = env.step({env.all_ts_ids[0]: steps % 4})
+            steps += 1
+            assert info == {'eps': episode}
+        assert steps == 360 and env.sim_time() == 28800.0
+    env.close()
+    for episode in (1, 2):
+        with open(os.path.join(tmp, env.connection_name, 'metrics_%d.csv' % episode)) as f:
+            rows = f.read().splitlines()
+        assert len(rows) == 360 and rows[0].startswith('25210.0, ') and rows[-1].startswith('28800.0, ')
+    ts = env.scenario.n_trips
+    assert ts == 2015
+
+
 def test_gymma_list_api_and_custom_state_fn():
     from resco_amd import rewards, states
     from resco_amd.multi_signal import MultiSignal
