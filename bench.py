@@ -125,7 +125,7 @@ def cpu_baseline(sc, seed, budget_s=15.0):
         done = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
     total = sum(done)
-    return dict(value=total / wall, unit='env-steps/s', cores=cores, kind='port',
+    return dict(value=total / wall, unit='env-steps/s', cores=cores, kind='port', single_thread_value=1.0 / probe,
                 sample='C oracle (oracle/resco_oracle.c, gcc -O2, scalar): %d processes (affinity %d, cgroup quota applied) x %d '
                        'env-steps of ingolstadt21 from episode start, same hashed random policy, %.1f s wall'
                        % (cores, len(os.sched_getaffinity(0)), per_worker, wall))
@@ -231,6 +231,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(sc, args.seed)
+                import shutil
+                have_sumo = shutil.which('sumo') is not None
+                try:
+                    import libsumo  # noqa: F401
+                    have_sumo = True
+                except Exception:
+                    pass
+                # a SUMO / libsumo timing is reported only when SUMO exists on the box
+                out['sumo_baseline'] = 'not measured (SUMO found but no runner shipped)' if have_sumo else \
+                    'SUMO unavailable on this host'
             except Exception as e:          # the baseline must never take the GPU number down with it
                 out['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
