@@ -216,10 +216,13 @@ struct __attribute__((aligned(16))) RStep {
     uint32_t next_mask2, next_mask1;
     float tlsdist;
 };
-struct __attribute__((aligned(8))) RouteRec {
+struct __attribute__((aligned(16))) RouteRec {
     uint32_t start;
     uint16_t depart_lane;
-    int16_t depart_arr;
+    int16_t depart_arr;         // insertion-candidate register of the departure lane
+    uint16_t first_link;        // cache_link() of (departure lane, first route step), precomputed
+    uint16_t depart_cell0;      // first list cell of the departure lane (a new vehicle always lands in it)
+    float depart_len;           // length of the departure lane
 };
 #define LF_INTERNAL 1u
 #define KF_MINOR 1u
@@ -382,6 +385,19 @@ __device__ __forceinline__ uint16_t cache_link(const KTab &T, const LaneRec &LR,
     return (uint16_t)(link | (T.links[link].arr_idx >= 0 ? NLINK_ARR : 0));
 }
 
+// A vehicle waiting for insertion keeps everything the insertion needs in its (otherwise unused) slot fields, so
+// that the per-tick insertion phases touch LDS only:  pos = insertion position, swait = candidate register,
+// nlink = first link, speed bits = departure lane << 16 | list cell, tloss bits = scheduled departure tick.
+__device__ __forceinline__ void stash_pending(const KTab &T, Lds &L, int s, int k, const float *vt) {
+    const RouteRec RR = T.routes[T.trip_route[k]];
+    const float mypos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
+    L.node[s].pos = mypos;
+    L.swait[s] = (uint16_t)RR.depart_arr;
+    L.nlink[s] = RR.first_link;
+    L.speed[s] = __int_as_float(((int)RR.depart_lane << 16) | (int)RR.depart_cell0);
+    L.tloss[s] = __int_as_float(T.cold->trip_depart[k]);
+}
+
 __device__ __forceinline__ int tls_state(const KTab &T, const Lds &L, const KParams &P, int tls, int pos) {
     if (tls == 0xFF) return TLS_G;
     return L.tstate[tls * T.tls_maxl + pos];
@@ -542,13 +558,14 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor()[eo + s];
                 L.rq[s] = (uint16_t)rq;
                 L.vt[s] = T.trip_vtype[tr];
-                uint16_t nl = NLINK_NONE;
                 if (ln != LANE_PENDING) {
                     const LaneRec LR0 = T.lanes[ln];
-                    nl = cache_link(T, LR0, rq);
+                    L.nlink[s] = cache_link(T, LR0, rq);
                     L.node[s].nxt = list_push(hc, LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0)), s, sp > HALT_SPEED);
-                } else npend += 1;
-                L.nlink[s] = nl;
+                } else {
+                    npend += 1;
+                    stash_pending(T, L, s, tr, T.cold->vtype_params + T.trip_vtype[tr] * VT_COLS);
+                }
             }
         }
         if (npend) atomicAdd(&L.sc[SC_NPEND], npend);
@@ -590,8 +607,8 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     const int k_ = nt_ + base_ + rank_;                                                            \
                     const int v_ = T.trip_vtype[k_];                                                               \
                     L.node[s_].trip = (uint16_t)k_; L.lane[s_] = LANE_PENDING;                                          \
-                    L.node[s_].pos = 0.0f; L.speed[s_] = 0.0f; L.swait[s_] = 0; L.nlink[s_] = NLINK_NONE; L.tloss[s_] = 0.0f; \
                     L.vt[s_] = (uint8_t)v_; L.rq[s_] = (uint16_t)T.routes[T.trip_route[k_]].start;                 \
+                    stash_pending(T, L, s_, k_, T.cold->vtype_params + v_ * VT_COLS);                              \
                     G.sf()[eo + s_] = speed_factor(P, genv, k_, T.cold->vtype_params + v_ * VT_COLS);                      \
                     G.rwait()[eo + s_] = 0; G.owner()[eo + s_] = OWNER_NONE; G.depart()[eo + s_] = 0; G.accel()[eo + s_] = 0.0f; G.wtot()[eo + s_] = 0; \
                     atomicMax(&L.sc[SC_HW], s_ + 1);                                                               \
@@ -628,7 +645,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         // ---- A: insertion candidates (lowest pending trip per departure lane) and approach registration
         if (pending)
             for (int s = tid; s < hw; s += B)
-                if (L.lane[s] == LANE_PENDING) atomicMin(&L.dep[T.routes[T.trip_route[L.node[s].trip]].depart_arr], (int)L.node[s].trip);
+                if (L.lane[s] == LANE_PENDING) atomicMin(&L.dep[L.swait[s]], (int)L.node[s].trip);
         if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_NLC] = 0; }
         // P3: vehicles that will pass a link somebody may have to yield to register their arrival time
         for (int s = tid; s < hw; s += B) {
@@ -655,27 +672,26 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             for (int s = tid; s < hw; s += B) {
                 if (L.lane[s] != LANE_PENDING) continue;
                 const int k = L.node[s].trip;
-                const RouteRec RR = T.routes[T.trip_route[k]];
-                if (L.dep[RR.depart_arr] != k) continue;        // lost (or the winner already cleared the register)
-                const int dl = RR.depart_lane;
+                const int di = L.swait[s];
+                if (L.dep[di] != k) continue;                   // lost (or the winner already cleared the register)
+                const int packed = __float_as_int(L.speed[s]);
+                const int dl = packed >> 16, cell = packed & 0xFFFF;
                 const float *vt = L.vtp + L.vt[s] * VT_COLS;
-                const LaneRec LRd = T.lanes[dl];
-                const float ll = LRd.len;
-                const float mypos = vt[VT_LENGTH] < ll ? vt[VT_LENGTH] : ll;
+                const float mypos = L.node[s].pos;
                 bool ins = true;
                 // only vehicles with pos < mypos + minGap + length can be in the way: they all sit in cell 0
-                for (int o = hc[LRd.cell0] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
+                for (int o = hc[cell] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
                     float back = L.node[o].pos - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
                     if (back - mypos - vt[VT_MINGAP] < 0.0f) ins = false;
                 }
-                L.dep[RR.depart_arr] = ARR_NONE;
+                L.dep[di] = ARR_NONE;
                 if (!ins) continue;
-                L.lane[s] = (uint16_t)dl; L.node[s].pos = mypos; L.speed[s] = 0.0f;
-                L.nlink[s] = cache_link(T, LRd, RR.start);
+                const int sched = __float_as_int(L.tloss[s]);
+                L.lane[s] = (uint16_t)dl; L.speed[s] = 0.0f; L.swait[s] = 0; L.tloss[s] = 0.0f;
                 G.depart()[eo + s] = (uint16_t)t;
-                L.node[s].nxt = list_push(hc, LRd.cell0 + cell_of(mypos, lane_cells(LRd)), s, false);
+                L.node[s].nxt = list_push(hc, cell, s, false);
                 atomicAdd(&L.sc[SC_STATS + ST_INSERTED], 1);
-                atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - T.cold->trip_depart[k]);
+                atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - sched);
                 atomicSub(&L.sc[SC_NPEND], 1);
             }
             __syncthreads();
@@ -955,9 +971,13 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (lane == LANE_NONE) continue;
             // store the slab back (once per env-step)
             const int rq = L.rq[s];
+            if (lane == LANE_PENDING) {     // the slot fields hold the insertion stash; the state of a waiting vehicle is all zero
+                G.pos()[eo + s] = 0.0f; G.speed()[eo + s] = 0.0f; G.swait()[eo + s] = 0; G.tloss()[eo + s] = 0.0f; G.cursor()[eo + s] = 0;
+                pend += 1;
+                continue;
+            }
             G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.speed[s]; G.swait()[eo + s] = L.swait[s]; G.tloss()[eo + s] = L.tloss[s];
             G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.node[s].trip]].start);
-            if (lane == LANE_PENDING) { pend += 1; continue; }
             act += 1;
             const LaneRec LR = T.lanes[lane];
             const int oi = T.cold->lane_obs[lane];
@@ -1184,6 +1204,9 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { h->err = "no HIP device visible (this library has no CPU fallback)"; return fail(RS_EHIP); }
     if (hipSetDevice(device_id) != hipSuccess) { h->err = "hipSetDevice failed"; return fail(RS_EHIP); }
+    if (sc->step_length <= 0 || sc->yellow_length < 0 || sc->yellow_length >= sc->step_length) {
+        h->err = "need 0 <= yellow_length < step_length"; return fail(RS_EINVAL);
+    }
     const int C = sc->capacity;
     if (C < 64 || (C & (C - 1)) || C > 16384) { h->err = "capacity must be a power of two in [64, 16384]"; return fail(RS_ELIMIT); }
     if (sc->n_lanes >= 0xFFFE || sc->n_trips >= 0xFFFF || sc->n_routes > 0xFFFF || sc->n_vtypes > 255 || sc->n_signals > 254) {
@@ -1311,6 +1334,24 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
             const int dl = sc->edge_lane0[e] + k;
             if (lane_dep[dl] < 0) lane_dep[dl] = (int16_t)n_dep++;
             routes[r].start = (uint32_t)rs; routes[r].depart_lane = (uint16_t)dl; routes[r].depart_arr = lane_dep[dl];
+            routes[r].depart_cell0 = lanes[dl].cell0; routes[r].depart_len = sc->lane_len[dl];
+            {   // choose_link(departure lane, first route step) + the approach-register flag, as cache_link() computes it
+                int link = -1;
+                if (re - rs >= 2) {
+                    const int ne = sc->route_edge[rs + 1];
+                    const uint32_t pref = sc->route_mask2[rs + 1], okm = sc->route_mask1[rs + 1];
+                    int best = -1, any = -1;
+                    for (int l = sc->lane_link_start[dl]; l < sc->lane_link_start[dl] + sc->lane_link_cnt[dl]; ++l) {
+                        if (sc->link_to_edge[l] != ne) continue;
+                        const int kk = sc->link_dest_lane[l] - sc->edge_lane0[ne];
+                        if ((pref >> kk) & 1u) { link = l; break; }
+                        if (best < 0 && ((okm >> kk) & 1u)) best = l;
+                        if (any < 0) any = l;
+                    }
+                    if (link < 0) link = best >= 0 ? best : any;
+                }
+                routes[r].first_link = link < 0 ? (uint16_t)NLINK_NONE : (uint16_t)(link | (link_arr[link] >= 0 ? NLINK_ARR : 0));
+            }
         }
         std::vector<uint16_t> trip_route((size_t)sc->n_trips);
         std::vector<uint8_t> trip_vtype((size_t)sc->n_trips);

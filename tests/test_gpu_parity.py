@@ -83,6 +83,36 @@ def test_gpu_equals_oracle_bit_exact(name, n_envs, steps, sigma, speed_dev, fixe
     sim.close()
 
 
+def test_full_episode_bit_exact_ingolstadt21():
+    """a whole 360-step episode (3600 ticks, ~4000 trips, congestion, slot reuse) stays bit-identical to the oracle"""
+    from oracle.pyoracle import OracleEnv
+    from oracle_batch import hashed_random_actions
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('ingolstadt21')
+    n, seed = 2, 12
+    sim = BatchedSim(sc, n, seed=seed, trip_log=1)
+    orcs = [OracleEnv(sc, env_index=e, seed=seed, sigma=-1.0, speed_dev=1, trip_log=1) for e in range(n)]
+    for o in orcs:
+        o.observe()
+    for k in range(360):
+        sim.act_random(k)
+        sim.step(None)
+        acts = hashed_random_actions(sc, seed, 0, n, k)
+        for e, o in enumerate(orcs):
+            o.step(acts[e])
+        if k % 30 == 29 or k == 359:
+            assert_env_equal(sim, orcs, k)
+    st = sim.stats()
+    log = sim.read('trip_log')
+    for e, o in enumerate(orcs):
+        so = o.stats()
+        for key in st:
+            assert st[key][e] == so[key], (key, e)
+        np.testing.assert_array_equal(log[e], o.trip_log())
+    assert st['arrived'].min() > 3000
+    sim.close()
+
+
 @pytest.mark.parametrize('tag', HOT_CASES)
 @pytest.mark.parametrize('fast', [True, False])
 def test_multisignal_matches_reference_python(tag, fast):
