@@ -20,6 +20,9 @@ def main(n=1024, steps=360, dtype=torch.float16):
     net = BatchedIDQN.from_scenario(env.scenario, dtype=dtype, device='cuda')
     net.init_like_reference(seed=0)
     stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):          # rocBLAS / allocator warm-up outside the timed regions
+        net.act(env.reset(stream)['drq_norm_f16'], epsilon=0.5)
+    torch.cuda.synchronize()
     out = {}
     for mode in ('sim_only', 'sim_plus_policy'):
         obs = env.reset(stream)['drq_norm_f16']
