@@ -9,11 +9,11 @@ LIB = os.path.join(HERE, 'csrc', 'libresco_sim.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: fp32 results must equal the CPU oracle bit-for-bit (no FMA fusion)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
-         '-I' + os.path.join(ROOT, 'include')]
+         '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(HERE, 'csrc')]
 
 
 def build_library(force=False, verbose=False):
-    deps = [SRC, os.path.join(ROOT, 'include', 'resco_sim.h')]
+    deps = [SRC, os.path.join(HERE, 'csrc', 'resco_kernels.h'), os.path.join(ROOT, 'include', 'resco_sim.h')]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     cmd = [HIPCC] + FLAGS + [SRC, '-o', LIB]
