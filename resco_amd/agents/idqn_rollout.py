@@ -31,9 +31,9 @@ class BatchedIDQN(nn.Module):
         S, self.lmax, self.amax = len(self.lanes), max(self.lanes), max(self.actions)
         H = self.lmax - 1
         kw = dict(dtype=dtype, device=device)
-        self.conv_w = nn.Parameter(torch.zeros(S, 4, 64, **kw))            # (kh*2+kw) x out-channel
-        self.conv_b = nn.Parameter(torch.zeros(S, 64, **kw))
-        self.fc1_w = nn.Parameter(torch.zeros(S, H * 4 * 64, 64, **kw))    # rows in (h, w, c) order
+        self.conv_w = nn.Parameter(torch.zeros(S * 64, 1, 2, 2, **kw))     # grouped conv2d: one group per signal
+        self.conv_b = nn.Parameter(torch.zeros(S * 64, **kw))
+        self.fc1_w = nn.Parameter(torch.zeros(S, 64 * H * 4, 64, **kw))    # rows in the reference's Flatten order (c, h, w)
         self.fc1_b = nn.Parameter(torch.zeros(S, 64, **kw))
         self.fc2_w = nn.Parameter(torch.zeros(S, 64, 64, **kw))
         self.fc2_b = nn.Parameter(torch.zeros(S, 64, **kw))
@@ -57,12 +57,12 @@ class BatchedIDQN(nn.Module):
         for s, m in enumerate(modules):
             conv, fc1, fc2, fc3 = m[0], m[3], m[5], m[7]
             hs = self.lanes[s] - 1
-            self.conv_w[s] = conv.weight.reshape(64, 4).t().to(self.conv_w)
-            self.conv_b[s] = conv.bias.to(self.conv_b)
+            self.conv_w[s * 64:(s + 1) * 64] = conv.weight.to(self.conv_w)
+            self.conv_b[s * 64:(s + 1) * 64] = conv.bias.to(self.conv_b)
             w1 = fc1.weight.reshape(64, 64, hs, 4)                       # out, c, h, w (Flatten order c, h, w)
             full = torch.zeros(64, 64, H, 4, dtype=w1.dtype)
             full[:, :, :hs] = w1                                          # rows of padded lanes stay zero
-            self.fc1_w[s] = full.permute(2, 3, 1, 0).reshape(H * 4 * 64, 64).to(self.fc1_w)
+            self.fc1_w[s] = full.reshape(64, 64 * H * 4).t().to(self.fc1_w)
             self.fc1_b[s] = fc1.bias.to(self.fc1_b)
             self.fc2_w[s] = fc2.weight.t().to(self.fc2_w)
             self.fc2_b[s] = fc2.bias.to(self.fc2_b)
@@ -86,13 +86,11 @@ class BatchedIDQN(nn.Module):
     def forward(self, obs):
         """obs [N, S, Lmax, 5] (zero padded) -> Q [N, S, Amax] (padded actions = -inf).
 
-        Signal-major batched GEMMs (rocBLAS strided-batched): the 2x2 convolution is a K=4 GEMM over unfolded
-        patches, the three linear layers are [S] x ([N, F] @ [F, O]) products."""
+        The S 2x2 convolutions are ONE grouped conv2d (signals = groups, MIOpen); the three linear layers are
+        signal-major strided-batched GEMMs (rocBLAS): [S] x ([N, F] @ [F, O])."""
         N, S = obs.shape[0], obs.shape[1]
-        x = obs.to(self.conv_w.dtype).transpose(0, 1)                       # [S, N, L, 5]
-        p = torch.stack((x[:, :, :-1, :-1], x[:, :, :-1, 1:], x[:, :, 1:, :-1], x[:, :, 1:, 1:]), dim=-1)   # [S, N, H, 4, 4]
-        y = torch.baddbmm(self.conv_b.unsqueeze(1), p.reshape(S, -1, 4), self.conv_w)     # [S, N*H*4, 64]
-        y = torch.relu_(y).reshape(S, N, -1)                                # features in (h, w, c) order
+        y = torch.nn.functional.conv2d(obs.to(self.conv_w.dtype), self.conv_w, self.conv_b, groups=S)   # [N, S*64, H, 4]
+        y = torch.relu_(y).reshape(N, S, -1).transpose(0, 1)                # [S, N, 64*H*4] in (c, h, w) order
         y = torch.relu_(torch.baddbmm(self.fc1_b.unsqueeze(1), y, self.fc1_w))
         y = torch.relu_(torch.baddbmm(self.fc2_b.unsqueeze(1), y, self.fc2_w))
         q = torch.baddbmm(self.fc3_b.unsqueeze(1), y, self.fc3_w).transpose(0, 1)         # [N, S, Amax]
@@ -105,8 +103,8 @@ class BatchedIDQN(nn.Module):
         greedy = q.argmax(dim=-1)
         if epsilon <= 0.0:
             return greedy.to(torch.int32)
-        n_act = torch.as_tensor(self.actions, device=q.device)
-        u = torch.rand(greedy.shape, device=q.device, generator=generator)
-        rnd = (torch.rand(greedy.shape, device=q.device, generator=generator) * n_act).long().clamp_(max=self.amax - 1)
-        rnd = torch.minimum(rnd, n_act - 1)
-        return torch.where(u < epsilon, rnd, greedy).to(torch.int32)
+        if not hasattr(self, '_n_act') or self._n_act.device != q.device:
+            self._n_act = torch.as_tensor(self.actions, device=q.device, dtype=torch.float32)
+        u = torch.rand((2,) + tuple(greedy.shape), device=q.device, generator=generator)
+        rnd = torch.minimum((u[1] * self._n_act).long(), (self._n_act - 1).long())
+        return torch.where(u[0] < epsilon, rnd, greedy).to(torch.int32)
