@@ -92,8 +92,12 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
 void rs_destroy(rs_handle h);
 const char *rs_last_error(rs_handle h);     /* h may be NULL: error of the last failed rs_create on this thread */
 
-/* Start a new episode in every environment and run the first observe.  stream: a hipStream_t, or NULL for
- * the handle's own stream. */
+/* Start a new episode in every environment and run the first observe.
+ * stream (here and below): a hipStream_t to launch on, or NULL for the handle's own non-blocking stream.  A
+ * caller that works on the default (null) stream - e.g. PyTorch's default stream, whose handle is 0 - must pass
+ * hipStreamLegacy ((hipStream_t)1), not 0, to be ordered with its own kernels.  The synchronous calls (rs_sync,
+ * rs_read_buffer, rs_stats, rs_snapshot, rs_restore) wait for the handle's stream and for the stream of the most
+ * recent launch, which therefore must still exist. */
 int rs_reset(rs_handle h, void *stream);
 /* One MultiSignal.step() for every environment.  actions: int32 [n_envs][n_signals] (green-phase index per
  * signal), host pointer, or device pointer when actions_on_device != 0; NULL = use the handle's RS_BUF_ACTIONS

@@ -10,7 +10,7 @@ signal) are evaluated for all N environments at once from the kernel-produced fp
 ``drq_norm_f16 [N, S, Lmax, 5]``: the 2x2 convolution becomes one einsum over unfolded patches, the three
 linear layers become batched matmuls over the signal axis, padded lanes / actions are masked.  Weights can be
 imported from / exported to the per-signal reference-architecture modules, so a trained IDQN plugs in.
-Learning (PFRL DQN) stays out of scope; epsilon-greedy action selection is included.
+Epsilon-greedy action selection is included; the replay ring and the DQN update live in idqn_learn.py.
 """
 import torch
 import torch.nn as nn

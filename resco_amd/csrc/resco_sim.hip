@@ -63,6 +63,7 @@ struct rs_sim {
     unsigned long long *prof = nullptr;
     int n_pairs = 0;
     hipStream_t stream = nullptr;
+    hipStream_t last = nullptr;         // stream of the most recent launch: what the synchronous calls wait for
     std::vector<void *> allocs;
     std::vector<int32_t> tls_ngreen;
     struct Buf { void *ptr; int64_t shape[4]; int ndim; int dtype; size_t bytes; };
@@ -111,6 +112,13 @@ static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_
     B.ptr = ptr; B.dtype = dtype; B.ndim = ndim;
     B.shape[0] = a; B.shape[1] = b; B.shape[2] = c; B.shape[3] = d;
     B.bytes = (size_t)(a * b * c * d) * kDtypeSize[dtype];
+}
+
+// every synchronous entry point waits for the handle's own stream AND the caller stream of the last launch
+static hipError_t wait_idle(rs_sim *h) {
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && h->last && h->last != h->stream) e = hipStreamSynchronize(h->last);
+    return e;
 }
 
 extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
@@ -389,7 +397,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
 extern "C" void rs_destroy(rs_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)wait_idle(h); (void)hipStreamDestroy(h->stream); }
     for (auto &e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void *p : h->allocs) (void)hipFree(p);
     delete h;
@@ -422,6 +430,7 @@ extern "C" int rs_reset(rs_handle h, void *stream) {
     if (!h) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last = st;
     hipLaunchKernelGGL(rs_reset_kernel, dim3(h->n_envs), dim3(256), 0, st, h->T, h->G, h->P);
     HIPCHK(h, hipGetLastError());
     bool tm = h->timing;
@@ -435,6 +444,7 @@ extern "C" int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_d
     if (!h) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last = st;
     if (actions) {
         size_t bytes = (size_t)h->n_envs * h->T.n_signals * sizeof(int32_t);
         HIPCHK(h, hipMemcpyAsync(h->actions, actions, bytes, actions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
@@ -447,7 +457,7 @@ extern "C" int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_d
 extern "C" int rs_sync(rs_handle h) {
     if (!h) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_idle(h));
     return RS_OK;
 }
 
@@ -455,6 +465,7 @@ extern "C" int rs_act_random(rs_handle h, uint32_t step_key, void *stream) {
     if (!h) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last = st;
     int total = h->n_envs * h->T.n_signals;
     hipLaunchKernelGGL(rs_act_random_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->T, h->P, step_key, h->actions);
     HIPCHK(h, hipGetLastError());
@@ -466,6 +477,7 @@ extern "C" int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n
     if (!h || n_pairs <= 0) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last = st;
     if (!h->pairs) {
         if (!phase_pairs || !valid || !order) { h->err = "rs_act_maxwave: tables required on first use"; return RS_EINVAL; }
         int rc;
@@ -499,7 +511,7 @@ extern "C" int rs_read_buffer(rs_handle h, int32_t which, void *host_dst, int64_
     auto &B = h->bufs[which];
     if ((size_t)nbytes != B.bytes) { h->err = "rs_read_buffer: size mismatch"; return RS_EINVAL; }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_idle(h));
     HIPCHK(h, hipMemcpy(host_dst, B.ptr, B.bytes, hipMemcpyDeviceToHost));
     return RS_OK;
 }
@@ -519,7 +531,7 @@ static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, 
 extern "C" int rs_snapshot(rs_handle h, void **snap) {
     if (!h || !snap) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_idle(h));
     Snapshot *S = new Snapshot();
     for (int b : kSnapBufs) {
         void *d = nullptr;
@@ -534,7 +546,7 @@ extern "C" int rs_snapshot(rs_handle h, void **snap) {
 extern "C" int rs_restore(rs_handle h, const void *snap) {
     if (!h || !snap) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_idle(h));
     const Snapshot *S = (const Snapshot *)snap;
     size_t i = 0;
     for (int b : kSnapBufs) { if (h->bufs[b].bytes) HIPCHK(h, hipMemcpy(h->bufs[b].ptr, S->ptrs[i], h->bufs[b].bytes, hipMemcpyDeviceToDevice)); ++i; }

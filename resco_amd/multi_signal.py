@@ -20,7 +20,7 @@ from . import states as _states
 from .config.map_config import map_configs
 from .config.signal_config import signal_configs
 from .scenario import Scenario, compile_from_sumocfg
-from .sim import BatchedSim
+from .sim import BatchedSim, torch_stream
 from .traffic_signal import Phase, Signal
 
 try:  # gym is optional: only observation_space / action_space use it
@@ -323,13 +323,23 @@ class VecMultiSignal:
     def _pack(self):
         return ({n: self.tensor(n) for n in self.state_names}, {n: self.tensor(n) for n in self.reward_names})
 
+    def _stream(self, stream):
+        # the tensors handed out are consumed by torch kernels: launch on torch's current stream unless told otherwise
+        return torch_stream(self.sim.device) if stream is None else stream
+
     def reset(self, stream=None):
-        self.sim.reset(stream)
+        self.sim.reset(self._stream(stream))
         self.steps = 0
         return self._pack()[0]
 
+    def act_random(self, step_key, stream=None):
+        self.sim.act_random(step_key, self._stream(stream))
+
+    def act_maxwave(self, use_pressure, stream=None):
+        self.sim.act_maxwave(use_pressure, self._stream(stream))
+
     def step(self, actions=None, stream=None):
-        self.sim.step(actions, stream)
+        self.sim.step(actions, self._stream(stream))
         self.steps += 1
         obs, rew = self._pack()
         return obs, rew, self.steps >= self.horizon_steps, {'steps': self.steps}

@@ -67,6 +67,14 @@ def load_library():
     return L
 
 
+def torch_stream(device=None):
+    """The stream argument that orders a launch with PyTorch's current stream.  PyTorch's default stream has the
+    handle 0, which the C ABI reads as "the handle's own stream": it is mapped to hipStreamLegacy (1)."""
+    import torch
+    p = torch.cuda.current_stream(device).cuda_stream
+    return p if p else 1
+
+
 class _DevArray:
     """Zero-copy view of a library-owned device buffer (__cuda_array_interface__, also honoured on ROCm)."""
 

@@ -434,6 +434,47 @@ def test_zero_copy_tensors_at_the_agent_boundary():
     env.close()
 
 
+@pytest.mark.parametrize('side_stream', [False, True])
+def test_vec_env_is_ordered_with_torch_stream(side_stream):
+    """Actions produced by torch kernels and observations consumed by torch kernels need no host synchronisation:
+    VecMultiSignal launches on torch's current stream (the default stream is passed as hipStreamLegacy, because a
+    0 handle means 'the handle's own stream' in the C ABI).  An unsynchronised run must equal a fully
+    synchronised one."""
+    import torch
+    from resco_amd.multi_signal import VecMultiSignal
+    n, steps = 512, 30
+    results = []
+    for synced in (True, False):
+        env = VecMultiSignal('cologne3', n, states=('mplight',), rewards=('wait',), seed=11)
+        S = env.n_signals
+        nact = torch.as_tensor(env.n_actions, device='cuda')
+        gen = torch.Generator(device='cuda').manual_seed(5)
+        ctx = torch.cuda.stream(torch.cuda.Stream()) if (side_stream and not synced) else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            obs = env.reset()
+            acc = torch.zeros(n, S, device='cuda')
+            big = torch.randn(2048, 2048, device='cuda', generator=gen)
+            for k in range(steps):
+                if synced:
+                    torch.cuda.synchronize()
+                # a slow producer in front of the actions widens the window a race would need
+                slow = (big @ big).sum() * 0.0
+                u = torch.rand(n, S, device='cuda', generator=gen) + slow
+                a = torch.minimum((u * nact).long(), nact - 1).to(torch.int32)
+                if synced:
+                    torch.cuda.synchronize()
+                obs, rew, done, _ = env.step(a)
+                if synced:
+                    torch.cuda.synchronize()
+                acc += obs['mplight'].float().sum(-1) + rew['wait']        # consumer right behind the kernel
+            torch.cuda.current_stream().synchronize()
+        results.append((acc.cpu().numpy(), env.sim.read('mplight'), env.sim.stats()['inserted']))
+        env.close()
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    np.testing.assert_array_equal(results[0][1], results[1][1])
+    np.testing.assert_array_equal(results[0][2], results[1][2])
+
+
 def test_idqn_rollout_on_fp16_observations():
     """BASELINE config 5 interface: the batched IDQN consumes drq_norm_f16 directly; actions stay on device."""
     import torch
@@ -442,12 +483,11 @@ def test_idqn_rollout_on_fp16_observations():
     env = VecMultiSignal('ingolstadt21', 256, states=('drq_norm_f16', 'drq_norm'), rewards=('wait_norm',), seed=4)
     net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float16, device='cuda')
     mods = net.init_like_reference(seed=1)
-    stream = torch.cuda.current_stream().cuda_stream
-    obs = env.reset(stream)
+    obs = env.reset()               # launches ride torch's current stream: no explicit synchronisation needed
     for k in range(25):
         a = net.act(obs['drq_norm_f16'], epsilon=0.2)
         assert a.dtype == torch.int32 and a.is_cuda
-        obs, rew, done, _ = env.step(a, stream)
+        obs, rew, done, _ = env.step(a)
     torch.cuda.synchronize()
     # the fp16 padded tensor is the fp32 drq_norm re-laid out per signal
     sc = env.scenario

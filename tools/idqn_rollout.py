@@ -19,24 +19,23 @@ def main(n=1024, steps=360, dtype=torch.float16):
     env = VecMultiSignal('ingolstadt21', n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=0)
     net = BatchedIDQN.from_scenario(env.scenario, dtype=dtype, device='cuda')
     net.init_like_reference(seed=0)
-    stream = torch.cuda.current_stream().cuda_stream
     for _ in range(5):          # rocBLAS / allocator warm-up outside the timed regions
-        net.act(env.reset(stream)['drq_norm_f16'], epsilon=0.5)
+        net.act(env.reset()['drq_norm_f16'], epsilon=0.5)
     torch.cuda.synchronize()
     out = {}
     for mode in ('sim_only', 'sim_plus_policy'):
-        obs = env.reset(stream)['drq_norm_f16']
+        obs = env.reset()['drq_norm_f16']
         ret = torch.zeros(n, env.n_signals, device='cuda')
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
             if mode == 'sim_only':
-                env.sim.act_random(k, stream)
-                o, r, done, _ = env.step(None, stream)
+                env.act_random(k)
+                o, r, done, _ = env.step(None)
             else:
                 eps = max(0.0, 1.0 - k / (0.8 * steps))
                 a = net.act(obs, epsilon=eps)
-                o, r, done, _ = env.step(a, stream)
+                o, r, done, _ = env.step(a)
                 ret += r['wait_norm']
             obs = o['drq_norm_f16']
         torch.cuda.synchronize()

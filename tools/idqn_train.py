@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""IDQN training loop entirely on the GPU: HIP simulator -> fp16 observations -> batched Q-networks ->
+device replay ring -> batched DQN update.  Nothing crosses PCIe per step except the launch calls.
+
+    python tools/idqn_train.py [map] [n_envs] [episodes] [batch] [updates_per_step]
+
+Prints one JSON line per episode (mean episode return of rewards.wait_norm per signal, mean trip time loss of
+the vehicles that arrived, epsilon, env-steps/s including learning) and a final line comparing with the
+on-device random policy on the same demand.  Random-init weights, synthetic (rou.xml) demand."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from resco_amd.agents.idqn_learn import BatchedDQNLearner, DeviceReplay, linear_epsilon      # noqa: E402
+from resco_amd.agents.idqn_rollout import BatchedIDQN                                       # noqa: E402
+from resco_amd.multi_signal import VecMultiSignal                                           # noqa: E402
+
+
+def delay(env):
+    st = env.sim.stats()
+    arrived = max(1, int(st['arrived'].sum()))
+    return float(st['sum_time_loss_q10'].sum()) / 1024.0 / arrived, arrived / env.n_envs
+
+
+def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
+    env = VecMultiSignal(map_name, n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=0)
+    S, steps = env.n_signals, env.horizon_steps
+    net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
+    net.init_like_reference(seed=0)
+    learner = BatchedDQNLearner(net, gamma=0.99, lr=1e-3, target_update=500, batch_size=batch)
+    replay = DeviceReplay(min(2048, 4 * steps), n, S, net.lmax, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    decay = int(0.8 * episodes * steps)                 # the reference decays over config['steps'] agent steps
+
+    env.sim.set_seed(12345)                             # baseline: random policy on an evaluation demand seed
+    env.reset()
+    for k in range(steps):
+        env.act_random(k)
+        env.step(None)
+    rnd_delay, _ = delay(env)
+
+    for ep in range(episodes):
+        env.sim.set_seed(1000 + ep)
+        obs = env.reset()['drq_norm_f16']
+        ret = torch.zeros(n, S, device='cuda')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            eps = linear_epsilon(learner.t, 1.0, 0.0, decay)
+            a = net.act(obs, epsilon=eps, generator=gen)
+            replay.stage(obs)
+            o, r, done, _ = env.step(a)
+            rew = r['wait_norm']
+            replay.commit(a, rew, done)
+            ret += rew
+            learner.observe_step(replay, gen, updates)
+            obs = o['drq_norm_f16']
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        d, arrived = delay(env)
+        print(json.dumps(dict(episode=ep, epsilon=round(eps, 3), mean_return=float(ret.sum(1).mean()) / S,
+                              time_loss_s=round(d, 2), arrived_per_env=round(arrived, 1), updates=learner.n_updates,
+                              env_steps_per_s=round(n * steps / dt), ms_per_step=round(dt / steps * 1e3, 3))), flush=True)
+
+    env.sim.set_seed(12345)                             # greedy evaluation on the baseline's demand seed
+    obs = env.reset()['drq_norm_f16']
+    for k in range(steps):
+        o, _, _, _ = env.step(net.act(obs))
+        obs = o['drq_norm_f16']
+    g_delay, _ = delay(env)
+    print(json.dumps(dict(map=map_name, envs=n, episodes=episodes, batch=batch, updates_per_step=updates,
+                          greedy_time_loss_s=round(g_delay, 2), random_time_loss_s=round(rnd_delay, 2))))
+    env.close()
+
+
+if __name__ == '__main__':
+    a = sys.argv[1:]
+    main(a[0] if len(a) > 0 else 'cologne1', int(a[1]) if len(a) > 1 else 256, int(a[2]) if len(a) > 2 else 12,
+         int(a[3]) if len(a) > 3 else 256, int(a[4]) if len(a) > 4 else 1)
