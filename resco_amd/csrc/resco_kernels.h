@@ -92,7 +92,15 @@ struct KParams {
     int32_t do_fsm;         // apply prep_phase / set_phase around the ticks
     int32_t n_envs;
     unsigned long long *prof;   // optional [16] per-phase cycle accumulators (rs_phase_profile), NULL = off
+#ifdef RS_DIAG
+    int32_t diag;           // diagnostic builds only (tools/diag_phases.sh): bit mask of phase parts to skip
+#endif
 };
+#ifdef RS_DIAG
+#define DIAG_SKIP(bit_) (P.diag & (bit_))
+#else
+#define DIAG_SKIP(bit_) false
+#endif
 
 // ------------------------------------------------------------------------------------------------ device math
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -159,6 +167,7 @@ struct __attribute__((aligned(16))) LinkRec {
     uint8_t tls, tls_pos;                           // tls 0xFF: uncontrolled
     uint8_t foe_cnt, flags;                         // flags bit0 minor, bit1 cont, bit2 to_lane is internal (= via1)
     uint8_t dest_k, pad;                            // lane index of the destination lane inside to_edge
+    LaneRec dest;                                   // copy of lanes[to_lane]: one dependent gather less per hop
 };
 struct __attribute__((aligned(16))) FoeRec {
     int16_t arr_idx;
@@ -605,7 +614,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 if (L.lane[s] == LANE_PENDING) atomicMin(&L.dep[L.swait[s]], (int)L.node[s].trip);
         if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_NLC] = 0; }
         // P3: vehicles that will pass a link somebody may have to yield to register their arrival time
-        for (int s = tid; s < hw; s += B) {
+        for (int s = tid; s < hw && !DIAG_SKIP(1); s += B) {
             const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
             const int nlk = L.nlink[s];
@@ -670,64 +679,72 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (vl < vfree) vfree = vl;
             if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
             float vsafe = BIGF;
+            // The look-ahead only FINDS what limits the vehicle (a leader, or a stop line = a standing leader of
+            // zero length): the Krauss safe speed is evaluated once, by all lanes together, after the walk.
+            float tgap = 0.0f, tvl = 0.0f, tbl = b;
+            bool have = false;
             const int lead = leader_of(L, hc, LR.cell0, lane_cells(LR), x, k, s);
             bool found = false;
             if (lead != NIL) {
                 const float *vo = L.vtp + L.vt[lead] * VT_COLS;
-                float gap = L.node[lead].pos - vo[VT_LENGTH] - x - mingap;
-                vsafe = d_follow_speed(gap, L.speed[lead], b, vo[VT_DECEL], tau);
+                tgap = L.node[lead].pos - vo[VT_LENGTH] - x - mingap;
+                tvl = L.speed[lead]; tbl = vo[VT_DECEL];
+                have = true;
                 found = true;
             }
             const float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
             float seen = LR.len - x;
             int rq = L.rq[s];
             if (link == NLINK_NONE) link = -1;
-            for (int hop = 0; hop < MAX_HOPS && !found && seen < look; ++hop) {
-                const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
-                if (hop > 0) link = choose_link(T, LR, rq);
-                if (link < 0) {
-                    // last edge of the route: free run to its end; otherwise wrong lane: wait for a lane change
-                    if (!cur_int && T.rsteps[rq].next_edge == 0xFFFF) break;
-                    float g = seen - STOP_OFFSET;
-                    float vs = d_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
-                    if (vs < vsafe) vsafe = vs;
-                    break;
-                }
-                const LinkRec K = T.links[link];
-                const int st = tls_state(T, L, P, K.tls, K.tls_pos);
-                bool stop_here = false;
-                if (K.tls != 0xFF && (st == TLS_R || st == TLS_Y)) {
-                    if (seen >= d_brake_gap(v, b)) stop_here = true;
-                }
-                if (!stop_here && !(K.flags & KF_CONT) && K.foe_cnt > 0 && ((K.flags & KF_MINOR) || (K.tls != 0xFF && st == TLS_g))) {
-                    if (foe_blocked(T, L, hc, P, K)) stop_here = true;
-                }
-                if (stop_here) {
-                    float g = seen - STOP_OFFSET;
-                    float vs = d_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
-                    if (vs < vsafe) vsafe = vs;
-                    break;
-                }
-                const int nl = K.to_lane;
-                LR = T.lanes[nl];
-                {   // slow down in time for a lower speed limit on the next lane
-                    float vnl = LR.vmax * sf;
-                    if (vnl < vfree) {
-                        float vs = d_free_speed(seen, vnl, b);
-                        if (vs < vsafe) vsafe = vs;
+            if (!found && seen < look && !DIAG_SKIP(2)) {
+                const float bgv = d_brake_gap(v, b);        // can I still stop in front of a red / yellow light?
+                for (int hop = 0; hop < MAX_HOPS; ++hop) {
+                    const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
+                    if (hop > 0) link = choose_link(T, LR, rq);
+                    bool stop_here = false;
+                    LinkRec K;
+                    if (link < 0) {
+                        // last edge of the route: free run to its end; otherwise wrong lane: wait for a lane change
+                        if (!cur_int && T.rsteps[rq].next_edge == 0xFFFF) break;
+                        stop_here = true;
+                    } else {
+                        K = T.links[link];
+                        const int st = tls_state(T, L, P, K.tls, K.tls_pos);
+                        if (K.tls != 0xFF && (st == TLS_R || st == TLS_Y) && seen >= bgv) stop_here = true;
+                        if (!stop_here && !(K.flags & KF_CONT) && K.foe_cnt > 0 && ((K.flags & KF_MINOR) || (K.tls != 0xFF && st == TLS_g))) {
+                            if (!DIAG_SKIP(8) && foe_blocked(T, L, hc, P, K)) stop_here = true;
+                        }
                     }
+                    if (stop_here) {
+                        const float g = seen - STOP_OFFSET;
+                        tgap = g > 0.0f ? g : 0.0f; tvl = 0.0f; tbl = b;       // d_follow_speed(g, 0, b, b) == d_stop_speed(g, b)
+                        have = true;
+                        break;
+                    }
+                    LR = K.dest;
+                    {   // slow down in time for a lower speed limit on the next lane
+                        float vnl = LR.vmax * sf;
+                        if (vnl < vfree) {
+                            float vs = d_free_speed(seen, vnl, b);
+                            if (vs < vsafe) vsafe = vs;
+                        }
+                    }
+                    const int o = DIAG_SKIP(16) ? NIL : rearmost(L, hc, LR.cell0, lane_cells(LR));
+                    if (o != NIL) {
+                        const float *vo = L.vtp + L.vt[o] * VT_COLS;
+                        tgap = seen + L.node[o].pos - vo[VT_LENGTH] - mingap;
+                        tvl = L.speed[o]; tbl = vo[VT_DECEL];
+                        have = true;
+                        break;
+                    }
+                    if (!cur_int) rq += 1;
+                    seen += LR.len;
+                    if (!(seen < look) || DIAG_SKIP(32)) break;
                 }
-                const int o = rearmost(L, hc, LR.cell0, lane_cells(LR));
-                if (o != NIL) {
-                    const float *vo = L.vtp + L.vt[o] * VT_COLS;
-                    float gap = seen + L.node[o].pos - vo[VT_LENGTH] - mingap;
-                    float vs = d_follow_speed(gap, L.speed[o], b, vo[VT_DECEL], tau);
-                    if (vs < vsafe) vsafe = vs;
-                    found = true;
-                    break;
-                }
-                if (!cur_int) rq += 1;
-                seen += LR.len;
+            }
+            if (have) {
+                const float vs = d_follow_speed(tgap, tvl, b, tbl, tau);
+                if (vs < vsafe) vsafe = vs;
             }
             float vmin_n = v - b; if (vmin_n < 0.0f) vmin_n = 0.0f;
             float vmin_e = v - vt[VT_EMERGENCY]; if (vmin_e < 0.0f) vmin_e = 0.0f;
@@ -784,8 +801,11 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     }
                     x -= LR.len;
                     if (!li) rq += 1;
-                    lane = T.links[link].to_lane;
-                    LR = T.lanes[lane];
+                    {
+                        const LinkRec Km = T.links[link];
+                        lane = Km.to_lane;
+                        LR = Km.dest;
+                    }
                     moved = true;
                 }
                 if (arrived) {
@@ -823,7 +843,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         for (int s = tid; s < hw2; s += B) {
             int target = -1;
             const int lane = L.lane[s];
-            if (lane < LANE_PENDING) {
+            if (lane < LANE_PENDING && !DIAG_SKIP(4)) {
                 const LaneRec LR = T.lanes[lane];
                 const int n = LR.flags >> 2;
                 const int l0 = LR.edge_lane0;

@@ -21,6 +21,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <new>
@@ -223,6 +224,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
             R.flags = (uint8_t)((sc->link_minor[l] ? KF_MINOR : 0u) | (sc->link_cont[l] ? KF_CONT : 0u) | (sc->link_via1[l] >= 0 ? KF_VIA1 : 0u));
             R.dest_k = (uint8_t)(sc->link_dest_lane[l] - sc->edge_lane0[sc->link_to_edge[l]]);
             R.pad = 0;
+            R.dest = lanes[sc->link_to_lane[l]];
         }
         std::vector<FoeRec> foes((size_t)(sc->n_foes > 0 ? sc->n_foes : 1));
         for (int i = 0; i < sc->n_foes; ++i) {
@@ -408,6 +410,13 @@ extern "C" const char *rs_last_error(rs_handle h) { return h ? h->err.c_str() : 
 static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
     KParams P = h->P;
     P.n_ticks = n_ticks; P.do_fsm = do_fsm; P.prof = h->prof;
+#ifdef RS_DIAG
+    {   // skip mask applied only after RS_DIAG_AFTER launches, so that the traffic state is the real one
+        static int n_launch = 0;
+        const char *e = getenv("RS_DIAG_SKIP"), *a = getenv("RS_DIAG_AFTER");
+        P.diag = (e && ++n_launch > (a ? atoi(a) : 0)) ? atoi(e) : 0;
+    }
+#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         if (h->ev_used == h->events.size()) {
