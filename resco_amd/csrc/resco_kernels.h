@@ -476,6 +476,26 @@ __device__ __forceinline__ void set_phase(const KTab &T, Lds &L, const KParams &
     tls_refresh(T, L, P, s, ph);
 }
 
+// Preparation of a tick for slot s (P2b + P3): a pending trip bids for its departure lane (lowest trip wins);
+// a moving vehicle whose next link somebody may have to yield to registers its arrival time there.
+__device__ __forceinline__ void tick_prepare(const KTab &T, Lds &L, const KParams &P, int s) {
+    const int lane = L.lane[s];
+    if (lane == LANE_PENDING) { atomicMin(&L.dep[L.swait[s]], (int)L.node[s].trip); return; }
+    if (lane > LANE_PENDING || DIAG_SKIP(1)) return;
+    const int nlk = L.nlink[s];
+    if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
+    const float v = L.speed[s];
+    if (v <= HALT_SPEED) return;
+    const LinkRec K = T.links[nlk & 0x7FFF];
+    const int st = tls_state(T, L, P, K.tls, K.tls_pos);
+    if (st == TLS_R) return;
+    const float dist = T.lanes[lane].len - L.node[s].pos;
+    if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) return;
+    const float ta = dist / (v > 1.0f ? v : 1.0f);
+    const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
+    atomicMin(&L.arr[K.arr_idx], q);
+}
+
 // ------------------------------------------------------------------------------------------------ the step kernel
 // grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 1024).
 // __launch_bounds__(1024, 8): <= 64 VGPRs so that 32 waves (e.g. two 1024-thread workgroups) share a CU.
@@ -603,36 +623,20 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     }
     __syncthreads();
     PROF_MARK(1)
+    // ---- A: insertion candidates and approach registration of the first tick (later ticks prepare the next
+    //         one while they rebuild the lists, see F)
+    // time, high-water mark and "somebody waits for insertion" of the tick about to run.  They are read while
+    // nobody can change them (B decrements SC_NPEND): behind the barrier above / the one after E, and in front
+    // of the barrier that ends the preparation sweep - `pending` guards a __syncthreads and must be block-uniform.
+    int t = L.sc[SC_T], hw = L.sc[SC_HW];
+    bool pending = L.sc[SC_NPEND] > 0;
+    if (P.n_ticks > 0) {
+        for (int s = tid; s < hw; s += B) tick_prepare(T, L, P, s);
+        __syncthreads();
+    }
+    PROF_MARK(2)
 
     for (int tick = 0; tick < P.n_ticks; ++tick) {
-        const int t = L.sc[SC_T];
-        const int hw = L.sc[SC_HW];
-        const bool pending = L.sc[SC_NPEND] > 0;       // block-uniform
-        // ---- A: insertion candidates (lowest pending trip per departure lane) and approach registration
-        if (pending)
-            for (int s = tid; s < hw; s += B)
-                if (L.lane[s] == LANE_PENDING) atomicMin(&L.dep[L.swait[s]], (int)L.node[s].trip);
-        if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_NLC] = 0; }
-        // P3: vehicles that will pass a link somebody may have to yield to register their arrival time
-        for (int s = tid; s < hw && !DIAG_SKIP(1); s += B) {
-            const int lane = L.lane[s];
-            if (lane >= LANE_PENDING) continue;
-            const int nlk = L.nlink[s];
-            if (!(nlk & NLINK_ARR)) continue;       // nobody yields to my next link (or I have none)
-            const float v = L.speed[s];
-            if (v <= HALT_SPEED) continue;
-            const LinkRec K = T.links[nlk & 0x7FFF];
-            const int ai = K.arr_idx;
-            const int st = tls_state(T, L, P, K.tls, K.tls_pos);
-            if (st == TLS_R) continue;
-            const float dist = T.lanes[lane].len - L.node[s].pos;
-            if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) continue;
-            const float ta = dist / (v > 1.0f ? v : 1.0f);
-            const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
-            atomicMin(&L.arr[ai], q);
-        }
-        __syncthreads();
-        PROF_MARK(2)
         // ---- B: the candidate of each departure lane checks the space and inserts itself (P2c + P2d)
         if (pending) {
             for (int s = tid; s < hw; s += B) {
@@ -664,6 +668,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             PROF_MARK(3)
         }
         // ---- C: plan (Krauss car-following + links)
+        if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_NLC] = 0; }     // written again in D / E, behind barriers
         for (int s = tid; s < hw; s += B) {
             const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
@@ -909,7 +914,12 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         }
         __syncthreads();
         PROF_MARK(7)
-        // ---- F: only when somebody changes lane: apply, rebuild the lists
+        // ---- F: when somebody changes lane: apply, rebuild the lists; in the same sweep (or on its own when
+        //         nobody did) the next tick's insertion bids and approach registrations (P2b + P3)
+        const bool more = tick + 1 < P.n_ticks;
+        const int hwn = L.sc[SC_HW];        // hw2 + the slots allocated for the next tick
+        const int tn = L.sc[SC_T];
+        const bool pn = L.sc[SC_NPEND] > 0;
         if (L.sc[SC_NLC]) {
             heads_clear(hn, T.n_cells, tid, B);
             for (int s = tid; s < hw2; s += B) {
@@ -920,16 +930,21 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 }
             }
             __syncthreads();
-            for (int s = tid; s < hw2; s += B) {
+            for (int s = tid; s < hwn; s += B) {
                 const int ln = L.lane[s];
                 if (ln < LANE_PENDING) {
                     const LaneRec LRn = T.lanes[ln];
                     L.node[s].nxt = list_push(hn, LRn.cell0 + cell_of(L.node[s].pos, lane_cells(LRn)), s, L.speed[s] > HALT_SPEED);
                 }
+                if (more) tick_prepare(T, L, P, s);
             }
             __syncthreads();
-            PROF_MARK(8)
+        } else if (more) {
+            for (int s = tid; s < hwn; s += B) tick_prepare(T, L, P, s);
+            __syncthreads();
         }
+        t = tn; hw = hwn; pending = pn;
+        PROF_MARK(8)
     }
 #undef TLS_BEGIN_OF_TICK
 #undef ALLOCATE_SLOTS

@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """A kernel that never returns (e.g. a barrier reached by part of a workgroup) blocks inside
+    hipStreamSynchronize, where no Python-level timeout can fire: GPU tests get a hard per-test limit enforced
+    from a watchdog thread that ends the process (pytest-timeout, method 'thread')."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker('gpu') and not item.get_closest_marker('timeout'):
+            item.add_marker(pytest.mark.timeout(180, method='thread'))
+
+
 @pytest.fixture(scope='session')
 def root():
     return ROOT
