@@ -252,25 +252,33 @@ __host__ __device__ inline size_t lds_scratch_bytes(int C, int n_obs) {       //
     size_t a = (size_t)C * 4, b = align16((size_t)n_obs * 4) * 5;
     return a > b ? a : b;
 }
+// LDS layout.  The per-slot arrays, the scalars and the list heads come first: with the capacity a template
+// parameter of the step kernel their offsets are compile-time constants (DS immediate offsets, no SGPR each);
+// the arrays whose size depends on the scenario follow.
 __host__ __device__ inline size_t lds_bytes_for(int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
-    o += align16((size_t)C * 8);                     // node {pos, trip, nxt}
-    o += align16((size_t)C * 4) * 2;                 // speed tloss
+    o += (size_t)C * 8;                              // node {pos, trip, nxt}
+    o += (size_t)C * 4 * 2;                          // speed tloss
+    o += (size_t)C * 2 * 4;                          // lane rq swait nlink
+    o += (size_t)C;                                  // vt
+    o += align16((size_t)(SC_STATS + ST_N) * 4);     // scalars
+    o += align16((size_t)(n_cells + 2) * 2);         // head per list cell (u16, CAS on the containing dword)
     o += align16(lds_scratch_bytes(C, n_obs));       // vnx | aggregates
     o += align16((size_t)n_vt * VT_COLS * 4);        // vtype table
-    o += align16((size_t)C * 2) * 4;                 // lane rq swait nlink
-    o += align16((size_t)(n_cells + 2) * 2);         // head per list cell (u16, CAS on the containing dword)
-    o += align16((size_t)C);                         // vt
     o += align16((size_t)n_arr * 4);                 // approach registers
     o += align16((size_t)n_dep * 4);                 // insertion candidates
     o += align16((size_t)S * 4) * 3 + align16((size_t)S * tls_maxl);   // tls phase/left/next + link states
-    o += align16((size_t)(SC_STATS + ST_N) * 4);
     return o;
 }
 __device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
 #define CARVE(field, type, bytes) L.field = (type *)(base + o); o += align16(bytes);
     CARVE(node, Node, (size_t)C * 8) CARVE(speed, float, (size_t)C * 4) CARVE(tloss, float, (size_t)C * 4)
+    CARVE(lane, uint16_t, (size_t)C * 2)
+    CARVE(rq, uint16_t, (size_t)C * 2) CARVE(swait, uint16_t, (size_t)C * 2) CARVE(nlink, uint16_t, (size_t)C * 2)
+    CARVE(vt, uint8_t, (size_t)C)
+    CARVE(sc, int32_t, (size_t)(SC_STATS + ST_N) * 4)
+    CARVE(head, uint16_t, (size_t)(n_cells + 2) * 2)
     {   // the per-lane aggregates of the observe phase live where vnx was (dead by then)
         char *sb = base + o;
         L.vnx = (float *)sb;
@@ -280,14 +288,9 @@ __device__ __forceinline__ void lds_carve(Lds &L, char *base, int C, int n_cells
         o += align16(lds_scratch_bytes(C, n_obs));
     }
     CARVE(vtp, float, (size_t)n_vt * VT_COLS * 4)
-    CARVE(lane, uint16_t, (size_t)C * 2)
-    CARVE(rq, uint16_t, (size_t)C * 2) CARVE(swait, uint16_t, (size_t)C * 2) CARVE(nlink, uint16_t, (size_t)C * 2)
-    CARVE(head, uint16_t, (size_t)(n_cells + 2) * 2)
-    CARVE(vt, uint8_t, (size_t)C)
     CARVE(arr, int32_t, (size_t)n_arr * 4) CARVE(dep, int32_t, (size_t)n_dep * 4)
     CARVE(phase, int32_t, (size_t)S * 4) CARVE(left, int32_t, (size_t)S * 4) CARVE(nextp, int32_t, (size_t)S * 4)
     CARVE(tstate, uint8_t, (size_t)S * tls_maxl)
-    CARVE(sc, int32_t, (size_t)(SC_STATS + ST_N) * 4)
 #undef CARVE
 }
 
@@ -499,13 +502,15 @@ __device__ __forceinline__ void tick_prepare(const KTab &T, Lds &L, const KParam
 // ------------------------------------------------------------------------------------------------ the step kernel
 // grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 1024).
 // __launch_bounds__(1024, 8): <= 64 VGPRs so that 32 waves (e.g. two 1024-thread workgroups) share a CU.
-extern "C" __global__ void __launch_bounds__(1024, 8)
+// CAP: the slot capacity as a compile-time constant (0: read it from the tables at run time)
+template <int CAP>
+__global__ void __launch_bounds__(1024, 8)
 rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int env = blockIdx.x;
     if (env >= P.n_envs) return;
     const int tid = threadIdx.x, B = blockDim.x;
-    const int C = T.capacity, S = T.n_signals, NO = T.n_obs;
+    const int C = CAP ? CAP : T.capacity, S = T.n_signals, NO = T.n_obs;
     const int genv = P.env_base + env;
     Lds L;
     lds_carve(L, smem, C, T.n_cells, T.n_arr, T.n_dep, NO, S, T.n_vtypes, T.tls_maxl);

@@ -115,6 +115,20 @@ static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_
     B.bytes = (size_t)(a * b * c * d) * kDtypeSize[dtype];
 }
 
+// the step kernel is instantiated for the capacities compile_scenario produces (constant LDS offsets); any other
+// capacity runs the generic instantiation
+typedef void (*step_kernel_fn)(KTab, State, Out, KParams, const int32_t *);
+static const int kStepCaps[] = {0, 128, 256, 512, 1024};
+static step_kernel_fn step_kernel_for(int capacity) {
+    switch (capacity) {
+        case 128: return rs_step_kernel<128>;
+        case 256: return rs_step_kernel<256>;
+        case 512: return rs_step_kernel<512>;
+        case 1024: return rs_step_kernel<1024>;
+        default: return rs_step_kernel<0>;
+    }
+}
+
 // every synchronous entry point waits for the handle's own stream AND the caller stream of the last launch
 static hipError_t wait_idle(rs_sim *h) {
     hipError_t e = hipStreamSynchronize(h->stream);
@@ -383,9 +397,10 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         std::lock_guard<std::mutex> lock(mu);
         size_t &cur = max_lds[device_id & 63];
         if (h->lds > cur) {
-            if (hipFuncSetAttribute((const void *)rs_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
-                h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
-            }
+            for (int c : kStepCaps)        // every instantiation: the ceiling is per kernel function
+                if (hipFuncSetAttribute((const void *)step_kernel_for(c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+                    h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
+                }
             cur = h->lds;
         }
     }
@@ -429,7 +444,7 @@ static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
         h->ev_used += 1;
         HIPCHK(h, hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(rs_step_kernel, dim3(h->n_envs), dim3(h->block), h->lds, st, h->K, h->G, h->O, P, (const int32_t *)h->actions);
+    hipLaunchKernelGGL(step_kernel_for(h->K.capacity), dim3(h->n_envs), dim3(h->block), h->lds, st, h->K, h->G, h->O, P, (const int32_t *)h->actions);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     return RS_OK;
