@@ -319,6 +319,48 @@ def test_gymma_list_api_and_custom_state_fn():
     env.close()
 
 
+def test_sampled_envs_bit_exact_at_full_occupancy():
+    """BASELINE config 3 launch shape (4096 workgroups, 4 resident per CU): eight sampled environments stay
+    bit-identical to the CPU oracle for 40 env-steps of the on-device random policy.  Few-environment parity runs
+    leave most of the chip idle and do not exercise the timing that exposes intra-workgroup races."""
+    from oracle.pyoracle import OracleEnv
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('ingolstadt21')
+    N, base = 4096, 1000
+    picks = [0, 1, 63, 511, 2048, 3000, 4094, 4095]
+    sim = BatchedSim(sc, N, seed=9, env_base=base)
+    orcs = [OracleEnv(sc, env_index=base + e, seed=9, sigma=-1.0, speed_dev=1) for e in picks]
+    for o in orcs:
+        o.observe()
+    names = INT_BUFS + FLT_BUFS
+    for step in range(40):
+        sim.act_random(step)
+        acts = sim.read('actions')                  # the hashed U{0..G_s-1} actions the kernel is about to use
+        sim.step(None)
+        for e, o in zip(picks, orcs):
+            o.step(acts[e])
+        if step % 13 == 0 or step == 39:
+            out = {b: sim.read(b) for b in names}
+            vg = {g: sim.read(g) for g in ('veh_lane', 'veh_pos', 'veh_speed', 'veh_trip')}
+            env = sim.read('env')
+            for e, o in zip(picks, orcs):
+                ref = o.outputs()
+                for b in names:
+                    np.testing.assert_array_equal(out[b][e], ref[b], err_msg='%s env %d step %d' % (b, e, step))
+                vo = o.vehicles()
+                hw = vo['hw']
+                assert env[e, 2] == hw and env[e, 1] == vo['next_trip'] and env[e, 0] == o.time
+                used = vo['lane'][:hw] != 0xFFFF
+                np.testing.assert_array_equal(vg['veh_lane'][e][:hw], vo['lane'][:hw])
+                np.testing.assert_array_equal(vg['veh_pos'][e][:hw][used], vo['pos'][:hw][used])
+                np.testing.assert_array_equal(vg['veh_speed'][e][:hw][used], vo['speed'][:hw][used])
+    st = sim.stats()
+    for e, o in zip(picks, orcs):
+        so = o.stats()
+        assert st['inserted'][e] == so['inserted'] and st['arrived'][e] == so['arrived']
+    sim.close()
+
+
 def test_properties_at_baseline_size():
     """BASELINE config 3 size: ingolstadt21 x 4096 lock-step environments, on-device random policy."""
     from resco_amd.sim import BatchedSim
@@ -502,4 +544,41 @@ def test_idqn_rollout_on_fp16_observations():
     ref = mods[s](torch.from_numpy(h[:, s, :L]).unsqueeze(1))
     np.testing.assert_allclose(q[:, s, :A].detach().numpy(), ref.detach().numpy(), rtol=5e-2, atol=5e-2)
     assert float(rew['wait_norm'].min()) >= -4.0
+    env.close()
+
+
+def test_idqn_training_loop_on_device():
+    """Replay ring + batched DQN update driven by the simulator's zero-copy tensors (tools/idqn_train.py in
+    small): transitions land in the ring as the kernel produced them, the update runs and changes the weights."""
+    import torch
+    from resco_amd.agents.idqn_learn import BatchedDQNLearner, DeviceReplay
+    from resco_amd.agents.idqn_rollout import BatchedIDQN
+    from resco_amd.multi_signal import VecMultiSignal
+    n = 64
+    env = VecMultiSignal('cologne3', n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=2)
+    net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
+    net.init_like_reference(seed=0)
+    w0 = net.fc3_w.detach().clone()
+    learner = BatchedDQNLearner(net, batch_size=32, target_update=10)
+    replay = DeviceReplay(16, n, env.n_signals, net.lmax, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    obs = env.reset()['drq_norm_f16']
+    seen = []
+    for k in range(24):
+        a = net.act(obs, epsilon=0.5, generator=gen)
+        replay.stage(obs)
+        o, r, done, _ = env.step(a)
+        replay.commit(a, r['wait_norm'], done)
+        seen.append((o['drq_norm_f16'].clone(), a.clone(), r['wait_norm'].clone()))
+        loss = learner.observe_step(replay, gen)
+        obs = o['drq_norm_f16']
+    torch.cuda.synchronize()
+    assert learner.n_updates == 23 and torch.isfinite(loss)
+    assert not torch.equal(w0, net.fc3_w.detach())
+    # the ring holds the last 16 steps; slot (k mod 16) = what the agents saw / did / got at step k
+    for k in (8, 15, 23):
+        i = k % 16
+        assert torch.equal(replay.act[i].int(), seen[k][1]) and torch.equal(replay.rew[i], seen[k][2])
+        assert torch.equal(replay.obs[(i + 1) % 16] if k < 23 else seen[k][0], seen[k][0])      # successor obs
+    assert float(replay.rew.min()) >= -4.0 and float(replay.rew.max()) <= 0.0
     env.close()
