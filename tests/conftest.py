@@ -8,7 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
-HOT_CASES = ['cologne1_d200', 'cologne8_d200', 'cologne8_d50', 'ingolstadt21_d200']
+HOT_CASES = ['cologne1_d200', 'cologne8_d200', 'cologne8_d50', 'ingolstadt21_d200', 'cologne3_d200',
+             'ingolstadt7_d200', 'ingolstadt1_d200']
 
 
 def pytest_configure(config):

@@ -24,6 +24,7 @@ from resco_amd.config.map_config import map_configs              # noqa: E402
 BASE_SEED = 7
 CASES = [  # (map, steps, max_distance)
     ('cologne1', 48, 200), ('cologne8', 40, 200), ('cologne8', 24, 50), ('ingolstadt21', 30, 200),
+    ('cologne3', 36, 200), ('ingolstadt7', 30, 200), ('ingolstadt1', 40, 200),
 ]
 STATE_FNS = ['drq', 'drq_norm', 'mplight', 'mplight_full', 'wave']
 REWARD_FNS = ['wait', 'wait_norm', 'pressure']
