@@ -96,6 +96,13 @@ struct KParams {
     int32_t diag;           // diagnostic builds only (tools/diag_phases.sh): bit mask of phase parts to skip
 #endif
 };
+#ifdef RS_COUNT
+// event counters of a -DRS_COUNT build (tools/count_events.sh): printed by rs_destroy
+__device__ unsigned long long g_count[32];
+#define COUNT(i_, n_) atomicAdd(&g_count[i_], (unsigned long long)(n_))
+#else
+#define COUNT(i_, n_)
+#endif
 #ifdef RS_DIAG
 #define DIAG_SKIP(bit_) (P.diag & (bit_))
 #else
@@ -316,7 +323,9 @@ __device__ __forceinline__ uint16_t list_push(uint16_t *head, int lane, int s, b
     const int sh = (lane & 1) * 16;
     const uint32_t flag = mover ? 0x8000u : 0u;
     uint32_t old = *w, assumed;
+    COUNT(9, 1);
     do {
+        COUNT(10, 1);
         assumed = old;
         const uint32_t keep = (assumed >> sh) & 0x8000u;          // sticky mover flag of the lane
         old = atomicCAS(w, assumed, (assumed & ~(0xFFFFu << sh)) | (((uint32_t)s | keep | flag) << sh));
@@ -337,6 +346,7 @@ __device__ __forceinline__ int choose_link(const KTab &T, const LaneRec &LR, int
     int best = -1, any = -1;
     for (int l = ls; l < ls + lc; ++l) {
         const LinkRec K = T.links[l];
+        COUNT(15, 1);
         if (K.to_edge != R.next_edge) continue;
         if ((R.next_mask2 >> K.dest_k) & 1u) return l;
         if (best < 0 && ((R.next_mask1 >> K.dest_k) & 1u)) best = l;
@@ -377,7 +387,9 @@ __device__ __forceinline__ int cell_of(float pos, int ncell) { const int c = (in
 
 // rear-most vehicle of a lane (min pos, ties -> larger trip index): the first non-empty cell holds it
 __device__ __forceinline__ int rearmost(const Lds &L, const uint16_t *head, int cell0, int ncell) {
+    COUNT(4, 1);
     for (int c = 0; c < ncell; ++c) {
+        COUNT(5, 1);
         int s = head[cell0 + c] & 0x7FFF;
         if (s == NIL) continue;
         int best = NIL, bk = 0;
@@ -387,6 +399,7 @@ __device__ __forceinline__ int rearmost(const Lds &L, const uint16_t *head, int 
             const int k = nd.trip;
             const float p = nd.pos;
             if (best == NIL || p < bp || (p == bp && k > bk)) { best = s; bk = k; bp = p; }
+            COUNT(6, 1);
             s = nd.nxt;
         }
         return best;
@@ -399,16 +412,20 @@ __device__ __forceinline__ int leader_of(const Lds &L, const uint16_t *head, int
     int Ld = NIL, Lk = 0;
     float Lp = 0.0f;
     int c = cell_of(pos, ncell);
+    COUNT(0, 1);
     for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
         const Node nd = L.node[s];
         const int cur = s;
+        COUNT(1, 1);
         s = nd.nxt;
         if (cur == self) continue;
         if (ahead_of(nd.pos, nd.trip, pos, k) && (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip))) { Ld = cur; Lk = nd.trip; Lp = nd.pos; }
     }
     for (c += 1; Ld == NIL && c < ncell; ++c) {
+        COUNT(2, 1);
         for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
             const Node nd = L.node[s];
+            COUNT(3, 1);
             if (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip)) { Ld = s; Lk = nd.trip; Lp = nd.pos; }
             s = nd.nxt;
         }
@@ -421,9 +438,11 @@ __device__ __forceinline__ void neighbours(const Lds &L, const uint16_t *head, i
     int Ld = NIL, Fd = NIL, Lk = 0, Fk = 0;
     float Lp = 0.0f, Fp = 0.0f;
     const int c0 = cell_of(pos, ncell);
+    COUNT(7, 1);
     for (int s = head[cell0 + c0] & 0x7FFF; s != NIL;) {
         const Node nd = L.node[s];
         const int cur = s;
+        COUNT(8, 1);
         s = nd.nxt;
         if (cur == self) continue;
         const int ks = nd.trip;
@@ -437,12 +456,14 @@ __device__ __forceinline__ void neighbours(const Lds &L, const uint16_t *head, i
     for (int c = c0 + 1; Ld == NIL && c < ncell; ++c)
         for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
             const Node nd = L.node[s];
+            COUNT(8, 1);
             if (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip)) { Ld = s; Lk = nd.trip; Lp = nd.pos; }
             s = nd.nxt;
         }
     for (int c = c0 - 1; Fd == NIL && c >= 0; --c)
         for (int s = head[cell0 + c] & 0x7FFF; s != NIL;) {
             const Node nd = L.node[s];
+            COUNT(8, 1);
             if (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk)) { Fd = s; Fk = nd.trip; Fp = nd.pos; }
             s = nd.nxt;
         }
@@ -450,13 +471,14 @@ __device__ __forceinline__ void neighbours(const Lds &L, const uint16_t *head, i
 }
 
 __device__ __forceinline__ bool cells_have_mover(const uint16_t *head, int cell0, int nc) {
-    for (int c = 0; c < nc; ++c) if (head[cell0 + c] & 0x8000) return true;
+    for (int c = 0; c < nc; ++c) { COUNT(13, 1); if (head[cell0 + c] & 0x8000) return true; }
     return false;
 }
 
 __device__ __forceinline__ bool foe_blocked(const KTab &T, const Lds &L, const uint16_t *head, const KParams &P, const LinkRec &K) {
     for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
         const FoeRec F = T.foes[i];
+        COUNT(12, 1);
         if (F.tls != 0xFF && tls_state(T, L, P, F.tls, F.tls_pos) == TLS_R) continue;
         if (F.arr_idx >= 0 && L.arr[F.arr_idx] < FOE_GAP_Q) return true;
         if (F.via1_cell0 != 0xFFFF && cells_have_mover(head, F.via1_cell0, F.via1_nc)) return true;   // a moving vehicle on
@@ -678,6 +700,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             const int lane = L.lane[s];
             if (lane >= LANE_PENDING) continue;
             const int k = L.node[s].trip;
+            COUNT(17, 1);
             const float *vt = L.vtp + L.vt[s] * VT_COLS;
             const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
             const float v = L.speed[s], x = L.node[s].pos;
@@ -707,8 +730,10 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             int rq = L.rq[s];
             if (link == NLINK_NONE) link = -1;
             if (!found && seen < look && !DIAG_SKIP(2)) {
+                COUNT(18, 1);
                 const float bgv = d_brake_gap(v, b);        // can I still stop in front of a red / yellow light?
                 for (int hop = 0; hop < MAX_HOPS; ++hop) {
+                    COUNT(11, 1);
                     const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
                     if (hop > 0) link = choose_link(T, LR, rq);
                     bool stop_here = false;
@@ -803,6 +828,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 bool arrived = false, moved = false;
                 for (int it = 0; it < 16; ++it) {
                     if (!(x > LR.len)) break;
+                    COUNT(14, 1);
                     const bool li = (LR.flags & LF_INTERNAL) != 0;
                     if (moved) link = choose_link(T, LR, rq);
                     if (link < 0) {
@@ -889,6 +915,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                         }
                     }
                     if (want) {
+                        COUNT(16, 1);
                         const bool urgent = want == 2 && (lane_len - x) <= URGENT_DIST;
                         bool safe = true;
                         if (lead_t != NIL) {

@@ -414,6 +414,19 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
 extern "C" void rs_destroy(rs_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+#ifdef RS_COUNT
+    {
+        unsigned long long c[32];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_count), sizeof(c)) == hipSuccess) {
+            static const char *nm[] = {"leader_of calls", "leader_of own-cell nodes", "leader_of further cells", "leader_of further nodes", "rearmost calls",
+                                       "rearmost cells", "rearmost nodes", "neighbours calls", "neighbours nodes", "list_push calls", "list_push CAS rounds",
+                                       "hop iterations", "foe records", "mover-flag cells", "move lane hand-overs", "choose_link records", "lane-change candidates",
+                                       "vehicle-ticks (plan)", "vehicles entering the hop loop"};
+            for (int i = 0; i < 19; ++i) fprintf(stderr, "RS_COUNT %-32s %llu\n", nm[i], c[i]);
+        }
+    }
+#endif
     if (h->stream) { (void)wait_idle(h); (void)hipStreamDestroy(h->stream); }
     for (auto &e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void *p : h->allocs) (void)hipFree(p);
