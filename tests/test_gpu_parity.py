@@ -361,6 +361,42 @@ def test_sampled_envs_bit_exact_at_full_occupancy():
     sim.close()
 
 
+def test_full_episode_invariants_at_baseline_size():
+    """One whole 360-step episode of BASELINE config 3 (4096 envs, on-device random policy): every environment
+    ends at t = 3600 with its vehicles conserved, inside their lanes, and with the episode totals consistent."""
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('ingolstadt21')
+    N = 4096
+    sim = BatchedSim(sc, N, seed=21)
+    prev_arrived = np.zeros(N, np.int64)
+    for k in range(360):
+        sim.act_random(k)
+        sim.step(None)
+        if k in (119, 239, 359):
+            st = sim.stats()
+            env = sim.read('env')
+            assert (env[:, 0] == 10 * (k + 1)).all()
+            assert (st['inserted'] == st['arrived'] + st['active']).all()
+            assert (env[:, 1] == st['inserted'] + st['pending']).all() and (env[:, 1] <= sc.n_trips).all()
+            assert (st['arrived'] >= prev_arrived).all()
+            prev_arrived = st['arrived'].copy()
+            lane, pos, spd = sim.read('veh_lane'), sim.read('veh_pos'), sim.read('veh_speed')
+            act = lane < 0xFFFE
+            assert (act.sum(axis=1) == st['active']).all() and (st['active'] <= sc.capacity).all()
+            assert (pos[act] >= 0).all() and (pos[act] <= sc.lane_len[lane[act]] + 1e-3).all()
+            assert (spd[act] >= 0).all() and (spd[act] <= 60.0).all()
+            trip = sim.read('veh_trip')
+            for e in (0, 1777, 4095):                  # a trip occupies at most one slot
+                t_e = trip[e][lane[e] != 0xFFFF]
+                assert len(np.unique(t_e)) == len(t_e)
+    st = sim.stats()
+    assert (st['ticks'] == 3600).all()
+    assert (st['sum_duration'] >= st['sum_time_loss_q10'] // 1024).all()       # time loss <= travel time
+    assert (st['sum_waiting'] <= st['active_ticks']).all()
+    assert st['arrived'].min() > 1000 and len(np.unique(st['arrived'])) > 100   # traffic flows; envs decorrelate
+    sim.close()
+
+
 def test_properties_at_baseline_size():
     """BASELINE config 3 size: ingolstadt21 x 4096 lock-step environments, on-device random policy."""
     from resco_amd.sim import BatchedSim
