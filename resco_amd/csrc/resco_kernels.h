@@ -103,6 +103,14 @@ __device__ unsigned long long g_count[32];
 #else
 #define COUNT(i_, n_)
 #endif
+#ifdef RS_BARWAIT
+// -DRS_BARWAIT build (tools/count_events.sh): time every wave spends inside the barriers of the step kernel
+__device__ unsigned long long g_bar[64];    // [0] barrier wait, [1] wave lifetime (wall_clock64 ticks), [2] barriers, [8 + k] wait at the barrier of source line k (see g_bar_line)
+__device__ int g_bar_line[56];
+#define SYNC() { constexpr int site_ = __COUNTER__; const unsigned long long a_ = wall_clock64(); __syncthreads(); if ((threadIdx.x & 63) == 0) { const unsigned long long w_ = wall_clock64() - a_; atomicAdd(&g_bar[0], w_); atomicAdd(&g_bar[2], 1ull); atomicAdd(&g_bar[8 + (site_ & 31)], w_); g_bar_line[site_ & 31] = __LINE__; } }
+#else
+#define SYNC() __syncthreads()
+#endif
 #ifdef RS_DIAG
 #define DIAG_SKIP(bit_) (P.diag & (bit_))
 #else
@@ -537,6 +545,9 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     Lds L;
     lds_carve(L, smem, C, T.n_cells, T.n_arr, T.n_dep, NO, S, T.n_vtypes, T.tls_maxl);
     unsigned long long pt_ = 0;
+#ifdef RS_BARWAIT
+    const unsigned long long born_ = wall_clock64();
+#endif
 #define PROF_START() if (P.prof && tid == 0) pt_ = wall_clock64();
 #define PROF_MARK(i_) if (P.prof && tid == 0) { unsigned long long n_ = wall_clock64(); atomicAdd(&P.prof[i_], n_ - pt_); pt_ = n_; }
     PROF_START()
@@ -557,7 +568,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         L.nextp[i] = G.tls[(env * S + i) * 3 + 2];
         tls_refresh(T, L, P, i, ph);
     }
-    __syncthreads();
+    SYNC();
     {
         const int hw0 = L.sc[SC_HW];
         int npend = 0;
@@ -583,7 +594,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         }
         if (npend) atomicAdd(&L.sc[SC_NPEND], npend);
     }
-    __syncthreads();
+    SYNC();
     PROF_MARK(0)
 
 // TLS switch events at the beginning of a tick (P0), preceded by Signal.set_phase when the yellow ticks are over
@@ -648,7 +659,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         TLS_BEGIN_OF_TICK(0)
         ALLOCATE_SLOTS(L.sc[SC_T])
     }
-    __syncthreads();
+    SYNC();
     PROF_MARK(1)
     // ---- A: insertion candidates and approach registration of the first tick (later ticks prepare the next
     //         one while they rebuild the lists, see F)
@@ -659,7 +670,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
     bool pending = L.sc[SC_NPEND] > 0;
     if (P.n_ticks > 0) {
         for (int s = tid; s < hw; s += B) tick_prepare(T, L, P, s);
-        __syncthreads();
+        SYNC();
     }
     PROF_MARK(2)
 
@@ -691,7 +702,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 atomicAdd(&L.sc[SC_STATS + ST_DEPDELAY], t - 1 - sched);
                 atomicSub(&L.sc[SC_NPEND], 1);
             }
-            __syncthreads();
+            SYNC();
             PROF_MARK(3)
         }
         // ---- C: plan (Krauss car-following + links)
@@ -796,11 +807,11 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             }
             L.vnx[s] = vd > vmin ? vd : vmin;
         }
-        __syncthreads();
+        SYNC();
         PROF_MARK(4)
         heads_clear(L.head, T.n_cells, tid, B);     // nobody reads the lists between plan and move
         for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;     // ... nor this tick's approach registrations
-        __syncthreads();
+        SYNC();
         PROF_MARK(5)
         // ---- D: move; drop this tick's approach registrations; build the lists of the moved state
         {
@@ -870,7 +881,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (halted) atomicAdd(&L.sc[SC_STATS + ST_WAITING], halted);
             if (top) atomicMax(&L.sc[SC_HWNEW], top);
         }
-        __syncthreads();
+        SYNC();
         PROF_MARK(6)
         // ---- E: lane-change decisions on the moved state (all changes of a tick go the same way: left on even
         //         ticks); the next tick's TLS events and slot allocation are prepared in the same phase
@@ -944,7 +955,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             TLS_BEGIN_OF_TICK(tick + 1)
             ALLOCATE_SLOTS(t + 1)       // wave 0; tid 0 has just published hw2 (same wave, program order)
         }
-        __syncthreads();
+        SYNC();
         PROF_MARK(7)
         // ---- F: when somebody changes lane: apply, rebuild the lists; in the same sweep (or on its own when
         //         nobody did) the next tick's insertion bids and approach registrations (P2b + P3)
@@ -961,7 +972,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     L.nlink[s] = cache_link(T, T.lanes[target], L.rq[s]);
                 }
             }
-            __syncthreads();
+            SYNC();
             for (int s = tid; s < hwn; s += B) {
                 const int ln = L.lane[s];
                 if (ln < LANE_PENDING) {
@@ -970,10 +981,10 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 }
                 if (more) tick_prepare(T, L, P, s);
             }
-            __syncthreads();
+            SYNC();
         } else if (more) {
             for (int s = tid; s < hwn; s += B) tick_prepare(T, L, P, s);
-            __syncthreads();
+            SYNC();
         }
         t = tn; hw = hwn; pending = pn;
         PROF_MARK(8)
@@ -983,7 +994,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
 
     // ---- Signal.observe for every signal (traffic_signal.py:189-247)
     for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
-    __syncthreads();
+    SYNC();
     const int hwf = L.sc[SC_HW];
     {
         const int hw0 = G.env[env * 4 + 2];
@@ -1025,7 +1036,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         if (act) atomicAdd(&L.sc[SC_STATS + ST_ACTIVE], act);
         if (pend) atomicAdd(&L.sc[SC_STATS + ST_PENDING], pend);
     }
-    __syncthreads();
+    SYNC();
     PROF_MARK(9)
     // per observed lane rows, written as flat coalesced streams (element i of [n_obs][5] / [S][Lmax][5])
     for (int i = tid; i < NO * 5; i += B) {
@@ -1088,7 +1099,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         G.tls[(env * S + sg) * 3 + 1] = L.left[sg];
         G.tls[(env * S + sg) * 3 + 2] = L.nextp[sg];
     }
-    __syncthreads();
+    SYNC();
     PROF_MARK(10)
     if (tid < 3) G.env[env * 4 + tid] = L.sc[tid];
     if (tid < ST_N) {
@@ -1096,6 +1107,9 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
         if (tid == ST_ACTIVE || tid == ST_PENDING) st[tid] = L.sc[SC_STATS + tid];
         else st[tid] += L.sc[SC_STATS + tid];
     }
+#ifdef RS_BARWAIT
+    if ((tid & 63) == 0) atomicAdd(&g_bar[1], wall_clock64() - born_);
+#endif
 }
 
 // reset every environment: no vehicles, TLS programs freshly installed (Signal.__init__, traffic_signal.py:93-100)

@@ -414,6 +414,17 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
 extern "C" void rs_destroy(rs_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+#ifdef RS_BARWAIT
+    {
+        unsigned long long b[64];
+        int ln[56];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(b, HIP_SYMBOL(g_bar), sizeof(b)) == hipSuccess && hipMemcpyFromSymbol(ln, HIP_SYMBOL(g_bar_line), sizeof(ln)) == hipSuccess) {
+            fprintf(stderr, "RS_BARWAIT barrier wait %llu  wave lifetime %llu  (%.1f %%)  barriers per wave %llu\n", b[0], b[1], 100.0 * (double)b[0] / (double)(b[1] ? b[1] : 1), b[2]);
+            for (int i = 0; i < 32; ++i) if (b[8 + i]) fprintf(stderr, "RS_BARWAIT   barrier at resco_kernels.h:%d  %.1f %% of the wave lifetime\n", ln[i], 100.0 * (double)b[8 + i] / (double)(b[1] ? b[1] : 1));
+        }
+    }
+#endif
 #ifdef RS_COUNT
     {
         unsigned long long c[32];
