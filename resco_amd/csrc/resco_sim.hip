@@ -177,7 +177,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     for (int s = 0; s < sc->n_signals; ++s) if (sc->tls_nlinks[s] > tls_maxl) tls_maxl = sc->tls_nlinks[s];
     // ---- packed 16-byte records for the step kernel
     {
-        if (sc->n_route_steps >= 0xFFFF || sc->n_foes >= 0xFFFF || sc->n_links >= 0xFFFF || sc->n_edges >= 0xFFFF || sc->n_obs >= 0x7FFF) {
+        if (sc->n_route_steps >= 0xFFFF || sc->n_foes >= 0xFFFF || sc->n_links >= 0x7FFF || sc->n_edges >= 0xFFFF || sc->n_obs >= 0x7FFF) {
             h->err = "scenario exceeds packed-table id widths (route steps / foes / links / edges u16)"; return fail(RS_ELIMIT);
         }
         std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
