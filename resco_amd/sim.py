@@ -201,6 +201,22 @@ class BatchedSim:
     def time(self):
         return self.read('env')[:, 0]
 
+    def trip_delay(self):
+        """Per-environment average trip delay as the reference's post-processing defines it (utils/readXML.py:
+        timeLoss + departDelay per tripinfo entry, unfinished trips included as tripinfo-output.write-unfinished
+        writes them): (time loss of arrived and of still-running vehicles + insertion delays + the waiting of trips
+        still queued for insertion) / (inserted + queued trips)."""
+        st = self.stats()
+        lane, trip = self.read('veh_lane'), self.read('veh_trip')
+        running = (self.read('veh_tloss') * (lane < 0xFFFE)).sum(axis=1)
+        # trips that were due but never got onto the network wait since their scheduled departure
+        # (readXML.py:52-68 charges end_time - depart for them and counts them as trips)
+        pend = lane == 0xFFFE
+        sched = np.asarray(self.sc.arrays['trip_depart'])[np.where(pend, trip, 0).astype(np.int64)]
+        waited = (np.maximum(0, self.time()[:, None] - sched) * pend).sum(axis=1)
+        trips = st['inserted'] + pend.sum(axis=1)
+        return (st['sum_time_loss_q10'] / 1024.0 + running + st['sum_depart_delay'] + waited) / np.maximum(1, trips)
+
     # ------------------------------------------------------------------ snapshots / timing
     def snapshot(self):
         snap = C.c_void_p()

@@ -4,8 +4,8 @@ device replay ring -> batched DQN update.  Nothing crosses PCIe per step except 
 
     python tools/idqn_train.py [map] [n_envs] [episodes] [batch] [updates_per_step]
 
-Prints one JSON line per episode (mean episode return of rewards.wait_norm per signal, mean trip time loss of
-the vehicles that arrived, epsilon, env-steps/s including learning) and a final line comparing with the
+Prints one JSON line per episode (mean episode return of rewards.wait_norm per signal, average trip delay as
+utils/readXML.py computes it, epsilon, env-steps/s including learning) and a final line comparing with the
 on-device random policy on the same demand.  Random-init weights, synthetic (rou.xml) demand."""
 import json
 import os
@@ -22,9 +22,8 @@ from resco_amd.multi_signal import VecMultiSignal                               
 
 
 def delay(env):
-    st = env.sim.stats()
-    arrived = max(1, int(st['arrived'].sum()))
-    return float(st['sum_time_loss_q10'].sum()) / 1024.0 / arrived, arrived / env.n_envs
+    """Mean over the environments of utils/readXML.py's episode figure (timeLoss + departDelay per trip)."""
+    return float(env.sim.trip_delay().mean()), float(env.sim.stats()['arrived'].mean())
 
 
 def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
@@ -64,7 +63,7 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
         dt = time.perf_counter() - t0
         d, arrived = delay(env)
         print(json.dumps(dict(episode=ep, epsilon=round(eps, 3), mean_return=float(ret.sum(1).mean()) / S,
-                              time_loss_s=round(d, 2), arrived_per_env=round(arrived, 1), updates=learner.n_updates,
+                              avg_delay_s=round(d, 2), arrived_per_env=round(arrived, 1), updates=learner.n_updates,
                               env_steps_per_s=round(n * steps / dt), ms_per_step=round(dt / steps * 1e3, 3))), flush=True)
 
     env.sim.set_seed(12345)                             # greedy evaluation on the baseline's demand seed
@@ -74,7 +73,7 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
         obs = o['drq_norm_f16']
     g_delay, _ = delay(env)
     print(json.dumps(dict(map=map_name, envs=n, episodes=episodes, batch=batch, updates_per_step=updates,
-                          greedy_time_loss_s=round(g_delay, 2), random_time_loss_s=round(rnd_delay, 2))))
+                          greedy_avg_delay_s=round(g_delay, 2), random_avg_delay_s=round(rnd_delay, 2))))
     env.close()
 
 
