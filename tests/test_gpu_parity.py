@@ -257,6 +257,8 @@ def test_trip_log_and_tripinfo_output():
     for k in range(80):
         env.step({env.all_ts_ids[0]: k % 4})
     ts = env.trip_stats()
+    lane, trip = env.sim.read('veh_lane')[0], env.sim.read('veh_trip')[0]
+    queued, now, delay = trip[lane == 0xFFFE].astype(np.int64), int(env.sim.read('env')[0, 0]), env.sim.trip_delay()[0]
     env.reset()                                   # closes episode 1: writes metrics_1.csv and tripinfo_1.xml
     root = ET.parse(os.path.join(tmp, env.connection_name, 'tripinfo_1.xml')).getroot()
     trips = list(root)
@@ -266,6 +268,11 @@ def test_trip_log_and_tripinfo_output():
     assert sum(float(t.get('duration')) for t in fin) == ts['sum_duration']
     assert sum(float(t.get('departDelay')) for t in trips) == ts['sum_depart_delay']
     assert all(float(t.get('depart')) >= 25200 for t in trips)
+    # BatchedSim.trip_delay() is utils/readXML.py's episode figure: (timeLoss + departDelay) per tripinfo entry,
+    # plus the trips still queued for insertion, which the reference charges from their scheduled departure
+    total = sum(float(t.get('timeLoss')) + float(t.get('departDelay')) for t in trips) \
+        + float(np.maximum(0, now - np.asarray(env.scenario.arrays['trip_depart'])[queued]).sum())
+    assert abs(delay - total / (len(trips) + len(queued))) < 0.02
     env.close()
 
 
