@@ -27,6 +27,8 @@
 #define BIGF 1.0e30f
 #define SG_ADVANTAGE 10.0f
 #define URGENT_DIST 50.0f
+#define SWAP_WAIT 20      /* a mutual block is broken up after both vehicles have stood for this many seconds ... */
+#define SWAP_EVERY 4      /* ... and is looked for on every 4th tick only */
 
 enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
 enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
@@ -527,6 +529,34 @@ static void move(orc_env *e) {
     while (e->hw > 0 && e->lane[e->hw - 1] == LANE_NONE) e->hw -= 1;
 }
 
+/* Mutual block (own rule; SUMO resolves the same situation with cooperative lane changing or teleports, which this
+ * model does not have): two stationary vehicles stand side by side near the end of their lanes, each in the lane
+ * the other one needs.  Neither can ever find a gap, so they trade places.  swap_dir: the strategic direction of
+ * such a vehicle (0: it is not one). */
+static int32_t swap_dir(const orc_env *e, int32_t s) {
+    const orc_scenario *sc = e->sc;
+    if (e->lane[s] >= LANE_PENDING) return 0;
+    int32_t lane = e->lane[s];
+    if (sc->lane_internal[lane] || e->speed[s] > HALT_SPEED || e->sumo_wait[s] < SWAP_WAIT) return 0;
+    int32_t ed = sc->lane_edge[lane], n = sc->edge_nlanes[ed], kk = lane - sc->edge_lane0[ed];
+    if (n < 2 || sc->lane_len[lane] - e->pos[s] > URGENT_DIST) return 0;
+    uint32_t m2 = sc->route_mask2[sc->route_start[sc->trip_route[e->trip[s]]] + e->cursor[s]];
+    if ((m2 >> kk) & 1u) return 0;
+    int32_t dl = 1000, dr = 1000;
+    for (int32_t j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
+    for (int32_t j = kk - 1; j >= 0; --j) if ((m2 >> j) & 1u) { dr = kk - j; break; }
+    if (dl == 1000 && dr == 1000) return 0;
+    return (dr <= dl) ? -1 : +1;
+}
+/* the vehicle on lane tl whose body overlaps mine lengthwise (the nearer one ahead first), NIL: none */
+static int32_t overlapping(const orc_env *e, int32_t s, int32_t tl) {
+    int32_t lead, foll;
+    int32_t k = e->trip[s];
+    neighbours(e, tl, e->pos[s], k, s, &lead, &foll);
+    if (lead != NIL && e->pos[lead] - vt_of(e, trip_of_slot(e, lead))[VT_LENGTH] - e->pos[s] < 0.0f) return lead;
+    if (foll != NIL && e->pos[s] - vt_of(e, k)[VT_LENGTH] - e->pos[foll] < 0.0f) return foll;
+    return NIL;
+}
 static void lane_change(orc_env *e) {
     const orc_scenario *sc = e->sc;
     int32_t dir_allowed = (e->t & 1) ? -1 : +1;
@@ -594,6 +624,17 @@ static void lane_change(orc_env *e) {
             if (gap < 0.0f || vb > orc_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = 0;
         }
         if (safe) e->lc_target[s] = tl;
+    }
+    /* mutual block at the end of the lanes: two stationary vehicles side by side, each in the lane the other needs */
+    /* (an overlapping vehicle makes the regular change above unsafe, and the partner, heading the other way, had
+     * no chance this tick: neither has a target yet; the mutual test makes the pairs unique) */
+    for (int32_t s = 0; s < e->hw && e->t % SWAP_EVERY == 0; ++s) {
+        if (swap_dir(e, s) != dir_allowed) continue;
+        int32_t lane = e->lane[s], tl = lane + dir_allowed;
+        int32_t b = overlapping(e, s, tl);
+        if (b == NIL || swap_dir(e, b) != -dir_allowed) continue;
+        if (overlapping(e, b, lane) != s) continue;
+        e->lc_target[s] = tl; e->lc_target[b] = lane;
     }
     for (int32_t s = 0; s < e->hw; ++s) {
         if (e->lane[s] >= LANE_PENDING) continue;

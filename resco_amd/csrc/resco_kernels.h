@@ -509,6 +509,26 @@ __device__ __forceinline__ void set_phase(const KTab &T, Lds &L, const KParams &
     tls_refresh(T, L, P, s, ph);
 }
 
+// strategic lane-change direction on an edge of n lanes for a vehicle on lane index kk whose route continues on the
+// lanes of mask m2: towards the nearest of them (right on a tie), 0 when kk itself continues the route (or none does)
+__device__ __forceinline__ int strategic_dir(uint32_t m2, int kk, int n) {
+    if ((m2 >> kk) & 1u) return 0;
+    int dl = 1000, dr = 1000;
+    for (int j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
+    for (int j = kk - 1; j >= 0; --j) if ((m2 >> j) & 1u) { dr = kk - j; break; }
+    if (dl == 1000 && dr == 1000) return 0;
+    return (dr <= dl) ? -1 : +1;
+}
+// the vehicle on the lane with cells [cell0, cell0 + ncell) whose body overlaps the one at (pos, k) lengthwise (the
+// nearer one ahead first), NIL: none
+__device__ __forceinline__ int overlapping(const Lds &L, const uint16_t *head, int cell0, int ncell, float pos, int k, int self, float len_self) {
+    int lead, foll;
+    neighbours(L, head, cell0, ncell, pos, k, self, lead, foll);
+    if (lead != NIL && L.node[lead].pos - L.vtp[L.vt[lead] * VT_COLS + VT_LENGTH] - pos < 0.0f) return lead;
+    if (foll != NIL && pos - len_self - L.node[foll].pos < 0.0f) return foll;
+    return NIL;
+}
+
 // Preparation of a tick for slot s (P2b + P3): a pending trip bids for its departure lane (lowest trip wins);
 // a moving vehicle whose next link somebody may have to yield to registers its arrival time there.
 __device__ __forceinline__ void tick_prepare(const KTab &T, Lds &L, const KParams &P, int s) {
@@ -896,54 +916,65 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 const int l0 = LR.edge_lane0;
                 const int kk = lane - l0;
                 const int tk = kk + dir_allowed;
-                if (!(LR.flags & LF_INTERNAL) && n >= 2 && tk >= 0 && tk < n) {
+                if (!(LR.flags & LF_INTERNAL) && n >= 2) {
                     const int k = L.node[s].trip;
                     const uint32_t m2 = T.route_mask2[L.rq[s]];
                     const float *vt = L.vtp + L.vt[s] * VT_COLS;
                     const float x = L.node[s].pos, v = L.speed[s];
-                    const int tl = l0 + tk;
                     const float lane_len = LR.len;
                     const int nc = lane_cells(LR);
-                    const int tcell0 = (int)LR.cell0 + dir_allowed * nc;     // lanes of an edge own consecutive cell blocks
-                    int want = 0;
-                    int lead_t = NIL, foll_t = NIL;
-                    if (!((m2 >> kk) & 1u)) {
-                        int dl = 1000, dr = 1000;
-                        for (int j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
-                        for (int j = kk - 1; j >= 0; --j) if ((m2 >> j) & 1u) { dr = kk - j; break; }
-                        int dir = 0;
-                        if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
-                        want = (dir == dir_allowed) ? 2 : 0;
-                        if (want) neighbours(L, hn, tcell0, nc, x, k, s, lead_t, foll_t);
-                    } else if (((m2 >> tk) & 1u) && ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) == 0u) {
-                        const int lead_c = leader_of(L, hn, LR.cell0, nc, x, k, s);
-                        if (lead_c != NIL) {
-                            neighbours(L, hn, tcell0, nc, x, k, s, lead_t, foll_t);
-                            float gcur = L.node[lead_c].pos - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
-                            float gtgt = BIGF;
-                            if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
-                            if (gcur < v * 3.0f + 15.0f && gtgt > gcur + SG_ADVANTAGE) want = 1;
+                    const int sdir = strategic_dir(m2, kk, n);      // 0: my lane continues the route
+                    if (tk >= 0 && tk < n) {
+                        const int tl = l0 + tk;
+                        const int tcell0 = (int)LR.cell0 + dir_allowed * nc;     // lanes of an edge own consecutive cell blocks
+                        int want = 0;
+                        int lead_t = NIL, foll_t = NIL;
+                        if (!((m2 >> kk) & 1u)) {
+                            want = (sdir == dir_allowed) ? 2 : 0;
+                            if (want) neighbours(L, hn, tcell0, nc, x, k, s, lead_t, foll_t);
+                        } else if (((m2 >> tk) & 1u) && ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) == 0u) {
+                            const int lead_c = leader_of(L, hn, LR.cell0, nc, x, k, s);
+                            if (lead_c != NIL) {
+                                neighbours(L, hn, tcell0, nc, x, k, s, lead_t, foll_t);
+                                float gcur = L.node[lead_c].pos - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
+                                float gtgt = BIGF;
+                                if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
+                                if (gcur < v * 3.0f + 15.0f && gtgt > gcur + SG_ADVANTAGE) want = 1;
+                            }
+                        }
+                        if (want) {
+                            COUNT(16, 1);
+                            const bool urgent = want == 2 && (lane_len - x) <= URGENT_DIST;
+                            bool safe = true;
+                            if (lead_t != NIL) {
+                                const float *vo = L.vtp + L.vt[lead_t] * VT_COLS;
+                                float gap = L.node[lead_t].pos - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
+                                float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
+                                float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
+                                if (gap < 0.0f || vb > d_follow_speed(gap, L.speed[lead_t], vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
+                            }
+                            if (safe && foll_t != NIL) {
+                                const float *vo = L.vtp + L.vt[foll_t] * VT_COLS;
+                                float gap = x - vt[VT_LENGTH] - L.node[foll_t].pos - (urgent ? 0.0f : vo[VT_MINGAP]);
+                                float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
+                                float vb = L.speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
+                                if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
+                            }
+                            if (safe) target = tl;
                         }
                     }
-                    if (want) {
-                        COUNT(16, 1);
-                        const bool urgent = want == 2 && (lane_len - x) <= URGENT_DIST;
-                        bool safe = true;
-                        if (lead_t != NIL) {
-                            const float *vo = L.vtp + L.vt[lead_t] * VT_COLS;
-                            float gap = L.node[lead_t].pos - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
-                            float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
-                            float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
-                            if (gap < 0.0f || vb > d_follow_speed(gap, L.speed[lead_t], vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
+                    // Mutual block: two vehicles that have stood side by side near the end of their lanes for SWAP_WAIT
+                    // seconds, each in the lane the other one needs, can never find a gap: they trade places.  The test is symmetric, so both
+                    // threads reach the same verdict from the moved state (whichever way this tick's changes go).
+                    if (sdir != 0 && (t % SWAP_EVERY) == 0 && v <= HALT_SPEED && L.swait[s] >= SWAP_WAIT && (lane_len - x) <= URGENT_DIST) {
+                        const int b = overlapping(L, hn, (int)LR.cell0 + sdir * nc, nc, x, k, s, vt[VT_LENGTH]);
+                        if (b != NIL && L.speed[b] <= HALT_SPEED && L.swait[b] >= SWAP_WAIT) {
+                            const Node nb = L.node[b];
+                            if (T.lanes[lane + sdir].len - nb.pos <= URGENT_DIST &&
+                                strategic_dir(T.route_mask2[L.rq[b]], kk + sdir, n) == -sdir &&
+                                overlapping(L, hn, LR.cell0, nc, nb.pos, nb.trip, b, L.vtp[L.vt[b] * VT_COLS + VT_LENGTH]) == s)
+                                target = lane + sdir;
                         }
-                        if (safe && foll_t != NIL) {
-                            const float *vo = L.vtp + L.vt[foll_t] * VT_COLS;
-                            float gap = x - vt[VT_LENGTH] - L.node[foll_t].pos - (urgent ? 0.0f : vo[VT_MINGAP]);
-                            float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
-                            float vb = L.speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
-                            if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
-                        }
-                        if (safe) target = tl;
                     }
                 }
             }

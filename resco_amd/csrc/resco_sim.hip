@@ -42,6 +42,8 @@
 #define BIGF 1.0e30f
 #define SG_ADVANTAGE 10.0f
 #define URGENT_DIST 50.0f
+#define SWAP_WAIT 20
+#define SWAP_EVERY 4
 
 enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
 enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };

@@ -54,6 +54,7 @@ def assert_env_equal(sim, orcs, step):
     ('cologne3', 2, 40, -1.0, 1, 0),         # <vehicle><route> demand, explicit routes
     ('ingolstadt1', 2, 40, -1.0, 1, 1),
     ('ingolstadt7', 2, 40, -1.0, 1, 0),
+    ('ingolstadt7', 2, 260, -1.0, 1, 1),     # long enough for mutual lane blocks to form and be swapped out
 ])
 def test_gpu_equals_oracle_bit_exact(name, n_envs, steps, sigma, speed_dev, fixed):
     from oracle.pyoracle import OracleEnv
