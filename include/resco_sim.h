@@ -176,6 +176,26 @@ int rs_set_seed(rs_handle h, uint32_t seed);
  * change, 8 F rebuild, 9 observe, 10 outputs.  Reading also resets. */
 int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16);
 
+/* ---- fused IDQN policy forward (BASELINE config 5) ------------------------------------------
+ * Replaces the per-signal Q-network evaluation + LinearDecayEpsilonGreedy action selection of the reference's
+ * IDQN agent (resco_benchmark/agents/pfrl_dqn.py:17-46, 62-67): Conv2d(1,64,(2,2)) - ReLU - Flatten -
+ * Linear(64*H*4,64) - ReLU - Linear(64,64) - ReLU - Linear(64,A) for every signal, on the fp16 observation tensor
+ * RS_BUF_DRQ_NORM_F16 [N][S][lmax][5] the step kernel writes.  Weights arrive pre-packed by
+ * resco_amd/agents/idqn_fused.py (fc weights as f16 MFMA B-fragments, see resco_amd/csrc/resco_policy.h):
+ *   conv_w f32 [S][64][4], conv_b f32 [S][64], w1 f16 [S][64][hp][2][64][4], b1 f32 [S][64], w2 f16 [S][8][2][64][4],
+ *   b2 f32 [S][64], w3 f16 [S][8][64][4], b3 f32 [S][32], n_actions i32 [S];  hp = ceil((lmax - 1) / 2), lmax <= 17.
+ * rs_idqn_act: obs / actions (int32 [N][S]) / q (float [N][S][8] or NULL) are DEVICE pointers; epsilon-greedy with
+ * the counter hash over (seed; env, signal, step_key); launched on `stream` (same convention as rs_step).  dyn: NULL, or a
+ * device pointer to {float epsilon; uint32 step_key} that overrides the two scalar arguments - for replaying a captured
+ * HIP graph of the whole env-step (policy kernel + rs_step) with values computed by an earlier node of the graph. */
+typedef struct rs_policy *rs_policy_handle;
+int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax, const int32_t *n_actions, const float *conv_w,
+                   const float *conv_b, const uint16_t *w1, const float *b1, const uint16_t *w2, const float *b2,
+                   const uint16_t *w3, const float *b3, rs_policy_handle *out);
+int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, float epsilon, uint32_t seed, uint32_t step_key,
+                const void *dyn, int32_t *actions, float *q, void *stream);
+void rs_idqn_destroy(rs_policy_handle p);
+
 /* static facts */
 int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int32_t *lds_bytes, int32_t *max_lanes_per_signal);
 

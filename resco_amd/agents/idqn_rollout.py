@@ -108,3 +108,4 @@ class BatchedIDQN(nn.Module):
         u = torch.rand((2,) + tuple(greedy.shape), device=q.device, generator=generator)
         rnd = torch.minimum((u[1] * self._n_act).long(), (self._n_act - 1).long())
         return torch.where(u[0] < epsilon, rnd, greedy).to(torch.int32)
+

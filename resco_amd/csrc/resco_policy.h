@@ -1,0 +1,199 @@
+// resco_policy.h -- fused forward of the S per-signal IDQN networks (BASELINE config 5).
+//
+// The reference network per signal (resco_benchmark/agents/pfrl_dqn.py:30-39):
+//     Conv2d(1, 64, (2,2)) - ReLU - Flatten(c,h,w) - Linear(64*H*4, 64) - ReLU - Linear(64, 64) - ReLU - Linear(64, A)
+// on the observation (1, L, 5), H = L - 1.  As separate library calls the 64*H*4-wide feature tensor (4 096 halfs
+// per env and signal) goes out to HBM and comes back - that traffic, not the 11 GFLOP of fc1, is what the PyTorch
+// forward spends its time on.  Here the features never exist in memory: for every conv channel a lane computes the
+// 4 features its MFMA A-fragment needs from the 2 x 5 observation values it keeps in registers, and feeds them
+// straight into v_mfma_f32_32x32x8_f16 against the pre-packed fc1 weights of that channel.
+//
+// One workgroup = 2 waves = 64 environments of ONE signal (grid: ceil(N/64) x S); a wave owns 32 rows (envs) x 64
+// fc1 outputs = two 32x32 accumulator tiles.  fc2 / fc3 reuse the same MFMA shape after an LDS round trip that
+// turns accumulator layout into A-fragment layout; the epilogue does the masked argmax and the epsilon-greedy draw
+// (counter hash over (seed; env, signal, step)) and writes int32 actions the step kernel consumes.
+//
+// MFMA 32x32x8 f16 fragment layout (lane l, g = l >> 5, i = l & 31):
+//     A: row i, k = 4 g + j (j = 0..3);   B: column i, k = 4 g + j;   C/D reg r: column i, row (r & 3) + 8 (r >> 2) + 4 g.
+#pragma once
+
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef float f16x_t __attribute__((ext_vector_type(16)));
+
+#define POL_C 64            // conv channels = fc widths of the reference network
+#define POL_TM 64           // environments per workgroup
+#define POL_QMAX 8          // at most 8 actions per signal
+
+struct PolicyTab {          // device pointers of the packed weights, all [S][...]
+    const float *conv_w;    // [S][64][4]  w00 w01 w10 w11
+    const float *conv_b;    // [S][64]
+    const h4_t *w1;         // [S][64 channels][HP k-steps][2 n-tiles][64 lanes]  B fragments of fc1
+    const float *b1;        // [S][64]
+    const h4_t *w2;         // [S][8][2][64]
+    const float *b2;        // [S][64]
+    const h4_t *w3;         // [S][8][64]       (columns >= n_actions are zero)
+    const float *b3;        // [S][32]
+    const int32_t *n_actions;   // [S]
+    int32_t S, lmax, hp;    // signals, padded lanes per signal (obs rows), k-steps of 8 per channel = ceil((lmax-1)/2)
+};
+
+__device__ __forceinline__ uint32_t pol_hash(uint32_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return d_hash(seed, a, b, c, d);
+}
+
+// HP (k-steps of 8 per conv channel = ceil(H / 2)) is a template parameter: the eight k-steps become straight-line
+// code, so the LDS fragment reads of later steps are issued ahead of the MFMAs of earlier ones
+template <int HP>
+__global__ void __launch_bounds__(128)
+rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, float eps, uint32_t seed, uint32_t step_key,
+                       const uint32_t *__restrict__ dyn, int32_t *__restrict__ actions, float *__restrict__ q_out) {
+    // dyn != NULL: epsilon (float bits) and step key come from device memory, so that a captured HIP graph of the
+    // env-step can be replayed with values an earlier node of the same graph computed
+    if (dyn) { eps = __uint_as_float(dyn[0]); step_key = dyn[1]; }
+    __shared__ __attribute__((aligned(16))) _Float16 xs[POL_TM][18][8];       // obs tile, rows padded to 8 halfs, +1 zero row
+    __shared__ __attribute__((aligned(16))) _Float16 ys[2][32][POL_C + 8];    // per wave: activations for the next layer's A fragments
+    __shared__ float qs[2][32][POL_QMAX];
+    __shared__ __attribute__((aligned(16))) h4_t wbuf[2 * 8 * 2 * 64];        // fc1 fragments of two conv channels
+    const int s = blockIdx.y;
+    const int m0 = blockIdx.x * POL_TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int LM = W.lmax, H = LM - 1;
+
+    // ---- stage the observation tile: [64 envs][LM][5] halfs, contiguous per env -> xs[env][row][0..4]
+    for (int e = tid; e < POL_TM * 18 * 8; e += 128) ((_Float16 *)xs)[e] = (_Float16)0.0f;
+    __syncthreads();
+    for (int e = tid; e < POL_TM * LM * 5; e += 128) {
+        const int m = e / (LM * 5), r = e - m * (LM * 5);
+        if (m0 + m < n_envs) {
+            const __half v = obs[((size_t)(m0 + m) * W.S + s) * LM * 5 + r];
+            xs[m][r / 5][r % 5] = *(const _Float16 *)&v;
+        }
+    }
+    __syncthreads();
+
+    // ---- my rows of the tile in registers: for k-step kk the lane needs obs rows h = 2 kk + g and h + 1
+    const int mrow = wave * 32 + i;
+    float x0[HP][5], x1[HP][5];
+#pragma unroll
+    for (int kk = 0; kk < HP; ++kk) {
+        const int h = 2 * kk + g;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            x0[kk][j] = h < H ? (float)xs[mrow][h][j] : 0.0f;
+            x1[kk][j] = h < H ? (float)xs[mrow][h + 1][j] : 0.0f;
+        }
+    }
+
+    // ---- conv + ReLU on the fly -> fc1 (two 32x32 tiles per wave).  The fc1 fragments of one conv channel (HP x 2 x 64
+    //      lanes x 8 B = 8 KB for H = 16) are shared by the two waves: staged through LDS, double-buffered, the next
+    //      channel's global loads in flight while this one is multiplied.
+    f16x_t acc0 = {0}, acc1 = {0};
+    const float *cw = W.conv_w + (size_t)s * POL_C * 4;
+    const float *cb = W.conv_b + (size_t)s * POL_C;
+    constexpr int chunk16 = HP * 64;                                // 16-byte units per channel: HP * 2 * 64 * 8 B / 16
+    constexpr int NQ = (chunk16 + 127) / 128;                       // copy passes of the 128 threads (the last one may run
+                                                                    // past the channel: the allocation and wbuf are padded)
+    const uint4 *w1g = (const uint4 *)(W.w1 + (size_t)s * POL_C * HP * 2 * 64);
+    uint4 *wbuf16 = (uint4 *)wbuf;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wbuf16[tid + q * 128] = w1g[tid + q * 128];
+    __syncthreads();
+    for (int c = 0; c < POL_C; ++c) {
+        uint4 nxt[NQ];
+        const uint4 *gn = w1g + (size_t)(c + 1 < POL_C ? c + 1 : c) * chunk16 + tid;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) nxt[q] = gn[q * 128];          // in flight while this channel is multiplied
+        const float w00 = cw[c * 4 + 0], w01 = cw[c * 4 + 1], w10 = cw[c * 4 + 2], w11 = cw[c * 4 + 3], bc = cb[c];
+        const h4_t *wc = wbuf + (size_t)(c & 1) * (8 * 2 * 64) + lane;
+#pragma unroll
+        for (int kk = 0; kk < HP; ++kk) {
+            h4_t a;         // rows beyond H give relu(bias): harmless, their fc1 weights are packed as zeros
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float f = __builtin_fmaf(w11, x1[kk][j + 1], __builtin_fmaf(w10, x1[kk][j], __builtin_fmaf(w01, x0[kk][j + 1], __builtin_fmaf(w00, x0[kk][j], bc))));
+                a[j] = (_Float16)__builtin_fmaxf(f, 0.0f);
+            }
+            const h4_t b0 = wc[(kk * 2 + 0) * 64], b1 = wc[(kk * 2 + 1) * 64];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(a, b1, acc1, 0, 0, 0);
+        }
+        uint4 *dst = wbuf16 + (size_t)((c + 1) & 1) * (8 * 2 * 64 / 2) + tid;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dst[q * 128] = nxt[q];
+        __syncthreads();
+    }
+
+    // ---- bias + ReLU, accumulator layout -> LDS [row][col] -> A fragments of the next layer
+    _Float16 (*y)[POL_C + 8] = ys[wave];
+    {
+        const float *b1v = W.b1 + (size_t)s * POL_C;
+        const float ba = b1v[i], bb = b1v[32 + i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            float u = acc0[r] + ba, v = acc1[r] + bb;
+            y[row][i] = (_Float16)(u > 0.0f ? u : 0.0f);
+            y[row][32 + i] = (_Float16)(v > 0.0f ? v : 0.0f);
+        }
+    }
+    __syncthreads();
+    // ---- fc2
+    f16x_t c0 = {0}, c1 = {0};
+    {
+        const h4_t *w2 = W.w2 + (size_t)s * 8 * 2 * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const h4_t a = *(const h4_t *)&y[i][kk * 8 + g * 4];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x8f16(a, w2[(kk * 2 + 0) * 64], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x8f16(a, w2[(kk * 2 + 1) * 64], c1, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    {
+        const float *b2v = W.b2 + (size_t)s * POL_C;
+        const float ba = b2v[i], bb = b2v[32 + i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * g;
+            float u = c0[r] + ba, v = c1[r] + bb;
+            y[row][i] = (_Float16)(u > 0.0f ? u : 0.0f);
+            y[row][32 + i] = (_Float16)(v > 0.0f ? v : 0.0f);
+        }
+    }
+    __syncthreads();
+    // ---- fc3 (columns >= n_actions are zero padding)
+    f16x_t d0 = {0};
+    {
+        const h4_t *w3 = W.w3 + (size_t)s * 8 * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const h4_t a = *(const h4_t *)&y[i][kk * 8 + g * 4];
+            d0 = __builtin_amdgcn_mfma_f32_32x32x8f16(a, w3[kk * 64], d0, 0, 0, 0);
+        }
+    }
+    if (i < POL_QMAX) {
+        const float b3v = W.b3[(size_t)s * 32 + i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qs[wave][(r & 3) + 8 * (r >> 2) + 4 * g][i] = d0[r] + b3v;
+    }
+    __syncthreads();
+    // ---- per environment: greedy action over the signal's actions, epsilon-greedy draw
+    if (lane < 32) {
+        const int m = m0 + wave * 32 + lane;
+        if (m < n_envs) {
+            const int na = W.n_actions[s];
+            int best = 0;
+            float bq = qs[wave][lane][0];
+            for (int a = 1; a < na; ++a) { const float v = qs[wave][lane][a]; if (v > bq) { bq = v; best = a; } }
+            int act = best;
+            if (eps > 0.0f) {
+                const float u = d_u01(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 0u));
+                if (u < eps) act = (int)(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 1u) % (uint32_t)na);
+            }
+            actions[(size_t)m * W.S + s] = act;
+            if (q_out)
+                for (int a = 0; a < POL_QMAX; ++a) q_out[((size_t)m * W.S + s) * POL_QMAX + a] = a < na ? qs[wave][lane][a] : -INFINITY;
+        }
+    }
+}

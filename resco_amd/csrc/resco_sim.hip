@@ -50,6 +50,7 @@ enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
 enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, ST_ACTIVE, ST_PENDING, ST_ACTIVE_TICKS, ST_TICKS, ST_N };
 
 #include "resco_kernels.h"
+#include "resco_policy.h"
 
 // ------------------------------------------------------------------------------------------------ host side
 struct rs_sim {
@@ -654,4 +655,74 @@ extern "C" int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int
     if (lds_bytes) *lds_bytes = (int32_t)h->lds;
     if (max_lanes_per_signal) *max_lanes_per_signal = h->T.lmax;
     return RS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ fused IDQN policy
+struct rs_policy {
+    int device = 0;
+    PolicyTab W{};
+    std::vector<void *> allocs;
+};
+
+template <class T> static int pol_upload(rs_policy *p, const T **dst, const void *src, size_t count) {
+    void *d = nullptr;
+    if (hipMalloc(&d, count * sizeof(T) + 2048) != hipSuccess) return RS_ENOMEM;     // the fc1 copy passes may read up to 1 KB past the end
+    p->allocs.push_back(d);
+    if (hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return RS_EHIP;
+    *dst = (const T *)d;
+    return RS_OK;
+}
+
+extern "C" int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax, const int32_t *n_actions, const float *conv_w,
+                              const float *conv_b, const uint16_t *w1, const float *b1, const uint16_t *w2, const float *b2,
+                              const uint16_t *w3, const float *b3, rs_policy_handle *out) {
+    if (!out) return RS_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_err = "no HIP device visible (this library has no CPU fallback)"; return RS_EHIP; }
+    if (device_id < 0 || device_id >= ndev || n_signals <= 0 || lmax < 2 || lmax > 17 || !n_actions || !conv_w || !conv_b || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) {
+        g_create_err = "rs_idqn_create: bad argument (1 <= signals, 2 <= lmax <= 17)"; return RS_EINVAL;
+    }
+    for (int s = 0; s < n_signals; ++s)
+        if (n_actions[s] < 1 || n_actions[s] > POL_QMAX) { g_create_err = "rs_idqn_create: 1..8 actions per signal"; return RS_ELIMIT; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_create_err = "hipSetDevice failed"; return RS_EHIP; }
+    rs_policy *p = new (std::nothrow) rs_policy();
+    if (!p) return RS_ENOMEM;
+    p->device = device_id;
+    const size_t S = (size_t)n_signals, hp = (size_t)(lmax / 2);       // ceil((lmax - 1) / 2)
+    p->W.S = n_signals; p->W.lmax = lmax; p->W.hp = (int32_t)hp;
+    int rc;
+    if ((rc = pol_upload<float>(p, &p->W.conv_w, conv_w, S * 64 * 4)) || (rc = pol_upload<float>(p, &p->W.conv_b, conv_b, S * 64)) ||
+        (rc = pol_upload<h4_t>(p, &p->W.w1, w1, S * 64 * hp * 2 * 64)) || (rc = pol_upload<float>(p, &p->W.b1, b1, S * 64)) ||
+        (rc = pol_upload<h4_t>(p, &p->W.w2, w2, S * 8 * 2 * 64)) || (rc = pol_upload<float>(p, &p->W.b2, b2, S * 64)) ||
+        (rc = pol_upload<h4_t>(p, &p->W.w3, w3, S * 8 * 64)) || (rc = pol_upload<float>(p, &p->W.b3, b3, S * 32)) ||
+        (rc = pol_upload<int32_t>(p, &p->W.n_actions, n_actions, S))) {
+        g_create_err = "rs_idqn_create: device allocation / upload failed";
+        rs_idqn_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return RS_OK;
+}
+
+extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, float epsilon, uint32_t seed, uint32_t step_key,
+                           const void *dyn, int32_t *actions, float *q, void *stream) {
+    if (!p || !obs || !actions || n_envs <= 0) return RS_EINVAL;
+    if (hipSetDevice(p->device) != hipSuccess) return RS_EHIP;
+    typedef void (*pol_fn)(PolicyTab, const __half *, int, float, uint32_t, uint32_t, const uint32_t *, int32_t *, float *);
+    static const pol_fn kernels[9] = {nullptr, rs_idqn_forward_kernel<1>, rs_idqn_forward_kernel<2>, rs_idqn_forward_kernel<3>,
+                                      rs_idqn_forward_kernel<4>, rs_idqn_forward_kernel<5>, rs_idqn_forward_kernel<6>,
+                                      rs_idqn_forward_kernel<7>, rs_idqn_forward_kernel<8>};
+    hipLaunchKernelGGL(kernels[p->W.hp], dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(128), 0, (hipStream_t)stream,
+                       p->W, (const __half *)obs, (int)n_envs, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
+    return hipGetLastError() == hipSuccess ? RS_OK : RS_EHIP;
+}
+
+extern "C" void rs_idqn_destroy(rs_policy_handle p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    for (void *d : p->allocs) (void)hipFree(d);
+    delete p;
 }

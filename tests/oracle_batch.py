@@ -17,6 +17,11 @@ def hashed_random_actions(sc, seed, env_base, n_envs, step_key):
     return out
 
 
+def murmur_hash(seed, a, b, c, d):
+    """The counter hash shared by the simulator and the fused policy (oracle's orc_hash = the kernels' d_hash)."""
+    return int(lib().orc_hash(seed & 0xFFFFFFFF, a & 0xFFFFFFFF, b & 0xFFFFFFFF, c & 0xFFFFFFFF, d & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+
 class OracleBatch:
     def __init__(self, sc, n_envs, seed=0, env_base=0, sigma=-1.0, speed_dev=1):
         self.sc, self.n_envs, self.seed, self.env_base = sc, n_envs, seed, env_base

@@ -626,3 +626,51 @@ def test_idqn_training_loop_on_device():
         assert torch.equal(replay.obs[(i + 1) % 16] if k < 23 else seen[k][0], seen[k][0])      # successor obs
     assert float(replay.rew.min()) >= -4.0 and float(replay.rew.max()) <= 0.0
     env.close()
+
+
+@pytest.mark.parametrize('map_name,n', [('ingolstadt21', 200), ('cologne8', 70), ('cologne1', 64)])
+def test_fused_idqn_policy_matches_torch_reference(map_name, n):
+    """rs_idqn_act (conv features computed inside the MFMA loop of fc1, fp16 operands / fp32 accumulate) against
+    the fp32 PyTorch forward of the same reference-architecture networks on the simulator's fp16 observations.
+    Tolerance 3e-2 absolute on Q (|Q| ~ 0.1-1, K = 64*H*4 fp16 products); greedy actions agree wherever the top two
+    Q-values are further apart than that; epsilon = 1 draws follow the counter hash."""
+    import torch
+    from oracle_batch import murmur_hash
+    from resco_amd.agents.idqn_fused import FusedIDQN
+    from resco_amd.agents.idqn_rollout import BatchedIDQN
+    from resco_amd.multi_signal import VecMultiSignal
+    env = VecMultiSignal(map_name, n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=3)
+    net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
+    net.init_like_reference(seed=5)
+    with torch.no_grad():                       # make the outputs less degenerate than a fresh initialisation
+        net.fc3_b.add_(0.1 * torch.randn_like(net.fc3_b))
+    fused = FusedIDQN(net, seed=11)
+    obs = env.reset()['drq_norm_f16']
+    for k in range(12):
+        env.act_random(k)
+        obs = env.step(None)[0]['drq_norm_f16']
+    acts, q = fused.act(obs, epsilon=0.0, want_q=True)
+    torch.cuda.synchronize()
+    ref = net(obs).float()
+    S = env.n_signals
+    for s_ in range(S):
+        A = net.actions[s_]
+        np.testing.assert_allclose(q[:, s_, :A].cpu().numpy(), ref[:, s_, :A].detach().cpu().numpy(), atol=3e-2, rtol=0)
+        assert torch.isinf(q[:, s_, A:]).all()
+    top2 = ref.masked_fill(~net.action_mask, float('-inf')).topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 6e-2
+    assert clear.float().mean() > 0.3
+    assert torch.equal(acts[clear].long(), ref.argmax(-1)[clear])
+    # epsilon = 1: every action is the hashed draw  hash(seed ^ 0x1D0A17; env, signal, step, 1) mod n_actions
+    a1 = fused.act(obs, epsilon=1.0, step_key=77).clone().cpu().numpy()
+    for m in (0, n // 2, n - 1):
+        for s_ in (0, S - 1):
+            assert a1[m, s_] == murmur_hash(11 ^ 0x1D0A17, m, s_, 77, 1) % net.actions[s_]
+    # the same draw with epsilon / step key taken from device memory (the HIP-graph replay path), written straight
+    # into the simulator's action buffer
+    dyn = torch.tensor([np.float32(1.0).view(np.int32), 77], dtype=torch.int32, device='cuda')
+    a2 = fused.act(obs, epsilon=0.0, step_key=0, dyn=dyn, out=env.tensor('actions'))
+    assert a2.data_ptr() == env.tensor('actions').data_ptr() and np.array_equal(a2.cpu().numpy(), a1)
+    env.step(None)
+    assert np.array_equal(env.sim.read('actions'), a1)
+    env.close()
