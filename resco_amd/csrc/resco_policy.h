@@ -18,6 +18,7 @@
 #pragma once
 
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef float f16x_t __attribute__((ext_vector_type(16)));
 
 #define POL_C 64            // conv channels = fc widths of the reference network
@@ -72,16 +73,20 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
     }
     __syncthreads();
 
-    // ---- my rows of the tile in registers: for k-step kk the lane needs obs rows h = 2 kk + g and h + 1
+    // ---- my rows of the tile in registers: for k-step kk the lane needs obs rows h = 2 kk + g and h + 1, as the four
+    //      overlapping column pairs (0,1) (1,2) (2,3) (3,4) of each row: the 2x2 convolution then is 8 packed f16 FMAs
+    //      per k-step (v_pk_fma_f16: two features per instruction) and its result already is the A fragment
     const int mrow = wave * 32 + i;
-    float x0[HP][5], x1[HP][5];
+    h2_t p0[HP][4], p1[HP][4];
 #pragma unroll
     for (int kk = 0; kk < HP; ++kk) {
         const int h = 2 * kk + g;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            x0[kk][j] = h < H ? (float)xs[mrow][h][j] : 0.0f;
-            x1[kk][j] = h < H ? (float)xs[mrow][h + 1][j] : 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const _Float16 a0 = h < H ? xs[mrow][h][j] : (_Float16)0.0f, a1 = h < H ? xs[mrow][h][j + 1] : (_Float16)0.0f;
+            const _Float16 b0 = h < H ? xs[mrow][h + 1][j] : (_Float16)0.0f, b1 = h < H ? xs[mrow][h + 1][j + 1] : (_Float16)0.0f;
+            p0[kk][j] = h2_t{a0, a1};
+            p1[kk][j] = h2_t{b0, b1};
         }
     }
 
@@ -104,16 +109,18 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
         const uint4 *gn = w1g + (size_t)(c + 1 < POL_C ? c + 1 : c) * chunk16 + tid;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) nxt[q] = gn[q * 128];          // in flight while this channel is multiplied
-        const float w00 = cw[c * 4 + 0], w01 = cw[c * 4 + 1], w10 = cw[c * 4 + 2], w11 = cw[c * 4 + 3], bc = cb[c];
+        const _Float16 s00 = (_Float16)cw[c * 4 + 0], s01 = (_Float16)cw[c * 4 + 1], s10 = (_Float16)cw[c * 4 + 2], s11 = (_Float16)cw[c * 4 + 3], sb = (_Float16)cb[c];
+        const h2_t h00 = {s00, s00}, h01 = {s01, s01}, h10 = {s10, s10}, h11 = {s11, s11}, hb = {sb, sb}, hz = {(_Float16)0.0f, (_Float16)0.0f};
         const h4_t *wc = wbuf + (size_t)(c & 1) * (8 * 2 * 64) + lane;
 #pragma unroll
         for (int kk = 0; kk < HP; ++kk) {
-            h4_t a;         // rows beyond H give relu(bias): harmless, their fc1 weights are packed as zeros
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float f = __builtin_fmaf(w11, x1[kk][j + 1], __builtin_fmaf(w10, x1[kk][j], __builtin_fmaf(w01, x0[kk][j + 1], __builtin_fmaf(w00, x0[kk][j], bc))));
-                a[j] = (_Float16)__builtin_fmaxf(f, 0.0f);
-            }
+            // features (w = 0,1) and (w = 2,3) of row h: rows beyond H give relu(bias), harmless (zero fc1 weights)
+            h2_t f01 = __builtin_elementwise_fma(h00, p0[kk][0], hb), f23 = __builtin_elementwise_fma(h00, p0[kk][2], hb);
+            f01 = __builtin_elementwise_fma(h01, p0[kk][1], f01); f23 = __builtin_elementwise_fma(h01, p0[kk][3], f23);
+            f01 = __builtin_elementwise_fma(h10, p1[kk][0], f01); f23 = __builtin_elementwise_fma(h10, p1[kk][2], f23);
+            f01 = __builtin_elementwise_fma(h11, p1[kk][1], f01); f23 = __builtin_elementwise_fma(h11, p1[kk][3], f23);
+            f01 = __builtin_elementwise_max(f01, hz); f23 = __builtin_elementwise_max(f23, hz);
+            const h4_t a = h4_t{f01[0], f01[1], f23[0], f23[1]};
             const h4_t b0 = wc[(kk * 2 + 0) * 64], b1 = wc[(kk * 2 + 1) * 64];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(a, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(a, b1, acc1, 0, 0, 0);
