@@ -194,6 +194,11 @@ int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax, const int
                    const uint16_t *w3, const float *b3, rs_policy_handle *out);
 int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, float epsilon, uint32_t seed, uint32_t step_key,
                 const void *dyn, int32_t *actions, float *q, void *stream);
+/* Point the policy at caller-owned DEVICE copies of the packed weights (same layouts as rs_idqn_create; any pointer may
+ * be NULL = keep the current one).  The buffers are borrowed: they must stay alive and are read by later rs_idqn_act
+ * launches in stream order - a learner re-packs its weights on the device after every update without a host copy. */
+int rs_idqn_set_device_weights(rs_policy_handle p, const float *conv_w, const float *conv_b, const uint16_t *w1, const float *b1,
+                               const uint16_t *w2, const float *b2, const uint16_t *w3, const float *b3);
 void rs_idqn_destroy(rs_policy_handle p);
 
 /* static facts */

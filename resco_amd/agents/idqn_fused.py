@@ -31,6 +31,15 @@ def _b_fragments(w, n_ksteps, n_tiles):
     return out
 
 
+def _fragment_index(K, N, n_ksteps, n_tiles, zero_index):
+    """Flat gather indices into a [K, N] matrix (row-major) for the B-fragment layout; `zero_index` where padded."""
+    k = (np.arange(n_ksteps)[:, None, None] * 8 + (_LANE[None, :, None] >> 5) * 4 + _J[None, None, :])
+    n = (np.arange(n_tiles)[:, None] * 32 + (_LANE[None, :] & 31))
+    kk = np.broadcast_to(k[:, None, :, :], (n_ksteps, n_tiles, 64, 4))
+    nn = np.broadcast_to(n[None, :, :, None], (n_ksteps, n_tiles, 64, 4))
+    return np.where((kk < K) & (nn < N), kk * N + nn, zero_index).astype(np.int64)
+
+
 def pack_idqn_weights(net):
     """numpy arrays in the order rs_idqn_create takes them."""
     S, lmax = len(net.lanes), net.lmax
@@ -76,6 +85,39 @@ class FusedIDQN:
             raise RuntimeError('rs_idqn_create failed (%d): %s' % (rc, msg.decode() if msg else '?'))
         self.close()
         self._h = h
+
+    @torch.no_grad()
+    def refresh_on_device(self):
+        """Re-pack the network's current weights on the GPU (no host round trip) and point the kernel at the result:
+        what a learner calls after every update.  fp32 parameters whose memory already has the kernel's layout (conv
+        weights, biases) are used in place; the three linear layers are gathered into persistent f16 fragment buffers
+        (index_select + mask + casting copy each)."""
+        net, S = self.net, self.S
+        dev = net.fc1_w.device
+        H, hp, A = self.lmax - 1, self.lmax // 2, net.amax
+        if not hasattr(self, '_idx'):
+            base = _fragment_index(H * 4, 64, hp, 2, -1)             # [hp, 2, 64, 4] into one channel's [H*4, 64] block
+            i1 = np.stack([np.where(base >= 0, c * H * 4 * 64 + base, -1) for c in range(64)]).reshape(-1)
+            i2 = _fragment_index(64, 64, 8, 2, -1).reshape(-1)
+            i3 = _fragment_index(64, A, 8, 1, -1).reshape(-1)
+            self._idx, self._mask, self._dev = {}, {}, {}
+            for k, i in (('w1', i1), ('w2', i2), ('w3', i3)):
+                self._idx[k] = torch.as_tensor(np.maximum(i, 0), device=dev)
+                self._mask[k] = torch.as_tensor((i >= 0).astype(np.float32), device=dev)
+                self._dev[k] = torch.empty(S, len(i), dtype=torch.float16, device=dev)
+            self._dev['b3'] = torch.zeros(S, 32, device=dev, dtype=torch.float32)
+        d = self._dev
+        for k, w in (('w1', net.fc1_w), ('w2', net.fc2_w), ('w3', net.fc3_w)):
+            d[k].copy_(torch.index_select(w.reshape(S, -1).float(), 1, self._idx[k]).mul_(self._mask[k]))
+        d['b3'][:, :A] = net.fc3_b
+        in_place = net.conv_w.dtype == torch.float32
+        for k, t in (('conv_w', net.conv_w), ('conv_b', net.conv_b), ('b1', net.fc1_b), ('b2', net.fc2_b)):
+            d[k] = t.detach() if (in_place and t.is_contiguous()) else t.detach().float().contiguous()
+        L = self._lib
+        L.rs_idqn_set_device_weights.argtypes = [C.c_void_p] * 9
+        rc = L.rs_idqn_set_device_weights(self._h, *[d[k].data_ptr() for k in ('conv_w', 'conv_b', 'w1', 'b1', 'w2', 'b2', 'w3', 'b3')])
+        if rc != 0:
+            raise RuntimeError('rs_idqn_set_device_weights failed (%d)' % rc)
 
     def close(self):
         if getattr(self, '_h', None):

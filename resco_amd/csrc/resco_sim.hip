@@ -719,6 +719,20 @@ extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, 
     return hipGetLastError() == hipSuccess ? RS_OK : RS_EHIP;
 }
 
+extern "C" int rs_idqn_set_device_weights(rs_policy_handle p, const float *conv_w, const float *conv_b, const uint16_t *w1, const float *b1,
+                                          const uint16_t *w2, const float *b2, const uint16_t *w3, const float *b3) {
+    if (!p) return RS_EINVAL;
+    if (conv_w) p->W.conv_w = conv_w;
+    if (conv_b) p->W.conv_b = conv_b;
+    if (w1) p->W.w1 = (const h4_t *)w1;
+    if (b1) p->W.b1 = b1;
+    if (w2) p->W.w2 = (const h4_t *)w2;
+    if (b2) p->W.b2 = b2;
+    if (w3) p->W.w3 = (const h4_t *)w3;
+    if (b3) p->W.b3 = b3;
+    return RS_OK;
+}
+
 extern "C" void rs_idqn_destroy(rs_policy_handle p) {
     if (!p) return;
     (void)hipSetDevice(p->device);

@@ -27,7 +27,7 @@ STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_wai
 ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
                'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_phase_profile', 'rs_info',
-               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_destroy']
+               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_destroy']
 
 _lib = None
 

@@ -673,4 +673,14 @@ def test_fused_idqn_policy_matches_torch_reference(map_name, n):
     assert a2.data_ptr() == env.tensor('actions').data_ptr() and np.array_equal(a2.cpu().numpy(), a1)
     env.step(None)
     assert np.array_equal(env.sim.read('actions'), a1)
+    # weights changed by a learner are re-packed on the device: same result as a fresh host-side packing
+    with torch.no_grad():
+        for prm in net.parameters():
+            prm.add_(0.05 * torch.randn_like(prm) * (prm != 0))
+    fused.refresh_on_device()
+    q_dev = fused.act(obs, want_q=True)[1].clone()
+    fused.refresh()
+    q_host = fused.act(obs, want_q=True)[1]
+    torch.cuda.synchronize()
+    assert torch.equal(q_dev, q_host) and not torch.allclose(q_dev[:, 0, :2], q[:, 0, :2])
     env.close()

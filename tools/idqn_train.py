@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""IDQN training loop entirely on the GPU: HIP simulator -> fp16 observations -> batched Q-networks ->
-device replay ring -> batched DQN update.  Nothing crosses PCIe per step except the launch calls.
+"""IDQN training loop entirely on the GPU: HIP simulator -> fp16 observations -> fused HIP policy kernel
+(rs_idqn_act) -> device replay ring -> batched DQN update (PyTorch) -> weights re-packed on the device.  Nothing crosses PCIe per step except the launch calls.
 
     python tools/idqn_train.py [map] [n_envs] [episodes] [batch] [updates_per_step]
 
@@ -17,6 +17,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from resco_amd.agents.idqn_learn import BatchedDQNLearner, DeviceReplay, linear_epsilon      # noqa: E402
+from resco_amd.agents.idqn_fused import FusedIDQN                                           # noqa: E402
 from resco_amd.agents.idqn_rollout import BatchedIDQN                                       # noqa: E402
 from resco_amd.multi_signal import VecMultiSignal                                           # noqa: E402
 
@@ -32,6 +33,8 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
     net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
     net.init_like_reference(seed=0)
     learner = BatchedDQNLearner(net, gamma=0.99, lr=1e-3, target_update=500, batch_size=batch)
+    policy = FusedIDQN(net, seed=7)             # acting: one HIP kernel; weights re-packed on the device after each update
+    actions = env.tensor('actions')
     replay = DeviceReplay(min(2048, 4 * steps), n, S, net.lmax, device='cuda')
     gen = torch.Generator(device='cuda').manual_seed(0)
     decay = int(0.8 * episodes * steps)                 # the reference decays over config['steps'] agent steps
@@ -51,13 +54,14 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
         t0 = time.perf_counter()
         for k in range(steps):
             eps = linear_epsilon(learner.t, 1.0, 0.0, decay)
-            a = net.act(obs, epsilon=eps, generator=gen)
+            policy.act(obs, epsilon=eps, step_key=learner.t, out=actions)
             replay.stage(obs)
-            o, r, done, _ = env.step(a)
+            o, r, done, _ = env.step(None)
             rew = r['wait_norm']
-            replay.commit(a, rew, done)
+            replay.commit(actions, rew, done)
             ret += rew
-            learner.observe_step(replay, gen, updates)
+            if learner.observe_step(replay, gen, updates) is not None:
+                policy.refresh_on_device()
             obs = o['drq_norm_f16']
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -69,7 +73,8 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
     env.sim.set_seed(12345)                             # greedy evaluation on the baseline's demand seed
     obs = env.reset()['drq_norm_f16']
     for k in range(steps):
-        o, _, _, _ = env.step(net.act(obs))
+        policy.act(obs, out=actions)
+        o, _, _, _ = env.step(None)
         obs = o['drq_norm_f16']
     g_delay, _ = delay(env)
     print(json.dumps(dict(map=map_name, envs=n, episodes=episodes, batch=batch, updates_per_step=updates,
