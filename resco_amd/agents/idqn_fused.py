@@ -104,7 +104,10 @@ class FusedIDQN:
             for k, i in (('w1', i1), ('w2', i2), ('w3', i3)):
                 self._idx[k] = torch.as_tensor(np.maximum(i, 0), device=dev)
                 self._mask[k] = torch.as_tensor((i >= 0).astype(np.float32), device=dev)
-                self._dev[k] = torch.empty(S, len(i), dtype=torch.float16, device=dev)
+                # + 2 KB: the kernel's copy passes of the last conv channel may read up to 1 KB past the fc1 fragments
+                self._pad = getattr(self, '_pad', {})
+                self._pad[k] = torch.zeros(S * len(i) + 1024, dtype=torch.float16, device=dev)
+                self._dev[k] = self._pad[k][:S * len(i)].view(S, len(i))
             self._dev['b3'] = torch.zeros(S, 32, device=dev, dtype=torch.float32)
         d = self._dev
         for k, w in (('w1', net.fc1_w), ('w2', net.fc2_w), ('w3', net.fc3_w)):
