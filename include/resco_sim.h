@@ -184,16 +184,17 @@ int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16);
  * resco_amd/agents/idqn_fused.py (fc weights as f16 MFMA B-fragments, see resco_amd/csrc/resco_policy.h):
  *   conv_w f32 [S][64][4], conv_b f32 [S][64], w1 f16 [S][64][hp][2][64][4], b1 f32 [S][64], w2 f16 [S][8][2][64][4],
  *   b2 f32 [S][64], w3 f16 [S][8][64][4], b3 f32 [S][32], n_actions i32 [S];  hp = ceil((lmax - 1) / 2), lmax <= 17.
- * rs_idqn_act: obs / actions (int32 [N][S]) / q (float [N][S][8] or NULL) are DEVICE pointers; epsilon-greedy with
- * the counter hash over (seed; env, signal, step_key); launched on `stream` (same convention as rs_step).  dyn: NULL, or a
+ * rs_idqn_act: obs / actions (int32 [N][S]) / q (float [N][S][8] or NULL) are DEVICE pointers; mode 0: epsilon-greedy with
+ * the counter hash over (seed; env, signal, step_key); mode 1: the outputs are logits and the action is drawn from
+ * softmax(logits) - the IPPO policy head on the same trunk (resco_benchmark/agents/pfrl_ppo.py:49-64, SoftmaxCategoricalHead); launched on `stream` (same convention as rs_step).  dyn: NULL, or a
  * device pointer to {float epsilon; uint32 step_key} that overrides the two scalar arguments - for replaying a captured
  * HIP graph of the whole env-step (policy kernel + rs_step) with values computed by an earlier node of the graph. */
 typedef struct rs_policy *rs_policy_handle;
 int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax, const int32_t *n_actions, const float *conv_w,
                    const float *conv_b, const uint16_t *w1, const float *b1, const uint16_t *w2, const float *b2,
                    const uint16_t *w3, const float *b3, rs_policy_handle *out);
-int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, float epsilon, uint32_t seed, uint32_t step_key,
-                const void *dyn, int32_t *actions, float *q, void *stream);
+int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, int32_t mode, float epsilon, uint32_t seed,
+                uint32_t step_key, const void *dyn, int32_t *actions, float *q, void *stream);
 /* Point the policy at caller-owned DEVICE copies of the packed weights (same layouts as rs_idqn_create; any pointer may
  * be NULL = keep the current one).  The buffers are borrowed: they must stay alive and are read by later rs_idqn_act
  * launches in stream order - a learner re-packs its weights on the device after every update without a host copy. */

@@ -11,7 +11,8 @@
 // One workgroup = 2 waves = 64 environments of ONE signal (grid: ceil(N/64) x S); a wave owns 32 rows (envs) x 64
 // fc1 outputs = two 32x32 accumulator tiles.  fc2 / fc3 reuse the same MFMA shape after an LDS round trip that
 // turns accumulator layout into A-fragment layout; the epilogue does the masked argmax and the epsilon-greedy draw
-// (counter hash over (seed; env, signal, step)) and writes int32 actions the step kernel consumes.
+// (counter hash over (seed; env, signal, step)) - or, in mode 1, samples from softmax(outputs), which is the IPPO
+// policy head on the same trunk - and writes int32 actions the step kernel consumes.
 //
 // MFMA 32x32x8 f16 fragment layout (lane l, g = l >> 5, i = l & 31):
 //     A: row i, k = 4 g + j (j = 0..3);   B: column i, k = 4 g + j;   C/D reg r: column i, row (r & 3) + 8 (r >> 2) + 4 g.
@@ -46,7 +47,7 @@ __device__ __forceinline__ uint32_t pol_hash(uint32_t seed, uint32_t a, uint32_t
 // code, so the LDS fragment reads of later steps are issued ahead of the MFMAs of earlier ones
 template <int HP>
 __global__ void __launch_bounds__(128)
-rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, float eps, uint32_t seed, uint32_t step_key,
+rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, int mode, float eps, uint32_t seed, uint32_t step_key,
                        const uint32_t *__restrict__ dyn, int32_t *__restrict__ actions, float *__restrict__ q_out) {
     // dyn != NULL: epsilon (float bits) and step key come from device memory, so that a captured HIP graph of the
     // env-step can be replayed with values an earlier node of the same graph computed
@@ -194,7 +195,15 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
             float bq = qs[wave][lane][0];
             for (int a = 1; a < na; ++a) { const float v = qs[wave][lane][a]; if (v > bq) { bq = v; best = a; } }
             int act = best;
-            if (eps > 0.0f) {
+            if (mode == 1) {
+                // categorical policy (the IPPO head, pfrl_ppo.py:57-60): the outputs are logits, a ~ softmax(logits)
+                float z = 0.0f;
+                for (int a = 0; a < na; ++a) z += __expf(qs[wave][lane][a] - bq);
+                const float u = d_u01(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 2u)) * z;
+                float cum = 0.0f;
+                act = na - 1;
+                for (int a = 0; a < na; ++a) { cum += __expf(qs[wave][lane][a] - bq); if (u < cum) { act = a; break; } }
+            } else if (eps > 0.0f) {
                 const float u = d_u01(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 0u));
                 if (u < eps) act = (int)(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 1u) % (uint32_t)na);
             }

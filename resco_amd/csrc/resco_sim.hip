@@ -706,16 +706,16 @@ extern "C" int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax
     return RS_OK;
 }
 
-extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, float epsilon, uint32_t seed, uint32_t step_key,
+extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, int32_t mode, float epsilon, uint32_t seed, uint32_t step_key,
                            const void *dyn, int32_t *actions, float *q, void *stream) {
-    if (!p || !obs || !actions || n_envs <= 0) return RS_EINVAL;
+    if (!p || !obs || !actions || n_envs <= 0 || mode < 0 || mode > 1) return RS_EINVAL;
     if (hipSetDevice(p->device) != hipSuccess) return RS_EHIP;
-    typedef void (*pol_fn)(PolicyTab, const __half *, int, float, uint32_t, uint32_t, const uint32_t *, int32_t *, float *);
+    typedef void (*pol_fn)(PolicyTab, const __half *, int, int, float, uint32_t, uint32_t, const uint32_t *, int32_t *, float *);
     static const pol_fn kernels[9] = {nullptr, rs_idqn_forward_kernel<1>, rs_idqn_forward_kernel<2>, rs_idqn_forward_kernel<3>,
                                       rs_idqn_forward_kernel<4>, rs_idqn_forward_kernel<5>, rs_idqn_forward_kernel<6>,
                                       rs_idqn_forward_kernel<7>, rs_idqn_forward_kernel<8>};
     hipLaunchKernelGGL(kernels[p->W.hp], dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(128), 0, (hipStream_t)stream,
-                       p->W, (const __half *)obs, (int)n_envs, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
+                       p->W, (const __half *)obs, (int)n_envs, (int)mode, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_EHIP;
 }
 

@@ -684,3 +684,60 @@ def test_fused_idqn_policy_matches_torch_reference(map_name, n):
     torch.cuda.synchronize()
     assert torch.equal(q_dev, q_host) and not torch.allclose(q_dev[:, 0, :2], q[:, 0, :2])
     env.close()
+
+
+def test_fused_policy_sampling_mode_follows_the_softmax():
+    """rs_idqn_act mode 1 (IPPO head on the same trunk): actions are drawn from softmax(logits) with the counter
+    hash; over many environments x step keys the empirical action frequencies match the mean probabilities the
+    PyTorch forward gives (4 sigma), the draw is a pure function of (seed, env, signal, step key), and an acting /
+    PPO-update / device re-pack cycle runs."""
+    import torch
+    from resco_amd.agents.idqn_fused import FusedIDQN
+    from resco_amd.agents.ippo import BatchedIPPO, BatchedPPOLearner
+    from resco_amd.multi_signal import VecMultiSignal
+    n = 1024
+    env = VecMultiSignal('cologne8', n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=1)
+    net = BatchedIPPO.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
+    net.init_like_reference(seed=2)
+    with torch.no_grad():
+        net.fc3_w.mul_(40.0)                    # the fresh 1e-2 head is almost uniform: make the policy informative
+    policy = FusedIDQN(net, seed=5)
+    obs = env.reset()['drq_norm_f16']
+    for k in range(10):
+        env.act_random(k)
+        obs = env.step(None)[0]['drq_norm_f16']
+    p = torch.softmax(net(obs)[0].float(), -1).detach()                  # [n, S, Amax]
+    S, A = env.n_signals, net.amax
+    counts = torch.zeros(S, A, device='cuda')
+    keys = 24
+    for key in range(keys):
+        a = policy.act(obs, step_key=key, sample=True).long()
+        assert all(int(a[:, s].max()) < net.actions[s] for s in range(S))
+        counts.scatter_add_(1, a.t().contiguous(), torch.ones(S, n, device='cuda'))
+    a_again = policy.act(obs, step_key=keys - 1, sample=True).long()
+    assert torch.equal(a, a_again)
+    freq = (counts / (n * keys)).cpu().numpy()
+    mean_p = p.mean(0).cpu().numpy()
+    sigma = np.sqrt(np.maximum(mean_p * (1 - mean_p), 1e-4) / (n * keys))
+    assert np.all(np.abs(freq - mean_p) < 4 * sigma + 2e-3), np.abs(freq - mean_p).max()
+    assert mean_p.max() > 0.4                                             # the test policy is not uniform
+    # one short acting / learning cycle
+    learner = BatchedPPOLearner(net, minibatch=2048, epochs=2)
+    T = 4
+    ob = torch.zeros(T, n, S, net.lmax, 5, dtype=torch.float16, device='cuda')
+    ac = torch.zeros(T, n, S, dtype=torch.int32, device='cuda')
+    rw = torch.zeros(T, n, S, device='cuda')
+    for t in range(T):
+        ob[t].copy_(obs)
+        policy.act(obs, step_key=100 + t, out=env.tensor('actions'), sample=True)
+        o, r, _, _ = env.step(None)
+        ac[t].copy_(env.tensor('actions'))
+        rw[t].copy_(r['wait_norm'])
+        obs = o['drq_norm_f16']
+    w0 = net.fc2_w.detach().clone()
+    loss = learner.update(ob, ac, rw, torch.zeros(T, dtype=torch.bool, device='cuda'), obs)
+    policy.refresh_on_device()
+    policy.act(obs, step_key=999, sample=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and not torch.equal(w0, net.fc2_w.detach()) and learner.n_updates == 2 * 2
+    env.close()
