@@ -70,15 +70,21 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
                               avg_delay_s=round(d, 2), arrived_per_env=round(arrived, 1), updates=learner.n_updates,
                               env_steps_per_s=round(n * steps / dt), ms_per_step=round(dt / steps * 1e3, 3))), flush=True)
 
-    env.sim.set_seed(12345)                             # greedy evaluation on the baseline's demand seed
-    obs = env.reset()['drq_norm_f16']
-    for k in range(steps):
-        policy.act(obs, out=actions)
-        o, _, _, _ = env.step(None)
-        obs = o['drq_norm_f16']
-    g_delay, _ = delay(env)
+    # greedy evaluation with the final weights (no further learning): on the baseline's seed and on the seed the last
+    # training episode used - DQN keeps adapting within an episode, so a frozen copy can do worse than the last
+    # training episodes did
+    evals = {}
+    for seed in (12345, 1000 + episodes - 1):
+        env.sim.set_seed(seed)
+        obs = env.reset()['drq_norm_f16']
+        for k in range(steps):
+            policy.act(obs, out=actions)
+            o, _, _, _ = env.step(None)
+            obs = o['drq_norm_f16']
+        evals[seed] = round(delay(env)[0], 2)
     print(json.dumps(dict(map=map_name, envs=n, episodes=episodes, batch=batch, updates_per_step=updates,
-                          greedy_avg_delay_s=round(g_delay, 2), random_avg_delay_s=round(rnd_delay, 2))))
+                          greedy_avg_delay_s=evals[12345], greedy_on_last_training_seed_s=evals[1000 + episodes - 1],
+                          random_avg_delay_s=round(rnd_delay, 2))))
     env.close()
 
 
