@@ -227,11 +227,12 @@ struct KTab {
     const FoeRec *foes;
     const RStep *rsteps;
     const uint32_t *route_mask2;
+    const uint16_t *next_link;      // [n_route_steps][kmax]: choose_link() of a normal lane, 0xFFFF: none
     const RouteRec *routes;
     const uint16_t *trip_route;
     const uint8_t *trip_vtype;
     const KCold *cold;
-    int32_t n_trips, tls_maxl;
+    int32_t n_trips, tls_maxl, kmax;
     int32_t n_lanes, n_cells, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
 };
 
@@ -344,30 +345,22 @@ __device__ __forceinline__ void heads_clear(uint16_t *head, int n_lanes, int tid
     for (int i = tid; i < (n_lanes + 2) / 2; i += B) ((uint32_t *)head)[i] = 0x7FFF7FFFu;
 }
 
-// the link a vehicle on `lane` (record LR) takes at route step rq; -1: none (last edge / wrong lane)
-__device__ __forceinline__ int choose_link(const KTab &T, const LaneRec &LR, int rq) {
-    const int ls = LR.link_start, lc = LR.link_cnt;
-    if (lc == 0) return -1;
-    if (LR.flags & LF_INTERNAL) return ls;
-    const RStep R = T.rsteps[rq];
-    if (R.next_edge == 0xFFFF) return -1;
-    int best = -1, any = -1;
-    for (int l = ls; l < ls + lc; ++l) {
-        const LinkRec K = T.links[l];
-        COUNT(15, 1);
-        if (K.to_edge != R.next_edge) continue;
-        if ((R.next_mask2 >> K.dest_k) & 1u) return l;
-        if (best < 0 && ((R.next_mask1 >> K.dest_k) & 1u)) best = l;
-        if (any < 0) any = l;
-    }
-    return best >= 0 ? best : any;
+// the link a vehicle on lane `lane` (record LR) takes at route step rq; -1: none (last edge / wrong lane).  For a normal
+// lane it is a function of (route step, lane index on the edge) only: rs_create tabulates it (prefer a destination
+// lane from which the route goes on without a lane change, then one from which it still can, then any connection
+// to the next edge), so the look-ahead does one gather per hop instead of a route-step fetch plus a scan of the links
+__device__ __forceinline__ int choose_link(const KTab &T, const LaneRec &LR, int lane, int rq) {
+    if (LR.link_cnt == 0) return -1;
+    if (LR.flags & LF_INTERNAL) return LR.link_start;
+    const int v = T.next_link[rq * T.kmax + (lane - (int)LR.edge_lane0)];
+    return v == 0xFFFF ? -1 : v;
 }
 
 // value cached in L.nlink: the link index (0x7FFF: none) with bit 15 set when the link owns an approach register
 #define NLINK_NONE 0x7FFF
 #define NLINK_ARR 0x8000
-__device__ __forceinline__ uint16_t cache_link(const KTab &T, const LaneRec &LR, int rq) {
-    const int link = choose_link(T, LR, rq);
+__device__ __forceinline__ uint16_t cache_link(const KTab &T, const LaneRec &LR, int lane, int rq) {
+    const int link = choose_link(T, LR, lane, rq);
     if (link < 0) return NLINK_NONE;
     return (uint16_t)(link | (T.links[link].arr_idx >= 0 ? NLINK_ARR : 0));
 }
@@ -604,7 +597,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 L.vt[s] = T.trip_vtype[tr];
                 if (ln != LANE_PENDING) {
                     const LaneRec LR0 = T.lanes[ln];
-                    L.nlink[s] = cache_link(T, LR0, rq);
+                    L.nlink[s] = cache_link(T, LR0, ln, rq);
                     L.node[s].nxt = list_push(hc, LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0)), s, sp > HALT_SPEED);
                 } else {
                     npend += 1;
@@ -762,11 +755,12 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
             if (link == NLINK_NONE) link = -1;
             if (!found && seen < look && !DIAG_SKIP(2)) {
                 COUNT(18, 1);
+                int cur_lane = lane;
                 const float bgv = d_brake_gap(v, b);        // can I still stop in front of a red / yellow light?
                 for (int hop = 0; hop < MAX_HOPS; ++hop) {
                     COUNT(11, 1);
                     const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
-                    if (hop > 0) link = choose_link(T, LR, rq);
+                    if (hop > 0) link = choose_link(T, LR, cur_lane, rq);
                     bool stop_here = false;
                     LinkRec K;
                     if (link < 0) {
@@ -788,6 +782,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                         break;
                     }
                     LR = K.dest;
+                    cur_lane = K.to_lane;
                     {   // slow down in time for a lower speed limit on the next lane
                         float vnl = LR.vmax * sf;
                         if (vnl < vfree) {
@@ -861,7 +856,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     if (!(x > LR.len)) break;
                     COUNT(14, 1);
                     const bool li = (LR.flags & LF_INTERNAL) != 0;
-                    if (moved) link = choose_link(T, LR, rq);
+                    if (moved) link = choose_link(T, LR, lane, rq);
                     if (link < 0) {
                         if (!li && T.rsteps[rq].next_edge == 0xFFFF) arrived = true; else x = LR.len;
                         break;
@@ -890,7 +885,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                     L.node[s].pos = x;
                     if (moved) {
                         L.lane[s] = (uint16_t)lane; L.rq[s] = (uint16_t)rq;
-                        L.nlink[s] = cache_link(T, LR, rq);
+                        L.nlink[s] = cache_link(T, LR, lane, rq);
                     }
                     active += 1;
                     top = s + 1;
@@ -1000,7 +995,7 @@ rs_step_kernel(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ ac
                 const int target = __float_as_int(L.vnx[s]);
                 if (L.lane[s] < LANE_PENDING && target >= 0) {
                     L.lane[s] = (uint16_t)target;
-                    L.nlink[s] = cache_link(T, T.lanes[target], L.rq[s]);
+                    L.nlink[s] = cache_link(T, T.lanes[target], target, L.rq[s]);
                 }
             }
             SYNC();

@@ -302,6 +302,30 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         std::vector<uint16_t> trip_route((size_t)sc->n_trips);
         std::vector<uint8_t> trip_vtype((size_t)sc->n_trips);
         for (int k = 0; k < sc->n_trips; ++k) { trip_route[k] = (uint16_t)sc->trip_route[k]; trip_vtype[k] = (uint8_t)sc->trip_vtype[k]; }
+        // choose_link() of every (route step, lane of that step's edge): the look-ahead and the lane hand-over read it
+        int kmax = 1;
+        for (int e = 0; e < sc->n_edges; ++e) if (sc->edge_nlanes[e] > kmax) kmax = sc->edge_nlanes[e];
+        std::vector<uint16_t> next_link((size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1) * kmax, (uint16_t)0xFFFF);
+        for (int r = 0; r < sc->n_routes; ++r) {
+            const int rs = sc->route_start[r], re = sc->route_start[r + 1];
+            for (int q = rs; q + 1 < re; ++q) {
+                const int e = sc->route_edge[q], ne = sc->route_edge[q + 1];
+                const uint32_t pref = sc->route_mask2[q + 1], okm = sc->route_mask1[q + 1];
+                for (int k = 0; k < sc->edge_nlanes[e]; ++k) {
+                    const int ln = sc->edge_lane0[e] + k;
+                    int link = -1, best = -1, any = -1;
+                    for (int l = sc->lane_link_start[ln]; l < sc->lane_link_start[ln] + sc->lane_link_cnt[ln]; ++l) {
+                        if (sc->link_to_edge[l] != ne) continue;
+                        const int kk = sc->link_dest_lane[l] - sc->edge_lane0[ne];
+                        if ((pref >> kk) & 1u) { link = l; break; }
+                        if (best < 0 && ((okm >> kk) & 1u)) best = l;
+                        if (any < 0) any = l;
+                    }
+                    if (link < 0) link = best >= 0 ? best : any;
+                    if (link >= 0) next_link[(size_t)q * kmax + k] = (uint16_t)link;
+                }
+            }
+        }
         std::vector<uint8_t> tls8((size_t)(sc->n_tls_states > 0 ? sc->n_tls_states : 1)), fix8((size_t)(sc->n_fix_states > 0 ? sc->n_fix_states : 1));
         for (int i = 0; i < sc->n_tls_states; ++i) tls8[i] = (uint8_t)sc->tls_states[i];
         for (int i = 0; i < sc->n_fix_states; ++i) fix8[i] = (uint8_t)sc->fix_states[i];
@@ -311,12 +335,14 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         if ((rc = dev_upload<LaneRec>(h, &K.lanes, lanes.data(), lanes.size())) || (rc = dev_upload<LinkRec>(h, &K.links, links.data(), links.size())) ||
             (rc = dev_upload<FoeRec>(h, &K.foes, foes.data(), foes.size())) || (rc = dev_upload<RStep>(h, &K.rsteps, rsteps.data(), rsteps.size())) ||
             (rc = dev_upload<RouteRec>(h, &K.routes, routes.data(), routes.size())) ||
+            (rc = dev_upload<uint16_t>(h, &K.next_link, next_link.data(), next_link.size())) ||
             (rc = dev_upload<uint16_t>(h, &K.trip_route, trip_route.data(), trip_route.size())) ||
             (rc = dev_upload<uint8_t>(h, &K.trip_vtype, trip_vtype.data(), trip_vtype.size())) ||
             (rc = dev_upload<int16_t>(h, &lane_obs_dev, lane_obs16.data(), lane_obs16.size())) ||
             (rc = dev_upload<uint8_t>(h, &tls8_dev, tls8.data(), tls8.size())) || (rc = dev_upload<uint8_t>(h, &fix8_dev, fix8.data(), fix8.size())))
             return fail(rc);
         K.route_mask2 = T.route_mask2;
+        K.kmax = kmax;
         KCold cold{};
         cold.trip_depart = T.trip_depart; cold.trips_cum = T.trips_cum; cold.vtype_params = T.vtype_params;
         cold.tls8 = tls8_dev; cold.fix8 = fix8_dev; cold.lane_obs = lane_obs_dev;
