@@ -46,6 +46,7 @@ class DeviceReplay:
         self.head = 0           # next slot to write
         self.count = 0          # slots written so far (saturates at T)
         self._sig = torch.arange(S, device=device)
+        self._pos = torch.zeros(2, dtype=torch.int64, device=device)     # [head, count] mirrored on the device (graph replay)
 
     def __len__(self):
         """Number of complete transitions that can be sampled (per signal)."""
@@ -64,6 +65,8 @@ class DeviceReplay:
         self.done[i] = bool(done)
         self.head = (i + 1) % self.T
         self.count = min(self.count + 1, self.T)
+        self._pos[0] = self.head
+        self._pos[1] = self.count
 
     def push(self, obs, act, rew, done):
         """obs [N,S,L,5], act [N,S] int, rew [N,S] float, done bool (lock-step: one flag for all envs)."""
@@ -84,6 +87,22 @@ class DeviceReplay:
         sig = self._sig
         return (self.obs[t, e, sig], self.act[t, e, sig].long(), self.rew[t, e, sig], self.obs[t2, e, sig],
                 self.done[t].to(torch.float32))
+
+
+def _sample_from_device_position(rp, batch_size):
+    """DeviceReplay.sample with the ring position read from device memory and PyTorch's default generator: every value
+    that changes between calls lives on the device, so the call can be captured in a HIP graph and replayed."""
+    dev = rp.obs.device
+    B, S = int(batch_size), rp.S
+    head, count = rp._pos[0], rp._pos[1]
+    n_ok = torch.clamp(count - 1, min=1)
+    k = (torch.rand(B, S, device=dev) * n_ok).long().clamp_(max=rp.T - 2)
+    k = torch.minimum(k, n_ok - 1)
+    t = torch.remainder(head - count + k, rp.T)
+    e = torch.randint(0, rp.N, (B, S), device=dev)
+    t2 = torch.remainder(t + 1, rp.T)
+    sig = rp._sig
+    return (rp.obs[t, e, sig], rp.act[t, e, sig].long(), rp.rew[t, e, sig], rp.obs[t2, e, sig], rp.done[t].to(torch.float32))
 
 
 def linear_epsilon(t, start, end, decay_steps):
@@ -133,6 +152,42 @@ class BatchedDQNLearner:
         self.n_updates += 1
         return loss.detach()
 
+    def capture_update(self, replay, warmup=3):
+        """Capture [sample a minibatch per signal -> loss -> backward -> Adam step] as ONE HIP graph.  The ~150 small
+        kernels of an update are launch-bound (S = 21 networks x batch 256 is little work each); replaying the graph
+        removes the launch gaps.  Needs >= 2 slots in the ring and an Adam created with capturable=True (done here,
+        optimiser state is carried over by re-creating it before any update has run)."""
+        assert self.n_updates == 0 and len(replay) >= 1
+        self.opt = torch.optim.Adam(self.q.parameters(), lr=self.opt.param_groups[0]['lr'], capturable=True)
+        self._graph_replay = replay
+
+        def one():
+            self.opt.zero_grad(set_to_none=False)
+            loss = self.loss(*_sample_from_device_position(replay, self.batch_size))
+            loss.backward()
+            self.opt.step()
+            return loss.detach()
+
+        state = {k: v.detach().clone() for k, v in self.q.state_dict().items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for p_ in self.q.parameters():
+                p_.grad = torch.zeros_like(p_)
+            for _ in range(warmup):
+                one()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_loss = one()
+        # the warm-up / capture iterations were real updates: rewind weights and optimiser to where they started
+        self.q.load_state_dict(state)
+        for st_ in self.opt.state.values():
+            for v in st_.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        return self
+
     def sync_target(self):
         self.target.load_state_dict(self.q.state_dict())
 
@@ -143,7 +198,12 @@ class BatchedDQNLearner:
         out = None
         if len(replay) >= self.batch_size:
             for _ in range(updates):
-                out = self.update(replay.sample(self.batch_size, generator))
+                if getattr(self, '_graph', None) is not None and replay is self._graph_replay:
+                    self._graph.replay()
+                    self.n_updates += 1
+                    out = self._graph_loss
+                else:
+                    out = self.update(replay.sample(self.batch_size, generator))
         if self.t % self.target_update == 0:
             self.sync_target()
         return out

@@ -602,7 +602,7 @@ def test_idqn_training_loop_on_device():
     env = VecMultiSignal('cologne3', n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=2)
     net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
     net.init_like_reference(seed=0)
-    w0 = net.fc3_w.detach().clone()
+    w0, w0_fc2 = net.fc3_w.detach().clone(), net.fc2_w.detach().clone()
     learner = BatchedDQNLearner(net, batch_size=32, target_update=10)
     replay = DeviceReplay(16, n, env.n_signals, net.lmax, device='cuda')
     gen = torch.Generator(device='cuda').manual_seed(0)
@@ -614,10 +614,15 @@ def test_idqn_training_loop_on_device():
         o, r, done, _ = env.step(a)
         replay.commit(a, r['wait_norm'], done)
         seen.append((o['drq_norm_f16'].clone(), a.clone(), r['wait_norm'].clone()))
+        if learner.n_updates == 0 and len(replay) >= 32 and getattr(learner, '_graph', None) is None:
+            learner.capture_update(replay)      # [sample -> loss -> backward -> Adam] replays as one HIP graph from here on
+            w_cap = net.fc2_w.detach().clone()
+            assert torch.equal(w_cap, w0_fc2)                                # capture leaves the weights where they were
         loss = learner.observe_step(replay, gen)
         obs = o['drq_norm_f16']
     torch.cuda.synchronize()
-    assert learner.n_updates == 23 and torch.isfinite(loss)
+    assert learner.n_updates == 23 and torch.isfinite(loss) and learner._graph is not None
+    assert not torch.equal(w_cap, net.fc2_w.detach())                       # the replayed graph really updates the weights
     assert not torch.equal(w0, net.fc3_w.detach())
     # the ring holds the last 16 steps; slot (k mod 16) = what the agents saw / did / got at step k
     for k in (8, 15, 23):

@@ -2,7 +2,7 @@
 """IDQN training loop entirely on the GPU: HIP simulator -> fp16 observations -> fused HIP policy kernel
 (rs_idqn_act) -> device replay ring -> batched DQN update (PyTorch) -> weights re-packed on the device.  Nothing crosses PCIe per step except the launch calls.
 
-    python tools/idqn_train.py [map] [n_envs] [episodes] [batch] [updates_per_step]
+    python tools/idqn_train.py [map] [n_envs] [episodes] [batch] [updates_per_step] [nograph]
 
 Prints one JSON line per episode (mean episode return of rewards.wait_norm per signal, average trip delay as
 utils/readXML.py computes it, epsilon, env-steps/s including learning) and a final line comparing with the
@@ -27,7 +27,7 @@ def delay(env):
     return float(env.sim.trip_delay().mean()), float(env.sim.stats()['arrived'].mean())
 
 
-def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
+def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1, use_graph=True):
     env = VecMultiSignal(map_name, n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=0)
     S, steps = env.n_signals, env.horizon_steps
     net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
@@ -60,6 +60,8 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
             rew = r['wait_norm']
             replay.commit(actions, rew, done)
             ret += rew
+            if use_graph and learner.n_updates == 0 and getattr(learner, '_graph', None) is None and len(replay) >= batch:
+                learner.capture_update(replay)      # [sample -> loss -> backward -> Adam] as one HIP graph
             if learner.observe_step(replay, gen, updates) is not None:
                 policy.refresh_on_device()
             obs = o['drq_norm_f16']
@@ -91,4 +93,4 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1):
 if __name__ == '__main__':
     a = sys.argv[1:]
     main(a[0] if len(a) > 0 else 'cologne1', int(a[1]) if len(a) > 1 else 256, int(a[2]) if len(a) > 2 else 12,
-         int(a[3]) if len(a) > 3 else 256, int(a[4]) if len(a) > 4 else 1)
+         int(a[3]) if len(a) > 3 else 256, int(a[4]) if len(a) > 4 else 1, (a[5] != 'nograph') if len(a) > 5 else True)
