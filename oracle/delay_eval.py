@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Model-fidelity study on the CPU oracle (TEST INFRASTRUCTURE, lives under oracle/ on purpose).
+
+Average trip delay (timeLoss + departDelay, the figure resco_benchmark/utils/readXML.py:16-77 computes)
+of the static controllers, E environments x one 360-step episode each, one process per core.  Used to
+explore changes of the microsimulation model against the reference's published bands
+(resco_benchmark/utils/avg_timeLoss.py) without a GPU; the HIP path is checked against the same bands in
+tests/test_gpu_parity.py::test_delay_band.
+
+  python oracle/delay_eval.py [map ...] [--policies FIXED,MAXWAVE] [--envs 8] [--diag]
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+REF = {  # avg delay (s) over the published episodes of utils/avg_timeLoss.py: (mean, median)
+    ('cologne1', 'FIXED'): (56.61, 56.85), ('cologne1', 'MAXWAVE'): (27.81, 27.94), ('cologne1', 'MAXPRESSURE'): (65.85, 31.09),
+    ('cologne3', 'FIXED'): (46.35, 39.04), ('cologne3', 'MAXWAVE'): (90.67, 21.95), ('cologne3', 'MAXPRESSURE'): (162.28, 28.05),
+    ('cologne8', 'FIXED'): (63.77, 64.21), ('cologne8', 'MAXWAVE'): (21.87, 21.85), ('cologne8', 'MAXPRESSURE'): (47.73, 29.71),
+    ('ingolstadt1', 'FIXED'): (39.40, 39.47), ('ingolstadt1', 'MAXWAVE'): (28.32, 27.99), ('ingolstadt1', 'MAXPRESSURE'): (23.62, 23.61),
+    ('ingolstadt7', 'FIXED'): (91.31, 91.45), ('ingolstadt7', 'MAXWAVE'): (80.56, 80.31), ('ingolstadt7', 'MAXPRESSURE'): (46.82, 46.41),
+    ('ingolstadt21', 'FIXED'): (133.10, 130.37), ('ingolstadt21', 'MAXWAVE'): (76.32, 69.61),
+    ('ingolstadt21', 'MAXPRESSURE'): (136.72, 115.61),
+}
+MAX_DISTANCE = {'FIXED': 200, 'MAXWAVE': 50, 'MAXPRESSURE': 200, 'STOCHASTIC': 1}
+
+
+def trip_delay(env, sc):
+    """what BatchedSim.trip_delay() computes, on one oracle environment"""
+    st = env.stats()
+    v = env.vehicles()
+    lane = v['lane']
+    running = float((v['time_loss'] * (lane < 0xFFFE)).sum())
+    waited, n_wait = env.backlog_delay()
+    trips = st['inserted'] + n_wait
+    return (st['sum_time_loss_q10'] / 1024.0 + running + st['sum_depart_delay'] + waited) / max(1, trips)
+
+
+def run_env(name, policy, env_index, seed, steps):
+    """one oracle environment driven by `policy` for `steps` env-steps; returns (env, scenario)"""
+    from oracle.pyoracle import OracleEnv, lib
+    from resco_amd.scenario import Scenario
+    from resco_amd.sim import maxwave_tables
+    sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
+    env = OracleEnv(sc, env_index=env_index, seed=seed, sigma=-1.0, speed_dev=1, max_distance=MAX_DISTANCE[policy],
+                    fixed_program=1 if policy == 'FIXED' else 0)
+    env.observe()
+    S = sc.n_signals
+    G = [int(g) for g in sc.tls_ngreen]
+    pairs, valid, order = maxwave_tables(sc)
+    L = lib()
+    for k in range(steps):
+        a = np.zeros(S, np.int32)
+        if policy in ('MAXWAVE', 'MAXPRESSURE'):
+            out = env.outputs()
+            obs = out['wave'] if policy == 'MAXWAVE' else out['mplight'][:, 1:]
+            for s in range(S):
+                best, have = 0, False
+                for j in range(len(pairs)):
+                    p = order[s, j]
+                    if p < 0:
+                        break
+                    act = valid[s, p]
+                    if act < 0:
+                        continue
+                    press = obs[s, pairs[p, 0]] + obs[s, pairs[p, 1]]
+                    if not have or press > best:
+                        have, best, a[s] = True, press, act
+        elif policy == 'STOCHASTIC':
+            for s in range(S):
+                a[s] = L.orc_hash((seed ^ 0xA5A5A5A5) & 0xFFFFFFFF, env_index, s, k, 7) % G[s]
+        env.step(a)
+    return env, sc
+
+
+def episode(job):
+    env, sc = run_env(*job)
+    st = env.stats()
+    return dict(delay=trip_delay(env, sc), arrived=st['arrived'], inserted=st['inserted'], pending=st['pending'],
+                mean_active=st['active_ticks'] / max(1, st['ticks']),
+                duration=st['sum_duration'] / max(1, st['arrived']))
+
+
+def run(name, policy, envs=8, seed=0, steps=360, pool=None):
+    jobs = [(name, policy, e, seed, steps) for e in range(envs)]
+    rows = pool.map(episode, jobs) if pool is not None else [episode(j) for j in jobs]
+    d = np.array([r['delay'] for r in rows])
+    return dict(map=name, policy=policy, envs=envs, avg_delay=float(d.mean()), median_delay=float(np.median(d)),
+                arrived=float(np.mean([r['arrived'] for r in rows])), inserted=float(np.mean([r['inserted'] for r in rows])),
+                pending=float(np.mean([r['pending'] for r in rows])), mean_active=float(np.mean([r['mean_active'] for r in rows])),
+                avg_duration=float(np.mean([r['duration'] for r in rows])), reference_delay=REF.get((name, policy)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('maps', nargs='*', default=['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'])
+    ap.add_argument('--policies', default='FIXED,MAXWAVE,MAXPRESSURE')
+    ap.add_argument('--envs', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=360)
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+    from oracle.pyoracle import build
+    build()
+    with mp.get_context('fork').Pool(min(args.envs, os.cpu_count() or 1)) as pool:
+        for m in args.maps:
+            for pol in args.policies.split(','):
+                r = run(m, pol, args.envs, args.seed, args.steps, pool)
+                ref = r['reference_delay']
+                print('%-13s %-12s delay %7.1f (ref %s)  arrived %6.0f inserted %6.0f pending %5.0f  V %6.1f  dur %6.1f'
+                      % (m, pol, r['avg_delay'], ('%.1f/%.1f' % ref) if ref else '-', r['arrived'], r['inserted'],
+                         r['pending'], r['mean_active'], r['avg_duration']), flush=True)
+                print(json.dumps(r), file=sys.stderr, flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -55,6 +55,7 @@ def lib():
         L.orc_get_vehicles.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_backlog.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_trip_log.argtypes = [C.c_void_p]
         L.orc_trip_log.restype = C.POINTER(C.c_int32)
         L.orc_wtot.argtypes = [C.c_void_p]
@@ -149,6 +150,15 @@ class OracleEnv:
         lib().orc_debug(self._h, C.byref(r), C.byref(b))
         cap = self.sc.capacity
         return np.ctypeslib.as_array(r, shape=(cap,)).copy(), np.ctypeslib.as_array(b, shape=(cap,)).copy()
+
+    def backlog_delay(self, per_lane=False):
+        """(seconds waited so far, count) over the trips that have departed but are not on the network yet"""
+        out = (C.c_int64 * 2)()
+        pl = np.zeros(self.sc.n_lanes, np.int32)
+        lib().orc_backlog(self._h, out, pl.ctypes.data)
+        if per_lane:
+            return float(out[1]), int(out[0]), pl
+        return float(out[1]), int(out[0])
 
     def stats(self):
         out = (C.c_int64 * 10)()

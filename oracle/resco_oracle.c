@@ -27,8 +27,39 @@
 #define BIGF 1.0e30f
 #define SG_ADVANTAGE 10.0f
 #define URGENT_DIST 50.0f
+#define GOOD_CONT 450.0f    /* a lane that can be followed this far is as good as the best one when connections are chosen */
+#define MIN_LC_LEN 5.0f      /* an edge shorter than this cannot host a lane change: do not enter it on a lane the route cannot leave */
 #define SWAP_WAIT 20      /* a mutual block is broken up after both vehicles have stood for this many seconds ... */
 #define SWAP_EVERY 4      /* ... and is looked for on every 4th tick only */
+static float X_VIS = 4.5f;
+static float X_FOE = 40.0f;
+static int X_INIT = 0;
+static int X_FIRST = 1;
+static int X_COOP = 2;
+static int X_ALT = 1;
+static int X_LAV = 1;
+static float X_LAT = 10.0f, X_LAB = 10.0f, X_URG = 50.0f, X_GOOD = 450.0f, X_SGA = 10.0f, X_LAMIN = 5.0f;
+static int X_EXTRA = 2, X_SWAPW = 20;
+static float X_COOPR = 50.0f;
+static void x_init(void) {
+    if (X_INIT) return;
+    X_INIT = 1;
+    if (getenv("X_VIS")) X_VIS = (float)atof(getenv("X_VIS"));
+    if (getenv("X_FIRST")) X_FIRST = atoi(getenv("X_FIRST"));
+    if (getenv("X_FOE")) X_FOE = (float)atof(getenv("X_FOE"));
+    if (getenv("X_LAV")) X_LAV = atoi(getenv("X_LAV"));
+    if (getenv("X_LAT")) X_LAT = (float)atof(getenv("X_LAT"));
+    if (getenv("X_LAB")) X_LAB = (float)atof(getenv("X_LAB"));
+    if (getenv("X_LAMIN")) X_LAMIN = (float)atof(getenv("X_LAMIN"));
+    if (getenv("X_URG")) X_URG = (float)atof(getenv("X_URG"));
+    if (getenv("X_GOOD")) X_GOOD = (float)atof(getenv("X_GOOD"));
+    if (getenv("X_SGA")) X_SGA = (float)atof(getenv("X_SGA"));
+    if (getenv("X_EXTRA")) X_EXTRA = atoi(getenv("X_EXTRA"));
+    if (getenv("X_SWAPW")) X_SWAPW = atoi(getenv("X_SWAPW"));
+    if (getenv("X_ALT")) X_ALT = atoi(getenv("X_ALT"));
+    if (getenv("X_COOP")) X_COOP = atoi(getenv("X_COOP"));
+    if (getenv("X_COOPR")) X_COOPR = (float)atof(getenv("X_COOPR"));
+}
 
 enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
 enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
@@ -38,7 +69,14 @@ struct orc_env {
     orc_params p;
     int32_t env_index;
     int32_t t;              /* ticks since begin */
-    int32_t next_trip;      /* trips [0,next_trip) have been given a slot */
+    int32_t n_inserted;     /* trips inserted so far */
+    int32_t n_active;       /* vehicles on the network */
+    int32_t *dep_next;      /* per lane: the next trip that departs from it (-1: none left) -- a FIFO per departure lane */
+    int32_t *trip_next;     /* trip -> next trip with the same departure lane */
+    int32_t *dep_first;     /* per lane: its first trip */
+    int32_t *coop_lead;     /* per slot: the vehicle on my strategic target lane I try to fall in behind (slot, -1 none), with its trip in coop_lead_trip */
+    int32_t *coop_lead_trip;
+    int64_t *coop;          /* per slot: cooperation request of this tick's lane-change phase, (trip << 32 | slot) of the changer, -1 none */
     int32_t hw;             /* high-water mark: slots >= hw are free */
     int32_t *trip;          /* slot -> trip index, -1 free */
     /* vehicles */
@@ -133,7 +171,11 @@ static float speed_factor(const orc_env *e, int32_t trip) {
 static inline int ahead_of(float pj, int32_t kj, float pi, int32_t ki) { /* j strictly ahead of i */
     return pj > pi || (pj == pi && kj < ki);
 }
-static int32_t choose_link(const orc_env *e, int32_t lane, int32_t route, int32_t cursor) {
+/* the link a vehicle on `lane` takes at route position `cursor`: of the connections to the next route edge the one whose
+ * destination lane lets it drive on furthest without a lane change (route_cont, SUMO's bestLanes [SUMO-K]); -1 when the
+ * lane has no connection to the next edge, or only into an edge too short to change lanes on (a dead end for this
+ * route: the vehicle waits here for a lane change) */
+static int32_t choose_link(const orc_env *e, int32_t lane, int32_t route, int32_t cursor, int32_t trip) {
     const orc_scenario *sc = e->sc;
     int32_t ls = sc->lane_link_start[lane], lc = sc->lane_link_cnt[lane];
     if (lc == 0) return -1;
@@ -141,16 +183,49 @@ static int32_t choose_link(const orc_env *e, int32_t lane, int32_t route, int32_
     int32_t rs = sc->route_start[route], rn = sc->route_start[route + 1] - rs;
     if (cursor + 1 >= rn) return -1;
     int32_t ne = sc->route_edge[rs + cursor + 1];
-    uint32_t pref = sc->route_mask2[rs + cursor + 1], okm = sc->route_mask1[rs + cursor + 1];
-    int32_t best = -1, any = -1;
+    const float *cn = sc->route_cont + (size_t)(rs + cursor + 1) * sc->kmax;
+    float bc = -1.0f;
     for (int32_t l = ls; l < ls + lc; ++l) {
         if (sc->link_to_edge[l] != ne) continue;
-        int32_t k = sc->link_dest_lane[l] - sc->edge_lane0[ne];
-        if ((pref >> k) & 1u) return l;                 /* lands on a lane that continues the route */
-        if (best < 0 && ((okm >> k) & 1u)) best = l;    /* lands where a lane change can still fix it */
-        if (any < 0) any = l;
+        float c = cn[sc->link_dest_lane[l] - sc->edge_lane0[ne]];
+        if (c > bc) bc = c;
     }
-    return best >= 0 ? best : any;
+    if (bc < MIN_LC_LEN) return -1;
+    /* parallel connections whose destination lanes are all good enough (the best one, or GOOD_CONT metres without a
+     * lane change) share the traffic: trips alternate between them (SUMO spreads them by lane occupation [SUMO-K]) */
+    int32_t n_acc = 0;
+    for (int32_t l = ls; l < ls + lc; ++l) {
+        if (sc->link_to_edge[l] != ne) continue;
+        float c = cn[sc->link_dest_lane[l] - sc->edge_lane0[ne]];
+        if (c >= bc - 0.5f || c >= X_GOOD) n_acc += 1;
+    }
+    int32_t pick = X_ALT ? trip % n_acc : 0;
+    for (int32_t l = ls; l < ls + lc; ++l) {
+        if (sc->link_to_edge[l] != ne) continue;
+        float c = cn[sc->link_dest_lane[l] - sc->edge_lane0[ne]];
+        if (c >= bc - 0.5f || c >= X_GOOD) { if (pick == 0) return l; pick -= 1; }
+    }
+    return -1;
+}
+/* strategic lane-change need of the vehicle in slot s (on a normal lane): 0 when its lane is as good as any of the edge
+ * or the need is still far away, else the direction (+1 left, -1 right) of the nearest best lane.  *rem = how far it can
+ * still drive on its lane [SUMO-K LC2013: a change is due when rem < lookahead * number of lanes to cross, lookahead =
+ * 10 s at the current speed (at least 5 m/s) + 10 m; `extra` = 2 when asking whether a lane is good enough to move INTO for
+ * speed gain: LC2013 leaves the best lanes only if it can stay away for (lanes + 2) look-aheads] */
+static int32_t strategic_dir_at(const orc_env *e, int32_t route, int32_t cursor, int32_t kk, int32_t n, float x, float v, int extra, float *rem) {
+    const orc_scenario *sc = e->sc;
+    const float *cn = sc->route_cont + (size_t)(sc->route_start[route] + cursor) * sc->kmax;
+    float best = 0.0f;
+    for (int32_t j = 0; j < n; ++j) if (cn[j] > best) best = cn[j];
+    *rem = cn[kk] - x;
+    if (cn[kk] >= best - 0.5f) return 0;
+    int32_t dl = 1000, dr = 1000;
+    for (int32_t j = kk + 1; j < n; ++j) if (cn[j] >= best - 0.5f) { dl = j - kk; break; }
+    for (int32_t j = kk - 1; j >= 0; --j) if (cn[j] >= best - 0.5f) { dr = kk - j; break; }
+    int32_t off = (dr <= dl ? dr : dl) + extra;
+    float la = (v > X_LAMIN ? v : X_LAMIN) * X_LAT + X_LAB;
+    if (*rem >= la * (float)off) return 0;
+    return (dr <= dl) ? -1 : +1;
 }
 static inline int32_t tls_state(const orc_env *e, int32_t link) {
     const orc_scenario *sc = e->sc;
@@ -160,15 +235,16 @@ static inline int32_t tls_state(const orc_env *e, int32_t link) {
         return sc->fix_states[sc->fix_state_off[s] + e->phase[s] * sc->tls_nlinks[s] + sc->link_tls_pos[link]];
     return sc->tls_states[sc->tls_state_off[s] + e->phase[s] * sc->tls_nlinks[s] + sc->link_tls_pos[link]];
 }
-/* departure lane: lowest-index lane of the first edge that continues the route ("best"; SUMO's default
- * "first" would force a lane change on the departure edge) */
+/* departure lane [SUMO-K departLane default "first"]: the right-most lane of the first edge the vehicle may use */
 static inline int32_t depart_lane(const orc_scenario *sc, int32_t route) {
-    int32_t rs = sc->route_start[route];
-    uint32_t m = sc->route_mask2[rs];
-    int32_t k = 0;
-    while (k < 31 && !((m >> k) & 1u)) k += 1;
-    if (k >= sc->edge_nlanes[sc->route_edge[rs]]) k = 0;
-    return sc->edge_lane0[sc->route_edge[rs]] + k;
+    int32_t ed = sc->route_edge[sc->route_start[route]];
+    if (!X_FIRST) {     /* study switch: "best" = the lane with the longest continuation */
+        const float *cn = sc->route_cont + (size_t)sc->route_start[route] * sc->kmax;
+        int32_t bk = 0;
+        for (int32_t j = 1; j < sc->edge_nlanes[ed]; ++j) if (cn[j] > cn[bk]) bk = j;
+        return sc->edge_lane0[ed] + bk;
+    }
+    return sc->edge_lane0[ed];
 }
 static void build_lists(orc_env *e) {
     const orc_scenario *sc = e->sc;
@@ -207,6 +283,7 @@ static void neighbours(const orc_env *e, int32_t lane, float pos, int32_t k, int
 #define ALLOC(p, n) p = calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(*(p)))
 orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_index) {
     orc_env *e = calloc(1, sizeof(orc_env));
+    x_init();
     e->sc = sc; e->p = *p; e->env_index = env_index;
     int32_t C = sc->capacity, S = sc->n_signals, O = sc->n_obs;
     ALLOC(e->lane, C); ALLOC(e->cursor, C); ALLOC(e->sumo_wait, C); ALLOC(e->resco_wait, C); ALLOC(e->depart, C);
@@ -215,6 +292,15 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     if (p->trip_log) ALLOC(e->trip_log, (size_t)sc->n_trips * 4);
     ALLOC(e->lane_head, sc->n_lanes); ALLOC(e->next_in_lane, C); ALLOC(e->link_arr, sc->n_links);
     ALLOC(e->lane_ins, sc->n_lanes);
+    ALLOC(e->dep_next, sc->n_lanes); ALLOC(e->dep_first, sc->n_lanes); ALLOC(e->trip_next, sc->n_trips); ALLOC(e->coop, C); ALLOC(e->coop_lead, C); ALLOC(e->coop_lead_trip, C);
+    {   /* the trips of one departure lane form a FIFO in trip (= departure time) order */
+        for (int32_t l = 0; l < sc->n_lanes; ++l) e->dep_first[l] = -1;
+        for (int32_t k = sc->n_trips - 1; k >= 0; --k) {
+            int32_t dl = depart_lane(sc, sc->trip_route[k]);
+            e->trip_next[k] = e->dep_first[dl];
+            e->dep_first[dl] = k;
+        }
+    }
     ALLOC(e->phase, S); ALLOC(e->left, S); ALLOC(e->next_phase, S);
     ALLOC(e->lane_agg, O * 5); ALLOC(e->drq_norm, O * 5); ALLOC(e->wait, S); ALLOC(e->wait_norm, S);
     ALLOC(e->agg_q, O); ALLOC(e->agg_a, O); ALLOC(e->agg_w, O); ALLOC(e->agg_m, O); ALLOC(e->agg_s, O);
@@ -228,6 +314,7 @@ void orc_destroy(orc_env *e) {
     free(e->lane); free(e->cursor); free(e->sumo_wait); free(e->resco_wait); free(e->depart); free(e->owner);
     free(e->pos); free(e->speed); free(e->accel); free(e->time_loss); free(e->vnext); free(e->lc_target); free(e->trip); free(e->dbg_reason); free(e->dbg_block); free(e->wtot); free(e->trip_log);
     free(e->lane_head); free(e->next_in_lane); free(e->link_arr); free(e->lane_ins);
+    free(e->dep_next); free(e->dep_first); free(e->trip_next); free(e->coop); free(e->coop_lead); free(e->coop_lead_trip);
     free(e->phase); free(e->left); free(e->next_phase);
     free(e->lane_agg); free(e->drq_norm); free(e->wait); free(e->wait_norm);
     free(e->agg_q); free(e->agg_a); free(e->agg_w); free(e->agg_m); free(e->agg_s);
@@ -236,7 +323,9 @@ void orc_destroy(orc_env *e) {
 }
 void orc_reset(orc_env *e) {
     const orc_scenario *sc = e->sc;
-    e->t = 0; e->next_trip = 0; e->hw = 0;
+    e->t = 0; e->n_inserted = 0; e->n_active = 0; e->hw = 0;
+    for (int32_t l = 0; l < sc->n_lanes; ++l) e->dep_next[l] = e->dep_first[l];
+    for (int32_t s = 0; s < sc->capacity; ++s) { e->coop[s] = -1; e->coop_lead[s] = -1; }
     for (int32_t s = 0; s < sc->capacity; ++s) {
         e->lane[s] = LANE_NONE; e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; e->sumo_wait[s] = 0; e->trip[s] = -1;
         e->pos[s] = 0; e->speed[s] = 0; e->accel[s] = 0; e->time_loss[s] = 0; e->cursor[s] = 0; e->depart[s] = 0;
@@ -284,30 +373,14 @@ static void tls_events(orc_env *e) {
 static void insertion(orc_env *e) {
     const orc_scenario *sc = e->sc;
     int32_t C = sc->capacity;
-    /* trips that departed before this tick take the lowest free slots, in trip order */
-    int32_t due = e->t >= 1 ? sc->trips_cum[e->t - 1 <= sc->horizon ? e->t - 1 : sc->horizon] : 0;
-    for (int32_t s = 0; s < C && e->next_trip < due; ++s) {
-        if (e->lane[s] != LANE_NONE) continue;
-        e->trip[s] = e->next_trip++;
-        e->lane[s] = LANE_PENDING;
-        e->pos[s] = 0; e->speed[s] = 0; e->accel[s] = 0; e->time_loss[s] = 0; e->cursor[s] = 0;
-        e->sumo_wait[s] = 0; e->resco_wait[s] = 0; e->owner[s] = OWNER_NONE; e->depart[s] = 0; e->wtot[s] = 0;
-        if (s + 1 > e->hw) e->hw = s + 1;
-    }
-    /* lowest pending trip per departure lane is the candidate */
-    for (int32_t s = 0; s < e->hw; ++s) {
-        int32_t k = e->trip[s];
-        if (e->lane[s] != LANE_PENDING) continue;
-        int32_t r = sc->trip_route[k];
-        int32_t dl = depart_lane(sc, r);
-        if (k < e->lane_ins[dl]) e->lane_ins[dl] = k;
-    }
-    for (int32_t s = 0; s < e->hw; ++s) {
-        int32_t k = e->trip[s];
-        if (e->lane[s] != LANE_PENDING) continue;
-        int32_t r = sc->trip_route[k];
-        int32_t dl = depart_lane(sc, r);
-        if (e->lane_ins[dl] != k) continue;
+    /* [SUMO-K] MSInsertionControl: every departure lane keeps its own backlog; its oldest trip is inserted
+     * (departPos "base", departSpeed 0) as soon as it has departed and the space behind the rear-most vehicle suffices.
+     * All checks read the state before this tick's insertions (lanes are independent of each other). */
+    int32_t room = C - e->n_active;         /* the network holds at most `capacity` vehicles */
+    for (int32_t dl = 0; dl < sc->n_lanes; ++dl) e->lane_ins[dl] = -1;
+    for (int32_t dl = 0; dl < sc->n_lanes; ++dl) {
+        int32_t k = e->dep_next[dl];
+        if (k < 0 || sc->trip_depart[k] > e->t - 1) continue;
         const float *vt = vt_of(e, k);
         float mypos = vt[VT_LENGTH] < sc->lane_len[dl] ? vt[VT_LENGTH] : sc->lane_len[dl];
         int ok = 1;
@@ -316,24 +389,25 @@ static void insertion(orc_env *e) {
             float back = e->pos[o] - vo[VT_LENGTH];
             if (back - mypos - vt[VT_MINGAP] < 0.0f) ok = 0;
         }
-        if (!ok) continue;
-        e->lc_target[s] = dl;        /* staged; applied after every candidate has been checked */
-        e->vnext[s] = mypos;
-        e->lane[s] = LANE_PENDING;   /* unchanged until the apply loop */
-        e->cursor[s] = 0xFFFF;       /* marker: insert me */
+        if (ok) e->lane_ins[dl] = k;
     }
-    for (int32_t s = 0; s < e->hw; ++s) {
-        int32_t k = e->trip[s];
-        if (e->lane[s] != LANE_PENDING) continue;
-        int32_t r = sc->trip_route[k];
-        int32_t dl = depart_lane(sc, r);
-        e->lane_ins[dl] = 0x7FFFFFFF;
-        if (e->cursor[s] != 0xFFFF) continue;
-        e->lane[s] = (uint16_t)dl;
-        e->pos[s] = e->vnext[s];
-        e->speed[s] = 0; e->cursor[s] = 0; e->depart[s] = (uint16_t)e->t;
+    for (int32_t dl = 0; dl < sc->n_lanes && room > 0; ++dl) {      /* lower lane index first when the network is full */
+        int32_t k = e->lane_ins[dl];
+        if (k < 0) continue;
+        int32_t s = 0;
+        while (s < C && e->lane[s] != LANE_NONE) s += 1;           /* lowest free slot (the slot index has no meaning) */
+        if (s >= C) break;
+        const float *vt = vt_of(e, k);
+        e->trip[s] = k; e->lane[s] = (uint16_t)dl;
+        e->pos[s] = vt[VT_LENGTH] < sc->lane_len[dl] ? vt[VT_LENGTH] : sc->lane_len[dl];
+        e->speed[s] = 0; e->accel[s] = 0; e->time_loss[s] = 0; e->cursor[s] = 0;
+        e->sumo_wait[s] = 0; e->resco_wait[s] = 0; e->owner[s] = OWNER_NONE; e->depart[s] = (uint16_t)e->t; e->wtot[s] = 0;
+        e->coop[s] = -1; e->coop_lead[s] = -1;
+        if (s + 1 > e->hw) e->hw = s + 1;
         e->next_in_lane[s] = e->lane_head[dl];
         e->lane_head[dl] = s;
+        e->dep_next[dl] = e->trip_next[k];
+        e->n_inserted += 1; e->n_active += 1; room -= 1;
         e->stats[0] += 1;
         e->stats[3] += e->t - 1 - sc->trip_depart[k];
     }
@@ -345,7 +419,7 @@ static void register_approaches(orc_env *e) {
         int32_t k = e->trip[s];
         if (e->lane[s] >= LANE_PENDING) continue;
         int32_t lane = e->lane[s];
-        int32_t link = choose_link(e, lane, sc->trip_route[k], e->cursor[s]);
+        int32_t link = choose_link(e, lane, sc->trip_route[k], e->cursor[s], k);
         if (link < 0) continue;
         const float *vt = vt_of(e, k);
         float dist = sc->lane_len[lane] - e->pos[s];
@@ -372,7 +446,7 @@ static int foe_blocked(const orc_env *e, int32_t link) {
     for (int32_t i = fs; i < fs + fc; ++i) {
         int32_t f = sc->foe_link[i];
         if (sc->link_tls[f] >= 0 && tls_state(e, f) == TLS_R) continue;
-        if (e->link_arr[f] < FOE_GAP_Q) return 1;
+        if (e->link_arr[f] < (int32_t)X_FOE) return 1;
         if (sc->link_via1[f] >= 0 && lane_has_mover(e, sc->link_via1[f])) return 1;
         if (sc->link_via2[f] >= 0 && lane_has_mover(e, sc->link_via2[f])) return 1;
     }
@@ -407,6 +481,41 @@ static void plan(orc_env *e) {
             found = 1;
             e->dbg_reason[s] = 1; e->dbg_block[s] = lead;
         }
+        /* cooperation [SUMO-K LC2013 informFollower]: a vehicle on the neighbouring lane that has to get into my lane and
+         * found no gap asked me (in the last lane-change phase) to let it in: I follow it as if it were already there,
+         * braking no harder than comfortably */
+        if (e->coop[s] >= 0) {
+            int32_t X = (int32_t)(e->coop[s] & 0xFFFFFFFF), kx = (int32_t)(e->coop[s] >> 32);
+            e->coop[s] = -1;
+            if (e->trip[X] == kx && e->lane[X] < LANE_PENDING && !sc->lane_internal[e->lane[X]] && !sc->lane_internal[lane] &&
+                sc->lane_edge[e->lane[X]] == sc->lane_edge[lane]) {
+                const float *vo = vt_of(e, kx);
+                float backx = e->pos[X] - vo[VT_LENGTH];
+                if (backx >= x) {
+                    float vs = orc_follow_speed(backx - x - mingap, e->speed[X], b, vo[VT_DECEL], tau);
+                    float vc = v - b; if (vc < 0.0f) vc = 0.0f;
+                    if (vs < vc) vs = vc;
+                    if (vs < vsafe) { vsafe = vs; e->dbg_reason[s] = 8; e->dbg_block[s] = X; }
+                }
+            }
+        }
+        /* ... and when I am the one who has to change: fall in behind the vehicle ahead of me on the target lane [informLeader] */
+        if (e->coop_lead[s] >= 0) {
+            int32_t X = e->coop_lead[s], kx = e->coop_lead_trip[s];
+            e->coop_lead[s] = -1;
+            if (X_COOP >= 2 && e->trip[X] == kx && e->lane[X] < LANE_PENDING && !sc->lane_internal[e->lane[X]] && !sc->lane_internal[lane] &&
+                sc->lane_edge[e->lane[X]] == sc->lane_edge[lane]) {
+                const float *vo = vt_of(e, kx);
+                float backx = e->pos[X] - vo[VT_LENGTH];
+                if (e->pos[X] >= x) {
+                    float g = backx - x - mingap;
+                    float vs = orc_follow_speed(g > 0.0f ? g : 0.0f, e->speed[X], b, vo[VT_DECEL], tau);
+                    float vc = v - b; if (vc < 0.0f) vc = 0.0f;
+                    if (vs < vc) vs = vc;
+                    if (vs < vsafe) { vsafe = vs; e->dbg_reason[s] = 9; e->dbg_block[s] = X; }
+                }
+            }
+        }
         /* look ahead along my path */
         float look = orc_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
         float seen = sc->lane_len[lane] - x;
@@ -414,7 +523,7 @@ static void plan(orc_env *e) {
         int32_t rn = sc->route_start[route + 1] - sc->route_start[route];
         for (int hop = 0; hop < MAX_HOPS && !found && seen < look; ++hop) {
             if (!sc->lane_internal[cur] && cur_cursor + 1 >= rn) break;     /* my last edge: free run to its end */
-            int32_t link = choose_link(e, cur, route, cur_cursor);
+            int32_t link = choose_link(e, cur, route, cur_cursor, k);
             if (link < 0) {     /* wrong lane for my route: wait at the end for a lane change */
                 float g = seen - STOP_OFFSET;
                 float vs = orc_stop_speed(g > 0.0f ? g : 0.0f, b, tau);
@@ -426,9 +535,12 @@ static void plan(orc_env *e) {
             if (sc->link_tls[link] >= 0 && (st == TLS_R || st == TLS_Y)) {
                 if (seen >= orc_brake_gap(v, b)) { stop_here = 1; e->dbg_reason[s] = 3; e->dbg_block[s] = link; }
             }
-            if (!stop_here && !sc->link_cont[link] && sc->link_foe_cnt[link] > 0 &&
+            if (!stop_here && !sc->link_cont[link] &&
                 (sc->link_minor[link] || (sc->link_tls[link] >= 0 && st == TLS_g))) {
-                if (foe_blocked(e, link)) { stop_here = 1; e->dbg_reason[s] = 4; e->dbg_block[s] = link; }
+                /* [SUMO-K] MSVehicle::processLinkApproaches: a minor link is approached as if one had to stop until the
+                 * foe lanes can be seen (foe visibility distance 4.5 m) */
+                if (X_VIS > 0.0f && seen > X_VIS) { stop_here = 1; e->dbg_reason[s] = 7; e->dbg_block[s] = link; }
+                else if (sc->link_foe_cnt[link] > 0 && foe_blocked(e, link)) { stop_here = 1; e->dbg_reason[s] = 4; e->dbg_block[s] = link; }
             }
             if (stop_here) {
                 float g = seen - STOP_OFFSET;
@@ -481,7 +593,7 @@ static void move(orc_env *e) {
         int32_t k = e->trip[s];
         if (e->lane[s] >= LANE_PENDING) continue;
         /* clear my approach registration (the table is all-ARR_NONE between ticks) */
-        int32_t lk = choose_link(e, e->lane[s], sc->trip_route[k], e->cursor[s]);
+        int32_t lk = choose_link(e, e->lane[s], sc->trip_route[k], e->cursor[s], k);
         if (lk >= 0) e->link_arr[lk] = ARR_NONE;
     }
     int32_t active = 0;
@@ -505,7 +617,7 @@ static void move(orc_env *e) {
             float len = sc->lane_len[lane];
             if (!(x > len)) break;
             if (!sc->lane_internal[lane] && cursor + 1 >= rn) { arrived = 1; break; }
-            int32_t link = choose_link(e, lane, route, cursor);
+            int32_t link = choose_link(e, lane, route, cursor, k);
             if (link < 0) { x = len; break; }
             x -= len;
             if (!sc->lane_internal[lane]) cursor += 1;
@@ -513,6 +625,7 @@ static void move(orc_env *e) {
         }
         if (arrived) {
             e->lane[s] = LANE_NONE; e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; e->trip[s] = -1;
+            e->n_active -= 1;
             e->stats[1] += 1;
             e->stats[2] += e->t + 1 - e->depart[s];
             e->stats[5] += (int64_t)(e->time_loss[s] * 1024.0f + 0.5f);
@@ -537,16 +650,11 @@ static int32_t swap_dir(const orc_env *e, int32_t s) {
     const orc_scenario *sc = e->sc;
     if (e->lane[s] >= LANE_PENDING) return 0;
     int32_t lane = e->lane[s];
-    if (sc->lane_internal[lane] || e->speed[s] > HALT_SPEED || e->sumo_wait[s] < SWAP_WAIT) return 0;
+    if (sc->lane_internal[lane] || e->speed[s] > HALT_SPEED || e->sumo_wait[s] < X_SWAPW) return 0;
     int32_t ed = sc->lane_edge[lane], n = sc->edge_nlanes[ed], kk = lane - sc->edge_lane0[ed];
-    if (n < 2 || sc->lane_len[lane] - e->pos[s] > URGENT_DIST) return 0;
-    uint32_t m2 = sc->route_mask2[sc->route_start[sc->trip_route[e->trip[s]]] + e->cursor[s]];
-    if ((m2 >> kk) & 1u) return 0;
-    int32_t dl = 1000, dr = 1000;
-    for (int32_t j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
-    for (int32_t j = kk - 1; j >= 0; --j) if ((m2 >> j) & 1u) { dr = kk - j; break; }
-    if (dl == 1000 && dr == 1000) return 0;
-    return (dr <= dl) ? -1 : +1;
+    if (n < 2 || sc->lane_len[lane] - e->pos[s] > X_URG) return 0;
+    float rem;
+    return strategic_dir_at(e, sc->trip_route[e->trip[s]], e->cursor[s], kk, n, e->pos[s], X_LAV ? sc->lane_vmax[lane] : e->speed[s], 0, &rem);
 }
 /* the vehicle on lane tl whose body overlaps mine lengthwise (the nearer one ahead first), NIL: none */
 static int32_t overlapping(const orc_env *e, int32_t s, int32_t tl) {
@@ -571,24 +679,25 @@ static void lane_change(orc_env *e) {
         if (n < 2) continue;
         int32_t kk = lane - sc->edge_lane0[ed];
         int32_t route = sc->trip_route[k];
-        uint32_t m2 = sc->route_mask2[sc->route_start[route] + e->cursor[s]];
-        int32_t tk = kk + dir_allowed;
-        if (tk < 0 || tk >= n) continue;
         const float *vt = vt_of(e, k);
         float x = e->pos[s], v = e->speed[s];
+        int want = 0, dir = dir_allowed;
+        float rem;
+        int32_t sdir = strategic_dir_at(e, route, e->cursor[s], kk, n, x, X_LAV ? sc->lane_vmax[lane] : v, 0, &rem);
+        if (sdir != 0) {
+            /* strategic: head for the nearest lane that continues my route.  The target lane is examined on every tick
+             * (a blocked vehicle asks for cooperation), the change itself happens on the ticks of its direction */
+            dir = sdir;
+            if (dir != dir_allowed && !X_COOP) continue;
+            want = 2;
+        }
+        int32_t tk = kk + dir;
+        if (tk < 0 || tk >= n) continue;
         int32_t tl = sc->edge_lane0[ed] + tk;
-        int want = 0;
         int32_t lead_c, foll_c, lead_t, foll_t;
         neighbours(e, tl, x, k, s, &lead_t, &foll_t);
-        if (!((m2 >> kk) & 1u)) {
-            /* strategic: head for the nearest lane that continues my route */
-            int32_t dl = 1000, dr = 1000;
-            for (int32_t j = kk + 1; j < n; ++j) if ((m2 >> j) & 1u) { dl = j - kk; break; }
-            for (int32_t j = kk - 1; j >= 0; --j) if ((m2 >> j) & 1u) { dr = kk - j; break; }
-            int32_t dir = 0;
-            if (dl < 1000 || dr < 1000) dir = (dr <= dl) ? -1 : +1;
-            want = (dir == dir_allowed) ? 2 : 0;
-        } else if (((m2 >> tk) & 1u) && ((((uint32_t)e->t >> 1) + (uint32_t)k) & 3u) == 0u) {
+        float rem_t;
+        if (!want && ((((uint32_t)e->t >> 1) + (uint32_t)k) & 3u) == 0u && strategic_dir_at(e, route, e->cursor[s], tk, n, x, X_LAV ? sc->lane_vmax[lane] : v, X_EXTRA, &rem_t) == 0) {
             /* speed gain between equally good lanes: more room ahead on the neighbour.  A vehicle reconsiders
              * only on one pair of ticks (one left, one right chance) out of four (LC2013 needs several
              * seconds of accumulated speed-gain incentive before it acts [SUMO-K]) */
@@ -601,13 +710,13 @@ static void lane_change(orc_env *e) {
                     const float *vq = vt_of(e, trip_of_slot(e, lead_t));
                     gtgt = e->pos[lead_t] - vq[VT_LENGTH] - x;
                 }
-                if (gcur < v * 3.0f + 15.0f && gtgt > gcur + SG_ADVANTAGE) want = 1;
+                if (gcur < v * 3.0f + 15.0f && gtgt > gcur + X_SGA) want = 1;
             }
         }
         if (!want) continue;
         /* urgent = strategic change close to the end of the lane: accept tighter gaps (followers may have to
          * brake with their emergency deceleration), otherwise dense queues would never let anybody in */
-        int urgent = want == 2 && (sc->lane_len[lane] - x) <= URGENT_DIST;
+        int urgent = want == 2 && rem <= X_URG;
         int safe = 1;
         if (lead_t != NIL) {
             const float *vo = vt_of(e, trip_of_slot(e, lead_t));
@@ -623,7 +732,22 @@ static void lane_change(orc_env *e) {
             float vb = e->speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
             if (gap < 0.0f || vb > orc_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = 0;
         }
-        if (safe) e->lc_target[s] = tl;
+        if (safe) { if (dir == dir_allowed) e->lc_target[s] = tl; continue; }
+        if (want == 2 && X_COOP && lead_t != NIL) { e->coop_lead[s] = lead_t; e->coop_lead_trip[s] = trip_of_slot(e, lead_t); }
+        if (want == 2 && X_COOP) {
+            /* blocked: ask the nearest vehicle of the target lane that is completely behind me to let me in */
+            float back = x - vt[VT_LENGTH];
+            int32_t R = NIL, Rk = 0;
+            for (int32_t o = e->lane_head[tl]; o != NIL; o = e->next_in_lane[o]) {
+                int32_t ko = trip_of_slot(e, o);
+                if (e->pos[o] > back || back - e->pos[o] > X_COOPR) continue;
+                if (R == NIL || ahead_of(e->pos[o], ko, e->pos[R], Rk)) { R = o; Rk = ko; }
+            }
+            if (R != NIL) {
+                int64_t key = ((int64_t)k << 32) | (int64_t)s;
+                if (e->coop[R] < 0 || key < e->coop[R]) e->coop[R] = key;
+            }
+        }
     }
     /* mutual block at the end of the lanes: two stationary vehicles side by side, each in the lane the other needs */
     /* (an overlapping vehicle makes the regular change above unsafe, and the partner, heading the other way, had
@@ -763,19 +887,28 @@ const int32_t *orc_pressure(const orc_env *e) { return e->pressure; }
 const int32_t *orc_queue_sum(const orc_env *e) { return e->queue_sum; }
 const int32_t *orc_queue_max(const orc_env *e) { return e->queue_max; }
 void orc_get_vehicles(const orc_env *e, orc_vehicles *o) {
-    o->hw = e->hw; o->next_trip = e->next_trip; o->trip = e->trip; o->lane = e->lane; o->pos = e->pos; o->speed = e->speed;
+    o->hw = e->hw; o->next_trip = e->n_inserted; o->trip = e->trip; o->lane = e->lane; o->pos = e->pos; o->speed = e->speed;
     o->accel = e->accel; o->time_loss = e->time_loss; o->cursor = e->cursor; o->sumo_wait = e->sumo_wait;
     o->resco_wait = e->resco_wait; o->depart = e->depart; o->owner = e->owner;
 }
 const int32_t *orc_trip_log(const orc_env *e) { return e->trip_log; }
+/* trips that have departed (depart tick < now) but are not on the network yet: count and seconds waited so far
+ * (utils/readXML.py:52-68 charges end_time - depart for them); per_lane[n_lanes] (may be NULL) receives the count per departure lane */
+void orc_backlog(const orc_env *e, int64_t out[2], int32_t *per_lane) {
+    const orc_scenario *sc = e->sc;
+    out[0] = 0; out[1] = 0;
+    for (int32_t dl = 0; dl < sc->n_lanes; ++dl) {
+        int32_t c = 0;
+        for (int32_t k = e->dep_next[dl]; k >= 0 && sc->trip_depart[k] < e->t; k = e->trip_next[k]) { c += 1; out[1] += e->t - sc->trip_depart[k]; }
+        out[0] += c;
+        if (per_lane) per_lane[dl] = c;
+    }
+}
 const uint16_t *orc_wtot(const orc_env *e) { return e->wtot; }
 void orc_debug(const orc_env *e, const int32_t **reason, const int32_t **block) { *reason = e->dbg_reason; *block = e->dbg_block; }
 void orc_stats(const orc_env *e, int64_t out[10]) {
     memcpy(out, e->stats, sizeof(e->stats));
-    int64_t act = 0, pend = 0;
-    for (int32_t s = 0; s < e->hw; ++s) {
-        uint16_t l = e->lane[s];
-        if (l == LANE_PENDING) pend += 1; else if (l != LANE_NONE) act += 1;
-    }
-    out[6] = act; out[7] = pend;
+    /* [7]: trips whose insertion has been tried and failed so far (departed before the last tick, not yet on the network) */
+    int32_t hz = e->t - 2 <= e->sc->horizon ? e->t - 2 : e->sc->horizon;
+    out[6] = e->n_active; out[7] = (e->t >= 2 ? e->sc->trips_cum[hz] : 0) - e->n_inserted;
 }

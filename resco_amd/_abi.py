@@ -10,7 +10,7 @@ _F32P = C.POINTER(C.c_float)
 _COUNTS = ['n_lanes', 'n_links', 'n_edges', 'n_routes', 'n_trips', 'n_signals', 'n_obs', 'n_vtypes',
            'n_foes', 'n_route_steps', 'n_tls_states', 'n_tls_dur', 'n_tls_yellow',
            'n_fix_states', 'n_fix_dur', 'n_mv_in', 'n_mv_out', 'n_pr_out',
-           'horizon', 'capacity', 'step_length', 'yellow_length']
+           'horizon', 'capacity', 'step_length', 'yellow_length', 'kmax']
 
 # (field, ctype) in the exact order of the C struct
 _POINTERS = [
@@ -25,7 +25,7 @@ _POINTERS = [
     ('edge_lane0', _I32P), ('edge_nlanes', _I32P),
     ('route_start', _I32P), ('route_edge', _I32P),
     ('route_tlsdist', _F32P),
-    ('route_mask1', _U32P), ('route_mask2', _U32P),
+    ('route_cont', _F32P),
     ('trip_depart', _I32P), ('trip_route', _I32P), ('trip_vtype', _I32P), ('trips_cum', _I32P),
     ('vtype_params', _F32P),
     ('tls_nphase', _I32P), ('tls_ngreen', _I32P), ('tls_nlinks', _I32P), ('tls_state_off', _I32P),
@@ -59,7 +59,7 @@ def pack_scenario(sc, step_length=10, yellow_length=None):
         n_tls_dur=len(A['tls_dur']), n_tls_yellow=len(A['tls_yellow']), n_fix_states=len(A['fix_states']),
         n_fix_dur=len(A['fix_dur']), n_mv_in=len(A['mv_in_idx']), n_mv_out=len(A['mv_out_idx']),
         n_pr_out=len(A['pr_out_idx']), horizon=sc.horizon, capacity=sc.capacity, step_length=step_length,
-        yellow_length=sc.yellow_length if yellow_length is None else yellow_length)
+        yellow_length=sc.yellow_length if yellow_length is None else yellow_length, kmax=sc.kmax)
     for k, v in counts.items():
         setattr(st, k, int(v))
     for name, ptype in _POINTERS:

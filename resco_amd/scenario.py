@@ -33,7 +33,6 @@ TLS_R, TLS_Y, TLS_g, TLS_G = 0, 1, 2, 3
 _TLS_CODE = {'r': TLS_R, 's': TLS_R, 'y': TLS_Y, 'Y': TLS_Y, 'u': TLS_R,
              'g': TLS_g, 'G': TLS_G, 'o': TLS_g, 'O': TLS_G}
 
-LC_LEN = 30.0                  # metres of edge needed per strategic lane shift (route lane planning)
 MOVEMENT_SLOTS = 12            # states.mplight / wave iterate the 12 movement keys
 BIG = np.float32(1.0e30)
 
@@ -288,7 +287,7 @@ _ARRAY_FIELDS = [
     # edges
     'edge_lane0', 'edge_nlanes',
     # routes
-    'route_start', 'route_edge', 'route_tlsdist', 'route_mask1', 'route_mask2',
+    'route_start', 'route_edge', 'route_tlsdist', 'route_cont',
     # demand
     'trip_depart', 'trip_route', 'trip_vtype', 'trips_cum', 'vtype_params',
     # signals (controlled, in all_ts_ids order)
@@ -343,6 +342,8 @@ class Scenario:
     @property
     def n_obs(self): return len(self.arrays['obs_lane'])
     @property
+    def kmax(self): return int(self.arrays['route_cont'].shape[1])
+    @property
     def horizon(self): return self.end - self.begin
 
     def save(self, path):
@@ -366,6 +367,42 @@ class Scenario:
             va = {k: {int(a): int(b) for a, b in v} for k, v in va.items()}
         arrays = {k: np.ascontiguousarray(z[k]) for k in z.files if k != '__meta__'}
         return Scenario(arrays=arrays, valid_acts=va, **meta)
+
+
+CONT_BIG = np.float32(1.0e6)    # "continues to the end of the route"
+
+
+def route_continuation(A):
+    """route_cont[route step][k] (float32, [n_route_steps, kmax]): how far a vehicle that enters edge c of its route on
+    lane k can drive along the route without changing lanes, measured from the start of the edge (the lane itself,
+    plus the best continuation through the connections to the next route edge; CONT_BIG on the last edge, where every
+    lane arrives).  This is SUMO's per-lane `length` of MSVehicle::getBestLanes [SUMO-K]; the simulator derives the
+    strategic lane-change need and the choice between parallel connections from it."""
+    kmax = int(A['edge_nlanes'].max())
+    rs = A['route_start']
+    n_steps = len(A['route_edge'])
+    cont = np.zeros((n_steps, kmax), np.float32)
+    l0, nl, llen = A['edge_lane0'], A['edge_nlanes'], A['lane_len']
+    ls, lc = A['lane_link_start'], A['lane_link_cnt']
+    for r in range(len(rs) - 1):
+        a, b = int(rs[r]), int(rs[r + 1])
+        for c in range(b - 1, a - 1, -1):
+            e = int(A['route_edge'][c])
+            for k in range(int(nl[e])):
+                if c == b - 1:
+                    cont[c, k] = CONT_BIG
+                    continue
+                lane = int(l0[e]) + k
+                ne = int(A['route_edge'][c + 1])
+                best = np.float32(0.0)
+                for li in range(int(ls[lane]), int(ls[lane]) + int(lc[lane])):
+                    if int(A['link_to_edge'][li]) != ne:
+                        continue
+                    v = np.float32(A['link_via_len'][li]) + cont[c + 1, int(A['link_dest_lane'][li]) - int(l0[ne])]
+                    if v > best:
+                        best = v
+                cont[c, k] = min(CONT_BIG, np.float32(llen[lane]) + best)
+    return np.ascontiguousarray(cont)
 
 
 def _dijkstra(succ, cost, src, dst):
@@ -692,41 +729,10 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
         fk = lane_index[lane_of(c.frm, c.from_lane).id] - edge_lane0[fe]
         tk = lane_index[lane_of(c.to, c.to_lane).id] - edge_lane0[te]
         conn_lanes.setdefault((fe, te), []).append((fk, tk, c))
-    route_start, route_edge, route_tls, route_m1, route_m2 = [0], [], [], [], []
+    route_start, route_edge, route_tls = [0], [], []
     for r in routes:
         ids = [edge_index[e] for e in r]
         n = len(ids)
-        m1 = [0] * n
-        for c_ in range(n):
-            if c_ == n - 1:
-                m1[c_] = (1 << edge_nl[ids[c_]]) - 1
-            else:
-                for fk, tk, _ in conn_lanes.get((ids[c_], ids[c_ + 1]), ()):
-                    m1[c_] |= 1 << fk
-        # preferred lanes: backward DP over the whole route ("bestLanes" [SUMO-K]).  reach[c] = lanes of
-        # edge c from which the rest of the route can be driven when a lane change needs LC_LEN metres.
-        m2 = [0] * n            # reach[c]: route continues from these lanes without a lane change on edge c
-        ok = [0] * n            # lanes of edge c from which a reach[c] lane is attainable on edge c itself
-        def widen(mask, nlanes, length):
-            shifts = int(length // LC_LEN)
-            out = 0
-            for k2 in range(nlanes):
-                for k3 in range(nlanes):
-                    if (mask >> k3) & 1 and abs(k3 - k2) <= shifts:
-                        out |= 1 << k2
-            return out
-        m2[n - 1] = m1[n - 1]
-        ok[n - 1] = m1[n - 1]
-        for c_ in range(n - 2, -1, -1):
-            strict, loose = 0, 0
-            for fk, tk, _ in conn_lanes.get((ids[c_], ids[c_ + 1]), ()):
-                if (m2[c_ + 1] >> tk) & 1:
-                    strict |= 1 << fk
-                if (ok[c_ + 1] >> tk) & 1:
-                    loose |= 1 << fk
-            m2[c_] = strict or loose or m1[c_]
-            ok[c_] = widen(m2[c_], edge_nl[ids[c_]], edge_len(r[c_]))
-        m1 = ok
         # distance from the end of edge c to the next TLS stop line along the route
         td = [float(BIG)] * n
         nxt = float(BIG)
@@ -745,14 +751,10 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
                 td[c_] = float(BIG) if ahead >= float(BIG) else via + edge_len(r[c_ + 1]) + ahead
         route_edge.extend(ids)
         route_tls.extend(td)
-        route_m1.extend(m1)
-        route_m2.extend(m2)
         route_start.append(len(route_edge))
     A['route_start'] = np.array(route_start, np.int32)
     A['route_edge'] = np.array(route_edge, np.int32)
     A['route_tlsdist'] = np.array(route_tls, np.float32)
-    A['route_mask1'] = np.array(route_m1, np.uint32).astype(np.int64).astype(np.uint32).view(np.int32)
-    A['route_mask2'] = np.array(route_m2, np.uint32).astype(np.int64).astype(np.uint32).view(np.int32)
 
     # ---- demand tables
     horizon = end - begin
@@ -821,6 +823,7 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
              mv_in_start=np.array(mv_in_start, np.int32), mv_in_idx=np.array(mv_in_idx or [0], np.int32),
              mv_out_start=np.array(mv_out_start, np.int32), mv_out_idx=np.array(mv_out_idx or [0], np.int32),
              pr_out_start=np.array(pr_out_start, np.int32), pr_out_idx=np.array(pr_out_idx or [0], np.int32))
+    A['route_cont'] = route_continuation(A)
     for k in _ARRAY_FIELDS:
         assert k in A, k
         A[k] = np.ascontiguousarray(A[k])
