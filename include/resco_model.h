@@ -1,0 +1,31 @@
+/*
+ * resco_model.h -- constants of the microsimulation model, shared by the HIP kernels (resco_amd/csrc) and by the CPU
+ * oracle (oracle/resco_oracle.c, test infrastructure).  Only numbers live here: the two implementations are written
+ * independently (a data-parallel one and a sequential one) and must agree bit for bit on every output.
+ *
+ * Everything tagged [SUMO-K] restates SUMO behaviour from general knowledge of its published model; SUMO itself is not
+ * available here, so these values are PARITY-UNPINNED against SUMO and calibrated against the delay figures the
+ * reference publishes (resco_benchmark/utils/avg_timeLoss.py), see DESIGN.md section 2.
+ */
+#ifndef RESCO_MODEL_H
+#define RESCO_MODEL_H
+
+#define RM_HALT_SPEED 0.1f        /* [SUMO-K] a vehicle at or below this speed is "waiting" (getWaitingTime) */
+#define RM_STOP_OFFSET 1.0f       /* metres kept to a stop line */
+#define RM_FOE_GAP_Q 40           /* a prohibitor arriving within 4.0 s (units of 0.1 s) closes a minor link */
+#define RM_VIS_DIST 4.5f          /* [SUMO-K] foe visibility distance: a minor link is approached ready to stop until this close */
+#define RM_MAX_HOPS 6             /* links examined ahead of a vehicle */
+#define RM_NB_WINDOW 128.0f       /* neighbours further away than this (front to front) play no role in a lane change */
+#define RM_SG_ADVANTAGE 20.0f     /* speed-gain change: metres of extra room needed on the neighbour lane */
+#define RM_URGENT_DIST 80.0f      /* a strategic change this close to the end of the drivable lane accepts tight gaps */
+#define RM_COOP_RANGE 80.0f       /* a blocked changer asks the nearest vehicle this far behind it on the target lane to let it in */
+#define RM_LOOK_TIME 8.0f         /* [SUMO-K] LC2013 LOOK_FORWARD (10 s there): strategic look-ahead = max(speed, RM_LOOK_MIN_SPEED) * this + RM_LOOK_BASE per lane to cross */
+#define RM_LOOK_BASE 10.0f
+#define RM_LOOK_MIN_SPEED 5.0f
+#define RM_SG_EXTRA_LANES 2       /* [SUMO-K] LC2013: leave the best lanes for speed gain only if (lanes to cross + 2) look-aheads remain */
+#define RM_GOOD_CONT 200.0f       /* a connection whose destination lane can be followed this far is as good as the best one */
+#define RM_MIN_LC_LEN 5.0f        /* an edge shorter than this cannot host a lane change */
+#define RM_CONT_EPS 0.5f
+#define RM_BIGF 1.0e30f
+
+#endif

@@ -46,7 +46,7 @@ typedef struct rs_scenario {
     int32_t n_lanes, n_links, n_edges, n_routes, n_trips, n_signals, n_obs, n_vtypes;
     int32_t n_foes, n_route_steps, n_tls_states, n_tls_dur, n_tls_yellow;
     int32_t n_fix_states, n_fix_dur, n_mv_in, n_mv_out, n_pr_out;
-    int32_t horizon, capacity, step_length, yellow_length;
+    int32_t horizon, capacity, step_length, yellow_length, kmax;     /* kmax: most lanes of one edge */
     /* lanes (normal + junction-internal), compact ids */
     const float *lane_len, *lane_vmax;
     const int32_t *lane_edge, *lane_left, *lane_right, *lane_link_start, *lane_link_cnt, *lane_obs, *lane_internal;
@@ -60,7 +60,7 @@ typedef struct rs_scenario {
     /* routes: CSR over route steps */
     const int32_t *route_start, *route_edge;
     const float *route_tlsdist;
-    const uint32_t *route_mask1, *route_mask2;
+    const float *route_cont;            /* [n_route_steps][kmax]: metres drivable along the route without a lane change (bestLanes) */
     /* demand (identical in every environment) */
     const int32_t *trip_depart, *trip_route, *trip_vtype, *trips_cum;
     const float *vtype_params;          /* [n_vtypes][10]: length minGap accel decel tau sigma maxSpeed sfMean sfDev emergencyDecel */
@@ -86,7 +86,8 @@ typedef struct rs_params {
 typedef struct rs_sim *rs_handle;
 
 /* env_base: global index of this handle's first environment (keys the counter-based RNG so that a batch
- * sharded over several GPUs reproduces the single-GPU batch).  block_threads: 0 = choose. */
+ * sharded over several GPUs reproduces the single-GPU batch).  block_threads: 0 = one thread per vehicle slot (<= 1024);
+ * a negative value selects the 128-VGPR build of the step kernel with |block_threads| (<= 512) threads. */
 int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
               int32_t block_threads, rs_handle *out);
 void rs_destroy(rs_handle h);
@@ -127,13 +128,13 @@ enum rs_buffer {
     RS_BUF_QUEUE_SUM,      /* i32 [N][S]         calc_metrics queue_lengths */
     RS_BUF_QUEUE_MAX,      /* i32 [N][S]         calc_metrics max_queues */
     RS_BUF_ACTIONS,        /* i32 [N][S]         action staging buffer */
-    RS_BUF_ENV,            /* i32 [N][4]         ticks since begin, next_trip, high-water slot, reserved */
+    RS_BUF_ENV,            /* i32 [N][4]         ticks since begin, trips inserted, high-water slot, vehicles on the network */
     RS_BUF_TLS,            /* i32 [N][S][3]      phase, time left, next_phase */
     RS_BUF_VEH_POS,        /* f32 [N][C] */
     RS_BUF_VEH_SPEED,      /* f32 [N][C] */
     RS_BUF_VEH_ACCEL,      /* f32 [N][C] */
     RS_BUF_VEH_TLOSS,      /* f32 [N][C] */
-    RS_BUF_VEH_LANE,       /* u16 [N][C]  0xFFFF free, 0xFFFE waiting for insertion */
+    RS_BUF_VEH_LANE,       /* u16 [N][C]  0xFFFF free */
     RS_BUF_VEH_TRIP,       /* u16 [N][C]  0xFFFF free */
     RS_BUF_VEH_CURSOR,     /* u16 [N][C] */
     RS_BUF_VEH_SWAIT,      /* u16 [N][C]  SUMO waiting time (s) */
@@ -146,16 +147,24 @@ enum rs_buffer {
     RS_BUF_VEH_WTOT,       /* u16 [N][C]  total halted seconds of the trip so far (maintained only with trip_log) */
     RS_BUF_TRIP_LOG,       /* i32 [N][n_trips][4] depart tick, arrival tick (0: not arrived), timeLoss (1/1024 s), waiting (s);
                               [N][0][4] when trip_log is off */
+    RS_BUF_DEP_NEXT,       /* u16 [N][n_dep] next trip of every departure lane's backlog (0xFFFF: none left); departure lanes are
+                              the first lanes of the routes' first edges in ascending lane order */
+    RS_BUF_VEH_COOP,       /* u32 [N][C]  cooperation request addressed to the vehicle: trip << 16 | slot of the requester (0xFFFFFFFF none) */
+    RS_BUF_VEH_COOPLEAD,   /* u32 [N][C]  the target-lane leader a blocked lane changer falls in behind (same encoding) */
+    RS_BUF_ARRIVALS,       /* i32 [N][S]  |Signal.arrivals| of the last observe (traffic_signal.py:222-229) */
+    RS_BUF_DEPARTURES,     /* i32 [N][S]  |Signal.departures| of the last observe */
+    RS_BUF_MPLIGHT_FULL,   /* f32 [N][S][49] states.mplight_full (states.py:83-113) */
     RS_BUF_COUNT
 };
-enum rs_dtype { RS_F32 = 0, RS_I32 = 1, RS_U16 = 2, RS_U8 = 3, RS_F16 = 4, RS_I64 = 5 };
+enum rs_dtype { RS_F32 = 0, RS_I32 = 1, RS_U16 = 2, RS_U8 = 3, RS_F16 = 4, RS_I64 = 5, RS_U32 = 6 };
 
 int rs_get_buffer(rs_handle h, int32_t which, void **dev_ptr, int64_t shape[4], int32_t *ndim, int32_t *dtype);
 /* convenience: synchronous device->host copy of a whole buffer */
 int rs_read_buffer(rs_handle h, int32_t which, void *host_dst, int64_t nbytes);
 
 /* per env: [0] inserted [1] arrived [2] sum duration(s) [3] sum departDelay(s) [4] sum waiting(s)
- * [5] sum timeLoss (1/1024 s) [6] active now [7] pending now [8] sum over ticks of active vehicles [9] ticks */
+ * [5] sum timeLoss (1/1024 s) [6] active now [7] backlog: trips whose insertion was tried and has failed so far
+ * [8] sum over ticks of active vehicles [9] ticks */
 int rs_stats(rs_handle h, int64_t *host_out /* [n_envs][10] */);
 
 /* environment snapshots (device-resident copies of the SoA state) */
@@ -172,8 +181,7 @@ int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches);   /* syncs;
 int rs_set_seed(rs_handle h, uint32_t seed);
 
 /* in-kernel phase timers (development aid): enable, run steps, then read 16 accumulators of wall_clock64 ticks
- * (100 MHz) summed over all workgroups: 0 load, 1 prologue, 2 A, 3 B, 4 C plan, 5 list clear, 6 D move, 7 E lane
- * change, 8 F rebuild, 9 observe, 10 outputs.  Reading also resets. */
+ * (100 MHz) summed over all workgroups.  Reading also resets.  (Kept in the ABI; the current kernel does not fill them.) */
 int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16);
 
 /* ---- fused IDQN policy forward (BASELINE config 5) ------------------------------------------

@@ -11,55 +11,20 @@
  *   P4 plan (Krauss)       P5 move         P6 lane lists  P7 lane change
  */
 #include "resco_oracle.h"
+#include "../include/resco_model.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #define LANE_NONE 0xFFFFu
-#define LANE_PENDING 0xFFFEu
+#define LANE_PENDING 0xFFFEu      /* (no longer a state: waiting trips hold no slot) kept so that `lane >= LANE_PENDING` reads "no vehicle" */
 #define OWNER_NONE 0xFFu
 #define NIL (-1)
-#define HALT_SPEED 0.1f
-#define STOP_OFFSET 1.0f
 #define ARR_NONE 65535
-#define FOE_GAP_Q 40 /* a foe arriving within 4.0 s blocks a minor link */
-#define MAX_HOPS 6
-#define BIGF 1.0e30f
-#define SG_ADVANTAGE 10.0f
-#define URGENT_DIST 50.0f
-#define GOOD_CONT 450.0f    /* a lane that can be followed this far is as good as the best one when connections are chosen */
-#define MIN_LC_LEN 5.0f      /* an edge shorter than this cannot host a lane change: do not enter it on a lane the route cannot leave */
-#define SWAP_WAIT 20      /* a mutual block is broken up after both vehicles have stood for this many seconds ... */
-#define SWAP_EVERY 4      /* ... and is looked for on every 4th tick only */
-static float X_VIS = 4.5f;
-static float X_FOE = 40.0f;
-static int X_INIT = 0;
-static int X_FIRST = 1;
-static int X_COOP = 2;
-static int X_ALT = 1;
-static int X_LAV = 1;
-static float X_LAT = 10.0f, X_LAB = 10.0f, X_URG = 50.0f, X_GOOD = 450.0f, X_SGA = 10.0f, X_LAMIN = 5.0f;
-static int X_EXTRA = 2, X_SWAPW = 20;
-static float X_COOPR = 50.0f;
-static void x_init(void) {
-    if (X_INIT) return;
-    X_INIT = 1;
-    if (getenv("X_VIS")) X_VIS = (float)atof(getenv("X_VIS"));
-    if (getenv("X_FIRST")) X_FIRST = atoi(getenv("X_FIRST"));
-    if (getenv("X_FOE")) X_FOE = (float)atof(getenv("X_FOE"));
-    if (getenv("X_LAV")) X_LAV = atoi(getenv("X_LAV"));
-    if (getenv("X_LAT")) X_LAT = (float)atof(getenv("X_LAT"));
-    if (getenv("X_LAB")) X_LAB = (float)atof(getenv("X_LAB"));
-    if (getenv("X_LAMIN")) X_LAMIN = (float)atof(getenv("X_LAMIN"));
-    if (getenv("X_URG")) X_URG = (float)atof(getenv("X_URG"));
-    if (getenv("X_GOOD")) X_GOOD = (float)atof(getenv("X_GOOD"));
-    if (getenv("X_SGA")) X_SGA = (float)atof(getenv("X_SGA"));
-    if (getenv("X_EXTRA")) X_EXTRA = atoi(getenv("X_EXTRA"));
-    if (getenv("X_SWAPW")) X_SWAPW = atoi(getenv("X_SWAPW"));
-    if (getenv("X_ALT")) X_ALT = atoi(getenv("X_ALT"));
-    if (getenv("X_COOP")) X_COOP = atoi(getenv("X_COOP"));
-    if (getenv("X_COOPR")) X_COOPR = (float)atof(getenv("X_COOPR"));
-}
+#define HALT_SPEED RM_HALT_SPEED
+#define STOP_OFFSET RM_STOP_OFFSET
+#define MAX_HOPS RM_MAX_HOPS
+#define BIGF RM_BIGF
 
 enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
 enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
@@ -69,6 +34,7 @@ struct orc_env {
     orc_params p;
     int32_t env_index;
     int32_t t;              /* ticks since begin */
+    float maxlen;           /* longest vehicle of the scenario */
     int32_t n_inserted;     /* trips inserted so far */
     int32_t n_active;       /* vehicles on the network */
     int32_t *dep_next;      /* per lane: the next trip that departs from it (-1: none left) -- a FIFO per departure lane */
@@ -190,20 +156,20 @@ static int32_t choose_link(const orc_env *e, int32_t lane, int32_t route, int32_
         float c = cn[sc->link_dest_lane[l] - sc->edge_lane0[ne]];
         if (c > bc) bc = c;
     }
-    if (bc < MIN_LC_LEN) return -1;
+    if (bc < RM_MIN_LC_LEN) return -1;
     /* parallel connections whose destination lanes are all good enough (the best one, or GOOD_CONT metres without a
      * lane change) share the traffic: trips alternate between them (SUMO spreads them by lane occupation [SUMO-K]) */
     int32_t n_acc = 0;
     for (int32_t l = ls; l < ls + lc; ++l) {
         if (sc->link_to_edge[l] != ne) continue;
         float c = cn[sc->link_dest_lane[l] - sc->edge_lane0[ne]];
-        if (c >= bc - 0.5f || c >= X_GOOD) n_acc += 1;
+        if (c >= bc - RM_CONT_EPS || c >= RM_GOOD_CONT) n_acc += 1;
     }
-    int32_t pick = X_ALT ? trip % n_acc : 0;
+    int32_t pick = n_acc >= 2 ? (trip & 1) : 0;     /* even trips take the first, odd trips the second of them */
     for (int32_t l = ls; l < ls + lc; ++l) {
         if (sc->link_to_edge[l] != ne) continue;
         float c = cn[sc->link_dest_lane[l] - sc->edge_lane0[ne]];
-        if (c >= bc - 0.5f || c >= X_GOOD) { if (pick == 0) return l; pick -= 1; }
+        if (c >= bc - RM_CONT_EPS || c >= RM_GOOD_CONT) { if (pick == 0) return l; pick -= 1; }
     }
     return -1;
 }
@@ -218,12 +184,12 @@ static int32_t strategic_dir_at(const orc_env *e, int32_t route, int32_t cursor,
     float best = 0.0f;
     for (int32_t j = 0; j < n; ++j) if (cn[j] > best) best = cn[j];
     *rem = cn[kk] - x;
-    if (cn[kk] >= best - 0.5f) return 0;
+    if (cn[kk] >= best - RM_CONT_EPS) return 0;
     int32_t dl = 1000, dr = 1000;
-    for (int32_t j = kk + 1; j < n; ++j) if (cn[j] >= best - 0.5f) { dl = j - kk; break; }
-    for (int32_t j = kk - 1; j >= 0; --j) if (cn[j] >= best - 0.5f) { dr = kk - j; break; }
+    for (int32_t j = kk + 1; j < n; ++j) if (cn[j] >= best - RM_CONT_EPS) { dl = j - kk; break; }
+    for (int32_t j = kk - 1; j >= 0; --j) if (cn[j] >= best - RM_CONT_EPS) { dr = kk - j; break; }
     int32_t off = (dr <= dl ? dr : dl) + extra;
-    float la = (v > X_LAMIN ? v : X_LAMIN) * X_LAT + X_LAB;
+    float la = (v > RM_LOOK_MIN_SPEED ? v : RM_LOOK_MIN_SPEED) * RM_LOOK_TIME + RM_LOOK_BASE;
     if (*rem >= la * (float)off) return 0;
     return (dr <= dl) ? -1 : +1;
 }
@@ -237,14 +203,7 @@ static inline int32_t tls_state(const orc_env *e, int32_t link) {
 }
 /* departure lane [SUMO-K departLane default "first"]: the right-most lane of the first edge the vehicle may use */
 static inline int32_t depart_lane(const orc_scenario *sc, int32_t route) {
-    int32_t ed = sc->route_edge[sc->route_start[route]];
-    if (!X_FIRST) {     /* study switch: "best" = the lane with the longest continuation */
-        const float *cn = sc->route_cont + (size_t)sc->route_start[route] * sc->kmax;
-        int32_t bk = 0;
-        for (int32_t j = 1; j < sc->edge_nlanes[ed]; ++j) if (cn[j] > cn[bk]) bk = j;
-        return sc->edge_lane0[ed] + bk;
-    }
-    return sc->edge_lane0[ed];
+    return sc->edge_lane0[sc->route_edge[sc->route_start[route]]];
 }
 static void build_lists(orc_env *e) {
     const orc_scenario *sc = e->sc;
@@ -255,17 +214,19 @@ static void build_lists(orc_env *e) {
         e->lane_head[e->lane[s]] = s;
     }
 }
-/* rear-most vehicle on a lane: min pos, ties -> larger trip index */
-static int32_t rearmost(const orc_env *e, int32_t lane) {
+/* rear-most vehicle of a lane (min pos, ties -> larger trip index) if its front is within `win` metres of the lane start.
+ * Vehicles further away cannot influence anybody who looks `win` metres ahead; the cut makes the search a bounded scan. */
+static int32_t rearmost(const orc_env *e, int32_t lane, float win) {
     int32_t best = NIL, bk = 0;
     for (int32_t s = e->lane_head[lane]; s != NIL; s = e->next_in_lane[s]) {
         int32_t k = trip_of_slot(e, s);
         if (best == NIL || e->pos[s] < e->pos[best] || (e->pos[s] == e->pos[best] && k > bk)) { best = s; bk = k; }
     }
+    if (best != NIL && e->pos[best] > win) return NIL;
     return best;
 }
-/* nearest vehicle ahead / behind of (pos,k) on a lane */
-static void neighbours(const orc_env *e, int32_t lane, float pos, int32_t k, int32_t self, int32_t *lead, int32_t *foll) {
+/* nearest vehicle ahead / behind of (pos,k) on a lane, at most `win` metres away (front to front) */
+static void neighbours(const orc_env *e, int32_t lane, float pos, int32_t k, int32_t self, float win, int32_t *lead, int32_t *foll) {
     int32_t L = NIL, F = NIL, Lk = 0, Fk = 0;
     for (int32_t s = e->lane_head[lane]; s != NIL; s = e->next_in_lane[s]) {
         if (s == self) continue;
@@ -276,6 +237,8 @@ static void neighbours(const orc_env *e, int32_t lane, float pos, int32_t k, int
             if (F == NIL || ahead_of(e->pos[s], ks, e->pos[F], Fk)) { F = s; Fk = ks; }
         }
     }
+    if (L != NIL && e->pos[L] - pos > win) L = NIL;
+    if (F != NIL && pos - e->pos[F] > win) F = NIL;
     *lead = L; *foll = F;
 }
 
@@ -283,7 +246,6 @@ static void neighbours(const orc_env *e, int32_t lane, float pos, int32_t k, int
 #define ALLOC(p, n) p = calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(*(p)))
 orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_index) {
     orc_env *e = calloc(1, sizeof(orc_env));
-    x_init();
     e->sc = sc; e->p = *p; e->env_index = env_index;
     int32_t C = sc->capacity, S = sc->n_signals, O = sc->n_obs;
     ALLOC(e->lane, C); ALLOC(e->cursor, C); ALLOC(e->sumo_wait, C); ALLOC(e->resco_wait, C); ALLOC(e->depart, C);
@@ -306,6 +268,8 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     ALLOC(e->agg_q, O); ALLOC(e->agg_a, O); ALLOC(e->agg_w, O); ALLOC(e->agg_m, O); ALLOC(e->agg_s, O);
     ALLOC(e->out_phase, S); ALLOC(e->mplight, S * 13); ALLOC(e->wave, S * 12); ALLOC(e->pressure, S);
     ALLOC(e->queue_sum, S); ALLOC(e->queue_max, S);
+    e->maxlen = 0.0f;
+    for (int32_t v = 0; v < sc->n_vtypes; ++v) if (sc->vtype_params[v * VT_COLS + VT_LENGTH] > e->maxlen) e->maxlen = sc->vtype_params[v * VT_COLS + VT_LENGTH];
     orc_reset(e);
     return e;
 }
@@ -370,17 +334,16 @@ static void tls_events(orc_env *e) {
     }
 }
 
-static void insertion(orc_env *e) {
+/* [SUMO-K] MSInsertionControl (emitVehicles runs at the end of a simulation step, after the lane changes): every
+ * departure lane keeps its own backlog; its oldest trip is inserted (departPos "base", departSpeed 0) as soon as it has
+ * departed and the space behind the rear-most vehicle suffices.  The check reads the moved state of this tick, before
+ * this tick's lane changes are applied (it is evaluated side by side with the lane-change decisions). */
+static void insertion_check(orc_env *e) {
     const orc_scenario *sc = e->sc;
-    int32_t C = sc->capacity;
-    /* [SUMO-K] MSInsertionControl: every departure lane keeps its own backlog; its oldest trip is inserted
-     * (departPos "base", departSpeed 0) as soon as it has departed and the space behind the rear-most vehicle suffices.
-     * All checks read the state before this tick's insertions (lanes are independent of each other). */
-    int32_t room = C - e->n_active;         /* the network holds at most `capacity` vehicles */
-    for (int32_t dl = 0; dl < sc->n_lanes; ++dl) e->lane_ins[dl] = -1;
     for (int32_t dl = 0; dl < sc->n_lanes; ++dl) {
+        e->lane_ins[dl] = -1;
         int32_t k = e->dep_next[dl];
-        if (k < 0 || sc->trip_depart[k] > e->t - 1) continue;
+        if (k < 0 || sc->trip_depart[k] > e->t) continue;
         const float *vt = vt_of(e, k);
         float mypos = vt[VT_LENGTH] < sc->lane_len[dl] ? vt[VT_LENGTH] : sc->lane_len[dl];
         int ok = 1;
@@ -391,6 +354,11 @@ static void insertion(orc_env *e) {
         }
         if (ok) e->lane_ins[dl] = k;
     }
+}
+static void insertion_apply(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    int32_t C = sc->capacity;
+    int32_t room = C - e->n_active;         /* the network holds at most `capacity` vehicles */
     for (int32_t dl = 0; dl < sc->n_lanes && room > 0; ++dl) {      /* lower lane index first when the network is full */
         int32_t k = e->lane_ins[dl];
         if (k < 0) continue;
@@ -401,15 +369,13 @@ static void insertion(orc_env *e) {
         e->trip[s] = k; e->lane[s] = (uint16_t)dl;
         e->pos[s] = vt[VT_LENGTH] < sc->lane_len[dl] ? vt[VT_LENGTH] : sc->lane_len[dl];
         e->speed[s] = 0; e->accel[s] = 0; e->time_loss[s] = 0; e->cursor[s] = 0;
-        e->sumo_wait[s] = 0; e->resco_wait[s] = 0; e->owner[s] = OWNER_NONE; e->depart[s] = (uint16_t)e->t; e->wtot[s] = 0;
+        e->sumo_wait[s] = 0; e->resco_wait[s] = 0; e->owner[s] = OWNER_NONE; e->depart[s] = (uint16_t)(e->t + 1); e->wtot[s] = 0;
         e->coop[s] = -1; e->coop_lead[s] = -1;
         if (s + 1 > e->hw) e->hw = s + 1;
-        e->next_in_lane[s] = e->lane_head[dl];
-        e->lane_head[dl] = s;
         e->dep_next[dl] = e->trip_next[k];
         e->n_inserted += 1; e->n_active += 1; room -= 1;
         e->stats[0] += 1;
-        e->stats[3] += e->t - 1 - sc->trip_depart[k];
+        e->stats[3] += e->t - sc->trip_depart[k];
     }
 }
 
@@ -446,7 +412,7 @@ static int foe_blocked(const orc_env *e, int32_t link) {
     for (int32_t i = fs; i < fs + fc; ++i) {
         int32_t f = sc->foe_link[i];
         if (sc->link_tls[f] >= 0 && tls_state(e, f) == TLS_R) continue;
-        if (e->link_arr[f] < (int32_t)X_FOE) return 1;
+        if (e->link_arr[f] < RM_FOE_GAP_Q) return 1;
         if (sc->link_via1[f] >= 0 && lane_has_mover(e, sc->link_via1[f])) return 1;
         if (sc->link_via2[f] >= 0 && lane_has_mover(e, sc->link_via2[f])) return 1;
     }
@@ -470,9 +436,10 @@ static void plan(orc_env *e) {
         if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
         float vsafe = BIGF;
         e->dbg_reason[s] = 0; e->dbg_block[s] = -1;
-        /* leader on my own lane */
+        /* leader on my own lane (one further away than I look ahead cannot matter) */
+        float look = orc_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
         int32_t lead, foll;
-        neighbours(e, lane, x, k, s, &lead, &foll);
+        neighbours(e, lane, x, k, s, look + e->maxlen, &lead, &foll);
         int found = 0;
         if (lead != NIL) {
             const float *vo = vt_of(e, trip_of_slot(e, lead));
@@ -503,7 +470,7 @@ static void plan(orc_env *e) {
         if (e->coop_lead[s] >= 0) {
             int32_t X = e->coop_lead[s], kx = e->coop_lead_trip[s];
             e->coop_lead[s] = -1;
-            if (X_COOP >= 2 && e->trip[X] == kx && e->lane[X] < LANE_PENDING && !sc->lane_internal[e->lane[X]] && !sc->lane_internal[lane] &&
+            if (e->trip[X] == kx && e->lane[X] < LANE_PENDING && !sc->lane_internal[e->lane[X]] && !sc->lane_internal[lane] &&
                 sc->lane_edge[e->lane[X]] == sc->lane_edge[lane]) {
                 const float *vo = vt_of(e, kx);
                 float backx = e->pos[X] - vo[VT_LENGTH];
@@ -517,7 +484,6 @@ static void plan(orc_env *e) {
             }
         }
         /* look ahead along my path */
-        float look = orc_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
         float seen = sc->lane_len[lane] - x;
         int32_t cur = lane, cur_cursor = cursor;
         int32_t rn = sc->route_start[route + 1] - sc->route_start[route];
@@ -539,7 +505,7 @@ static void plan(orc_env *e) {
                 (sc->link_minor[link] || (sc->link_tls[link] >= 0 && st == TLS_g))) {
                 /* [SUMO-K] MSVehicle::processLinkApproaches: a minor link is approached as if one had to stop until the
                  * foe lanes can be seen (foe visibility distance 4.5 m) */
-                if (X_VIS > 0.0f && seen > X_VIS) { stop_here = 1; e->dbg_reason[s] = 7; e->dbg_block[s] = link; }
+                if (seen > RM_VIS_DIST) { stop_here = 1; e->dbg_reason[s] = 7; e->dbg_block[s] = link; }
                 else if (sc->link_foe_cnt[link] > 0 && foe_blocked(e, link)) { stop_here = 1; e->dbg_reason[s] = 4; e->dbg_block[s] = link; }
             }
             if (stop_here) {
@@ -556,7 +522,7 @@ static void plan(orc_env *e) {
                     if (vs < vsafe) { vsafe = vs; e->dbg_reason[s] = 6; e->dbg_block[s] = nl; }
                 }
             }
-            int32_t o = rearmost(e, nl);
+            int32_t o = rearmost(e, nl, look - seen + e->maxlen);
             if (o != NIL) {
                 const float *vo = vt_of(e, trip_of_slot(e, o));
                 float gap = seen + e->pos[o] - vo[VT_LENGTH] - mingap;
@@ -642,29 +608,6 @@ static void move(orc_env *e) {
     while (e->hw > 0 && e->lane[e->hw - 1] == LANE_NONE) e->hw -= 1;
 }
 
-/* Mutual block (own rule; SUMO resolves the same situation with cooperative lane changing or teleports, which this
- * model does not have): two stationary vehicles stand side by side near the end of their lanes, each in the lane
- * the other one needs.  Neither can ever find a gap, so they trade places.  swap_dir: the strategic direction of
- * such a vehicle (0: it is not one). */
-static int32_t swap_dir(const orc_env *e, int32_t s) {
-    const orc_scenario *sc = e->sc;
-    if (e->lane[s] >= LANE_PENDING) return 0;
-    int32_t lane = e->lane[s];
-    if (sc->lane_internal[lane] || e->speed[s] > HALT_SPEED || e->sumo_wait[s] < X_SWAPW) return 0;
-    int32_t ed = sc->lane_edge[lane], n = sc->edge_nlanes[ed], kk = lane - sc->edge_lane0[ed];
-    if (n < 2 || sc->lane_len[lane] - e->pos[s] > X_URG) return 0;
-    float rem;
-    return strategic_dir_at(e, sc->trip_route[e->trip[s]], e->cursor[s], kk, n, e->pos[s], X_LAV ? sc->lane_vmax[lane] : e->speed[s], 0, &rem);
-}
-/* the vehicle on lane tl whose body overlaps mine lengthwise (the nearer one ahead first), NIL: none */
-static int32_t overlapping(const orc_env *e, int32_t s, int32_t tl) {
-    int32_t lead, foll;
-    int32_t k = e->trip[s];
-    neighbours(e, tl, e->pos[s], k, s, &lead, &foll);
-    if (lead != NIL && e->pos[lead] - vt_of(e, trip_of_slot(e, lead))[VT_LENGTH] - e->pos[s] < 0.0f) return lead;
-    if (foll != NIL && e->pos[s] - vt_of(e, k)[VT_LENGTH] - e->pos[foll] < 0.0f) return foll;
-    return NIL;
-}
 static void lane_change(orc_env *e) {
     const orc_scenario *sc = e->sc;
     int32_t dir_allowed = (e->t & 1) ? -1 : +1;
@@ -683,25 +626,24 @@ static void lane_change(orc_env *e) {
         float x = e->pos[s], v = e->speed[s];
         int want = 0, dir = dir_allowed;
         float rem;
-        int32_t sdir = strategic_dir_at(e, route, e->cursor[s], kk, n, x, X_LAV ? sc->lane_vmax[lane] : v, 0, &rem);
+        int32_t sdir = strategic_dir_at(e, route, e->cursor[s], kk, n, x, v, 0, &rem);
         if (sdir != 0) {
             /* strategic: head for the nearest lane that continues my route.  The target lane is examined on every tick
              * (a blocked vehicle asks for cooperation), the change itself happens on the ticks of its direction */
             dir = sdir;
-            if (dir != dir_allowed && !X_COOP) continue;
-            want = 2;
+                        want = 2;
         }
         int32_t tk = kk + dir;
         if (tk < 0 || tk >= n) continue;
         int32_t tl = sc->edge_lane0[ed] + tk;
         int32_t lead_c, foll_c, lead_t, foll_t;
-        neighbours(e, tl, x, k, s, &lead_t, &foll_t);
+        neighbours(e, tl, x, k, s, RM_NB_WINDOW, &lead_t, &foll_t);
         float rem_t;
-        if (!want && ((((uint32_t)e->t >> 1) + (uint32_t)k) & 3u) == 0u && strategic_dir_at(e, route, e->cursor[s], tk, n, x, X_LAV ? sc->lane_vmax[lane] : v, X_EXTRA, &rem_t) == 0) {
+        if (!want && ((((uint32_t)e->t >> 1) + (uint32_t)k) & 3u) == 0u && strategic_dir_at(e, route, e->cursor[s], tk, n, x, v, RM_SG_EXTRA_LANES, &rem_t) == 0) {
             /* speed gain between equally good lanes: more room ahead on the neighbour.  A vehicle reconsiders
              * only on one pair of ticks (one left, one right chance) out of four (LC2013 needs several
              * seconds of accumulated speed-gain incentive before it acts [SUMO-K]) */
-            neighbours(e, lane, x, k, s, &lead_c, &foll_c);
+            neighbours(e, lane, x, k, s, RM_NB_WINDOW, &lead_c, &foll_c);
             if (lead_c != NIL) {
                 const float *vo = vt_of(e, trip_of_slot(e, lead_c));
                 float gcur = e->pos[lead_c] - vo[VT_LENGTH] - x;
@@ -710,13 +652,13 @@ static void lane_change(orc_env *e) {
                     const float *vq = vt_of(e, trip_of_slot(e, lead_t));
                     gtgt = e->pos[lead_t] - vq[VT_LENGTH] - x;
                 }
-                if (gcur < v * 3.0f + 15.0f && gtgt > gcur + X_SGA) want = 1;
+                if (gcur < v * 3.0f + 15.0f && gtgt > gcur + RM_SG_ADVANTAGE) want = 1;
             }
         }
         if (!want) continue;
         /* urgent = strategic change close to the end of the lane: accept tighter gaps (followers may have to
          * brake with their emergency deceleration), otherwise dense queues would never let anybody in */
-        int urgent = want == 2 && rem <= X_URG;
+        int urgent = want == 2 && rem <= RM_URGENT_DIST;
         int safe = 1;
         if (lead_t != NIL) {
             const float *vo = vt_of(e, trip_of_slot(e, lead_t));
@@ -733,14 +675,14 @@ static void lane_change(orc_env *e) {
             if (gap < 0.0f || vb > orc_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = 0;
         }
         if (safe) { if (dir == dir_allowed) e->lc_target[s] = tl; continue; }
-        if (want == 2 && X_COOP && lead_t != NIL) { e->coop_lead[s] = lead_t; e->coop_lead_trip[s] = trip_of_slot(e, lead_t); }
-        if (want == 2 && X_COOP) {
+        if (want == 2 && lead_t != NIL) { e->coop_lead[s] = lead_t; e->coop_lead_trip[s] = trip_of_slot(e, lead_t); }
+        if (want == 2) {
             /* blocked: ask the nearest vehicle of the target lane that is completely behind me to let me in */
             float back = x - vt[VT_LENGTH];
             int32_t R = NIL, Rk = 0;
             for (int32_t o = e->lane_head[tl]; o != NIL; o = e->next_in_lane[o]) {
                 int32_t ko = trip_of_slot(e, o);
-                if (e->pos[o] > back || back - e->pos[o] > X_COOPR) continue;
+                if (e->pos[o] > back || back - e->pos[o] > RM_COOP_RANGE) continue;
                 if (R == NIL || ahead_of(e->pos[o], ko, e->pos[R], Rk)) { R = o; Rk = ko; }
             }
             if (R != NIL) {
@@ -749,17 +691,8 @@ static void lane_change(orc_env *e) {
             }
         }
     }
-    /* mutual block at the end of the lanes: two stationary vehicles side by side, each in the lane the other needs */
-    /* (an overlapping vehicle makes the regular change above unsafe, and the partner, heading the other way, had
-     * no chance this tick: neither has a target yet; the mutual test makes the pairs unique) */
-    for (int32_t s = 0; s < e->hw && e->t % SWAP_EVERY == 0; ++s) {
-        if (swap_dir(e, s) != dir_allowed) continue;
-        int32_t lane = e->lane[s], tl = lane + dir_allowed;
-        int32_t b = overlapping(e, s, tl);
-        if (b == NIL || swap_dir(e, b) != -dir_allowed) continue;
-        if (overlapping(e, b, lane) != s) continue;
-        e->lc_target[s] = tl; e->lc_target[b] = lane;
-    }
+}
+static void lane_change_apply(orc_env *e) {
     for (int32_t s = 0; s < e->hw; ++s) {
         if (e->lane[s] >= LANE_PENDING) continue;
         if (e->lc_target[s] >= 0) e->lane[s] = (uint16_t)e->lc_target[s];
@@ -769,12 +702,14 @@ static void lane_change(orc_env *e) {
 void orc_tick(orc_env *e) {
     tls_events(e);
     build_lists(e);
-    insertion(e);
     register_approaches(e);
     plan(e);
     move(e);
     build_lists(e);
-    lane_change(e);
+    lane_change(e);         /* decisions + cooperation requests on the moved state ... */
+    insertion_check(e);     /* ... and, on the same state, which departure lanes have room */
+    lane_change_apply(e);
+    insertion_apply(e);
     e->t += 1;
     e->stats[9] += 1;
 }
@@ -909,6 +844,6 @@ void orc_debug(const orc_env *e, const int32_t **reason, const int32_t **block) 
 void orc_stats(const orc_env *e, int64_t out[10]) {
     memcpy(out, e->stats, sizeof(e->stats));
     /* [7]: trips whose insertion has been tried and failed so far (departed before the last tick, not yet on the network) */
-    int32_t hz = e->t - 2 <= e->sc->horizon ? e->t - 2 : e->sc->horizon;
-    out[6] = e->n_active; out[7] = (e->t >= 2 ? e->sc->trips_cum[hz] : 0) - e->n_inserted;
+    int32_t hz = e->t - 1 <= e->sc->horizon ? e->t - 1 : e->sc->horizon;
+    out[6] = e->n_active; out[7] = (e->t >= 1 ? e->sc->trips_cum[hz] : 0) - e->n_inserted;
 }

@@ -13,7 +13,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
 
 
 def build_library(force=False, verbose=False):
-    deps = [SRC, os.path.join(HERE, 'csrc', 'resco_kernels.h'), os.path.join(ROOT, 'include', 'resco_sim.h')]
+    deps = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('resco_step.h', 'resco_tables.h', 'resco_policy.h')] + \
+           [os.path.join(ROOT, 'include', f) for f in ('resco_sim.h', 'resco_model.h')]
+    force = force or os.environ.get('GRAFT_FORCE_BUILD') == '1'
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     cmd = [HIPCC] + FLAGS + [SRC, '-o', LIB]

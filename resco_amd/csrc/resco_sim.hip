@@ -30,35 +30,119 @@
 
 #include "resco_sim.h"
 
-#define LANE_NONE 0xFFFFu
-#define LANE_PENDING 0xFFFEu
-#define OWNER_NONE 0xFFu
-#define NIL 0x7FFF              /* list terminator (15-bit slot ids; bit 15 of a head = lane has a moving vehicle) */
-#define HALT_SPEED 0.1f
-#define STOP_OFFSET 1.0f
-#define ARR_NONE 65535
-#define FOE_GAP_Q 40
-#define MAX_HOPS 6
-#define BIGF 1.0e30f
-#define SG_ADVANTAGE 10.0f
-#define URGENT_DIST 50.0f
-#define SWAP_WAIT 20
-#define SWAP_EVERY 4
+// ---- what resco_step.h asks of its includer (the GPU flavour: LDS atomics, one thread per call of a phase)
+#define RS_DEV __device__ __forceinline__
+#define RS_HD __host__ __device__
+#define RS_MEM __device__ __forceinline__
+#define RS_CARVE __host__ __device__ __forceinline__
+__device__ __forceinline__ void rs_atomic_min(int32_t *p, int32_t v) { atomicMin(p, v); }
+__device__ __forceinline__ void rs_atomic_min(uint32_t *p, uint32_t v) { atomicMin(p, v); }
+__device__ __forceinline__ void rs_atomic_max(int32_t *p, int32_t v) { atomicMax(p, v); }
+__device__ __forceinline__ void rs_atomic_add(int32_t *p, int32_t v) { atomicAdd(p, v); }
+__device__ __forceinline__ void rs_atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+__device__ __forceinline__ void rs_atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
+__device__ __forceinline__ uint32_t rs_atomic_cas(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
+__device__ __forceinline__ int rs_ffsll(unsigned long long x) { return __ffsll(x); }
+__device__ __forceinline__ int rs_clzll(unsigned long long x) { return __clzll((long long)x); }
+__device__ __forceinline__ int rs_ffs(uint32_t x) { return __ffs((int)x); }
+__device__ __forceinline__ int rs_popc(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ float rs_int_as_float(int x) { return __int_as_float(x); }
+__device__ __forceinline__ int rs_float_as_int(float x) { return __float_as_int(x); }
+__device__ __forceinline__ uint16_t rs_f2h(float x) { return __half_as_ushort(__float2half(x)); }
 
-enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
-enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
-enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, ST_ACTIVE, ST_PENDING, ST_ACTIVE_TICKS, ST_TICKS, ST_N };
+extern __shared__ __attribute__((aligned(16))) char rs_smem[];      // THE working memory of a workgroup (dynamic LDS)
+#define RS_SMEM rs_smem
 
-#include "resco_kernels.h"
+#include "resco_step.h"
 #include "resco_policy.h"
+
+// ------------------------------------------------------------------------------------------------ kernels
+// grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 1024), normally one thread per slot.
+struct DevExec {
+    int B;
+    template <class F> __device__ __forceinline__ void phase(F f) { f((int)threadIdx.x); __syncthreads(); }
+};
+// Two register budgets: 64 VGPRs (two 1024-thread workgroups = 32 waves share a CU) and 128 VGPRs (blocks of <= 512);
+// CAP = the slot capacity as a compile-time constant (0: any)
+template <int CAP>
+__global__ void __launch_bounds__(1024, 8)
+rs_step_kernel_v64(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
+    if ((int)blockIdx.x >= P.n_envs) return;
+    DevExec ex{(int)blockDim.x};
+    rs_step_body<CAP>(ex, T, G, O, P, actions, (int)blockIdx.x);
+}
+template <int CAP>
+__global__ void __launch_bounds__(512, 4)
+rs_step_kernel_v128(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
+    if ((int)blockIdx.x >= P.n_envs) return;
+    DevExec ex{(int)blockDim.x};
+    rs_step_body<CAP>(ex, T, G, O, P, actions, (int)blockIdx.x);
+}
+
+// reset every environment: no vehicles, every backlog at its first trip, TLS programs freshly installed
+// (Signal.__init__, traffic_signal.py:93-100)
+__global__ void rs_reset_kernel(KTab T, State G, KParams P) {
+    const int env = blockIdx.x;
+    const int C = T.capacity, S = T.n_signals;
+    const size_t eo = (size_t)env * C;
+    for (int s = threadIdx.x; s < C; s += blockDim.x) {
+        G.lane()[eo + s] = LANE_NONE; G.trip()[eo + s] = TRIP_NONE; G.owner()[eo + s] = OWNER_NONE;
+        G.rwait()[eo + s] = 0; G.swait()[eo + s] = 0; G.cursor()[eo + s] = 0; G.depart()[eo + s] = 0; G.wtot()[eo + s] = 0;
+        G.pos()[eo + s] = 0.0f; G.speed()[eo + s] = 0.0f; G.accel()[eo + s] = 0.0f; G.tloss()[eo + s] = 0.0f; G.sf()[eo + s] = 1.0f;
+        G.coop()[eo + s] = COOP_NONE; G.cooplead()[eo + s] = COOP_NONE;
+    }
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        int ph, left;
+        if (P.fixed_program) { ph = T.cold->fix_init_phase[s]; left = T.cold->fix_init_left[s]; }
+        else { ph = T.cold->tls_init_phase[s]; left = T.cold->tls_dur[T.cold->tls_dur_off[s] + ph]; }
+        G.tls[(env * S + s) * 3 + 0] = ph; G.tls[(env * S + s) * 3 + 1] = left; G.tls[(env * S + s) * 3 + 2] = 0;
+    }
+    for (int d = threadIdx.x; d < T.n_dep; d += blockDim.x) G.dep_next[(size_t)env * T.n_dep + d] = T.cold->dep_first[d];
+    if (threadIdx.x < 4) G.env[env * 4 + threadIdx.x] = 0;
+    if (threadIdx.x < ST_N) G.stats[(size_t)env * ST_N + threadIdx.x] = 0;
+    if (G.trip_log)
+        for (int i = threadIdx.x; i < T.n_trips * 4; i += blockDim.x) G.trip_log[(size_t)env * T.n_trips * 4 + i] = 0;
+}
+
+// ---- static agents
+// STOCHASTIC (agents/stochastic.py:17-18): uniform green index per (env, signal, step)
+__global__ void rs_act_random_kernel(KTab T, KParams P, uint32_t step_key, int32_t *actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = T.n_signals;
+    if (i >= P.n_envs * S) return;
+    const int env = i / S, s = i - env * S;
+    const uint32_t h = d_hash(P.seed ^ 0xA5A5A5A5u, (uint32_t)(P.env_base + env), (uint32_t)s, step_key, 7u);
+    actions[i] = (int32_t)(h % (uint32_t)T.cold->tls_ngreen[s]);
+}
+// MAXWAVE / MAXPRESSURE (agents/maxwave.py:18-38, maxpressure.py:13-18): first maximum over the valid
+// phase pairs (in the reference's iteration order) of obs[pair0] + obs[pair1]
+__global__ void rs_act_maxwave_kernel(KTab T, KParams P, const int32_t *pairs, int n_pairs, const int32_t *valid, const int32_t *order,
+                                      int use_pressure, const int32_t *mplight, const int32_t *wave, int32_t *actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = T.n_signals;
+    if (i >= P.n_envs * S) return;
+    const int s = i % S;
+    const int32_t *obs = use_pressure ? mplight + (size_t)i * 13 + 1 : wave + (size_t)i * 12;
+    bool have = false;
+    int best = 0, best_act = 0;
+    for (int j = 0; j < n_pairs; ++j) {
+        const int p = order[s * n_pairs + j];     // the reference walks valid_acts in dict order; ties keep the first
+        if (p < 0) break;
+        const int act = valid[s * n_pairs + p];
+        if (act < 0) continue;
+        const int press = obs[pairs[p * 2]] + obs[pairs[p * 2 + 1]];
+        if (!have || press > best) { have = true; best = press; best_act = act; }
+    }
+    actions[i] = best_act;
+}
 
 // ------------------------------------------------------------------------------------------------ host side
 struct rs_sim {
     int device = 0;
     int n_envs = 0, env_base = 0, block = 256;
     size_t lds = 0;
-    Tab T{};
     KTab K{};
+    int use_v128 = 0;
     State G{};
     Out O{};
     KParams P{};
@@ -110,7 +194,7 @@ static int dev_upload(rs_sim *h, const Tp **dst, const Tp *src, size_t count) {
     return RS_OK;
 }
 
-static const size_t kDtypeSize[] = {4, 4, 2, 1, 2, 8};
+static const size_t kDtypeSize[] = {4, 4, 2, 1, 2, 8, 4};
 static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_t a, int64_t b = 1, int64_t c = 1, int64_t d = 1) {
     auto &B = h->bufs[which];
     B.ptr = ptr; B.dtype = dtype; B.ndim = ndim;
@@ -118,17 +202,15 @@ static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_
     B.bytes = (size_t)(a * b * c * d) * kDtypeSize[dtype];
 }
 
-// the step kernel is instantiated for the capacities compile_scenario produces (constant LDS offsets); any other
-// capacity runs the generic instantiation
 typedef void (*step_kernel_fn)(KTab, State, Out, KParams, const int32_t *);
 static const int kStepCaps[] = {0, 128, 256, 512, 1024};
-static step_kernel_fn step_kernel_for(int capacity) {
+static step_kernel_fn step_kernel_for(int v128, int capacity) {
     switch (capacity) {
-        case 128: return rs_step_kernel<128>;
-        case 256: return rs_step_kernel<256>;
-        case 512: return rs_step_kernel<512>;
-        case 1024: return rs_step_kernel<1024>;
-        default: return rs_step_kernel<0>;
+        case 128: return v128 ? rs_step_kernel_v128<128> : rs_step_kernel_v64<128>;
+        case 256: return v128 ? rs_step_kernel_v128<256> : rs_step_kernel_v64<256>;
+        case 512: return v128 ? rs_step_kernel_v128<512> : rs_step_kernel_v64<512>;
+        case 1024: return v128 ? rs_step_kernel_v128<1024> : rs_step_kernel_v64<1024>;
+        default: return v128 ? rs_step_kernel_v128<0> : rs_step_kernel_v64<0>;
     }
 }
 
@@ -154,212 +236,47 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     }
     const int C = sc->capacity;
     if (C < 64 || (C & (C - 1)) || C > 16384) { h->err = "capacity must be a power of two in [64, 16384]"; return fail(RS_ELIMIT); }
-    if (sc->n_lanes >= 0xFFFE || sc->n_trips >= 0xFFFF || sc->n_routes > 0xFFFF || sc->n_vtypes > 255 || sc->n_signals > 254) {
-        h->err = "scenario exceeds id widths (lanes/trips/routes u16, vtypes/signals u8)"; return fail(RS_ELIMIT);
-    }
-    Tab &T = h->T;
-    int rc;
-#define X(name, type, count)                                                                  \
-    if ((rc = dev_upload<type>(h, &T.name, sc->name, (size_t)(sc->count)))) return fail(rc);
-    RS_TABLES(X)
-#undef X
-    T.n_lanes = sc->n_lanes; T.n_links = sc->n_links; T.n_edges = sc->n_edges; T.n_routes = sc->n_routes;
-    T.n_trips = sc->n_trips; T.n_signals = sc->n_signals; T.n_obs = sc->n_obs; T.n_vtypes = sc->n_vtypes;
-    T.horizon = sc->horizon; T.capacity = C; T.step_length = sc->step_length; T.yellow_length = sc->yellow_length;
-    std::vector<int32_t> obs_sig((size_t)sc->n_obs > 0 ? sc->n_obs : 1, 0);
-    int lmax = 1;
-    for (int s = 0; s < sc->n_signals; ++s) {
-        for (int oi = sc->sig_obs_start[s]; oi < sc->sig_obs_start[s + 1]; ++oi) obs_sig[oi] = s;
-        int n = sc->sig_obs_start[s + 1] - sc->sig_obs_start[s];
-        if (n > lmax) lmax = n;
-    }
-    T.lmax = lmax;
-    if ((rc = dev_upload<int32_t>(h, &T.obs_sig, obs_sig.data(), obs_sig.size()))) return fail(rc);
+    if (sc->kmax < 1 || sc->kmax > 16) { h->err = "kmax (lanes per edge) must be in [1, 16]"; return fail(RS_ELIMIT); }
+    PackedTables PT;
+    if (!PT.build(sc)) { h->err = PT.err; return fail(RS_ELIMIT); }
     h->tls_ngreen.assign(sc->tls_ngreen, sc->tls_ngreen + sc->n_signals);
-    int tls_maxl = 1;
-    for (int s = 0; s < sc->n_signals; ++s) if (sc->tls_nlinks[s] > tls_maxl) tls_maxl = sc->tls_nlinks[s];
-    // ---- packed 16-byte records for the step kernel
+    int rc;
+    KTab &K = h->K;
     {
-        if (sc->n_route_steps >= 0xFFFF || sc->n_foes >= 0xFFFF || sc->n_links >= 0x7FFF || sc->n_edges >= 0xFFFF || sc->n_obs >= 0x7FFF) {
-            h->err = "scenario exceeds packed-table id widths (route steps / foes / links / edges u16)"; return fail(RS_ELIMIT);
-        }
-        std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
-        int n_foe_targets = 0;
-        for (int l = 0; l < sc->n_links; ++l)
-            for (int i = sc->link_foe_start[l]; i < sc->link_foe_start[l] + sc->link_foe_cnt[l]; ++i) {
-                int f = sc->foe_link[i];
-                if (link_arr[f] < 0) link_arr[f] = (int16_t)n_foe_targets++;
-            }
-        std::vector<LaneRec> lanes((size_t)sc->n_lanes);
-        for (int l = 0; l < sc->n_lanes; ++l) {
-            LaneRec &R = lanes[l];
-            R.len = sc->lane_len[l]; R.vmax = sc->lane_vmax[l];
-            R.link_start = (uint16_t)sc->lane_link_start[l];
-            if (sc->lane_link_cnt[l] > 255) { h->err = "more than 255 links on one lane"; return fail(RS_ELIMIT); }
-            R.link_cnt = (uint8_t)sc->lane_link_cnt[l];
-            int e = sc->lane_edge[l];
-            int nl = e >= 0 ? sc->edge_nlanes[e] : 0;
-            R.flags = (uint8_t)((sc->lane_internal[l] ? LF_INTERNAL : 0u) | ((unsigned)nl << 2));
-            R.cell0 = 0;        // filled below
-            R.edge_lane0 = (uint16_t)(e >= 0 ? sc->edge_lane0[e] : 0);
-        }
-        // list cells: floor(len / CELL_LEN) + 1 per lane, lanes in index order (lanes of one edge are consecutive
-        // and equally long, so their cell blocks are consecutive and equally sized -- relied on by the lane change)
-        int n_cells = 0;
-        std::vector<int> lane_nc((size_t)sc->n_lanes);
-        for (int l = 0; l < sc->n_lanes; ++l) {
-            lane_nc[l] = (int)(sc->lane_len[l] * CELL_INV) + 1;
-            lanes[l].cell0 = (uint16_t)n_cells;
-            n_cells += lane_nc[l];
-        }
-        if (n_cells >= 0x7FFF) { h->err = "too many list cells"; return fail(RS_ELIMIT); }
-        for (int e = 0; e < sc->n_edges; ++e)
-            for (int j = 1; j < sc->edge_nlanes[e]; ++j)
-                if (lane_nc[sc->edge_lane0[e] + j] != lane_nc[sc->edge_lane0[e]]) { h->err = "lanes of one edge differ in length"; return fail(RS_ELIMIT); }
-        {
-            float max_len = 0.0f, max_gap = 0.0f;
-            for (int v = 0; v < sc->n_vtypes; ++v) {
-                if (sc->vtype_params[v * VT_COLS + VT_LENGTH] > max_len) max_len = sc->vtype_params[v * VT_COLS + VT_LENGTH];
-                if (sc->vtype_params[v * VT_COLS + VT_MINGAP] > max_gap) max_gap = sc->vtype_params[v * VT_COLS + VT_MINGAP];
-            }
-            // the insertion check scans cell 0 only: everything that can be in the way must sit there
-            if (2.0f * max_len + max_gap >= CELL_LEN) { h->err = "vehicle length + minGap + length must stay below the list cell size"; return fail(RS_ELIMIT); }
-        }
-        std::vector<int16_t> lane_obs16((size_t)sc->n_lanes);
-        for (int l = 0; l < sc->n_lanes; ++l) lane_obs16[l] = (int16_t)sc->lane_obs[l];
-        std::vector<LinkRec> links((size_t)sc->n_links);
-        for (int l = 0; l < sc->n_links; ++l) {
-            LinkRec &R = links[l];
-            R.to_lane = (uint16_t)sc->link_to_lane[l]; R.to_edge = (uint16_t)sc->link_to_edge[l];
-            R.foe_start = (uint16_t)sc->link_foe_start[l];
-            R.via2 = sc->link_via2[l] >= 0 ? (uint16_t)sc->link_via2[l] : (uint16_t)0xFFFF;
-            R.arr_idx = link_arr[l];
-            R.tls = sc->link_tls[l] >= 0 ? (uint8_t)sc->link_tls[l] : (uint8_t)0xFF;
-            R.tls_pos = sc->link_tls[l] >= 0 ? (uint8_t)sc->link_tls_pos[l] : (uint8_t)0;
-            if (sc->link_foe_cnt[l] > 255 || (sc->link_tls[l] >= 0 && sc->link_tls_pos[l] > 255)) { h->err = "foe count / TLS link index exceeds u8"; return fail(RS_ELIMIT); }
-            R.foe_cnt = (uint8_t)sc->link_foe_cnt[l];
-            R.flags = (uint8_t)((sc->link_minor[l] ? KF_MINOR : 0u) | (sc->link_cont[l] ? KF_CONT : 0u) | (sc->link_via1[l] >= 0 ? KF_VIA1 : 0u));
-            R.dest_k = (uint8_t)(sc->link_dest_lane[l] - sc->edge_lane0[sc->link_to_edge[l]]);
-            R.pad = 0;
-            R.dest = lanes[sc->link_to_lane[l]];
-        }
-        std::vector<FoeRec> foes((size_t)(sc->n_foes > 0 ? sc->n_foes : 1));
-        for (int i = 0; i < sc->n_foes; ++i) {
-            int f = sc->foe_link[i];
-            FoeRec &R = foes[i];
-            R.arr_idx = link_arr[f];
-            R.tls = sc->link_tls[f] >= 0 ? (uint8_t)sc->link_tls[f] : (uint8_t)0xFF;
-            R.tls_pos = sc->link_tls[f] >= 0 ? (uint8_t)sc->link_tls_pos[f] : (uint8_t)0;
-            const int v1 = sc->link_via1[f], v2 = sc->link_via2[f];
-            R.via1_cell0 = v1 >= 0 ? lanes[v1].cell0 : (uint16_t)0xFFFF;
-            R.via2_cell0 = v2 >= 0 ? lanes[v2].cell0 : (uint16_t)0xFFFF;
-            R.via1_nc = v1 >= 0 ? (uint8_t)lane_nc[v1] : (uint8_t)0;
-            R.via2_nc = v2 >= 0 ? (uint8_t)lane_nc[v2] : (uint8_t)0;
-            memset(R.pad, 0, sizeof(R.pad));
-        }
-        std::vector<RStep> rsteps((size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1));
-        std::vector<RouteRec> routes((size_t)sc->n_routes);
-        std::vector<int16_t> lane_dep((size_t)sc->n_lanes, -1);
-        int n_dep = 0;
-        for (int r = 0; r < sc->n_routes; ++r) {
-            const int rs = sc->route_start[r], re = sc->route_start[r + 1];
-            for (int q = rs; q < re; ++q) {
-                RStep &R = rsteps[q];
-                R.edge = (uint16_t)sc->route_edge[q];
-                const bool last = q + 1 >= re;
-                R.next_edge = last ? (uint16_t)0xFFFF : (uint16_t)sc->route_edge[q + 1];
-                R.next_mask2 = last ? 0u : sc->route_mask2[q + 1];
-                R.next_mask1 = last ? 0u : sc->route_mask1[q + 1];
-                R.tlsdist = sc->route_tlsdist[q];
-            }
-            const uint32_t m = sc->route_mask2[rs];
-            const int e = sc->route_edge[rs];
-            int k = 0;
-            while (k < 31 && !((m >> k) & 1u)) k += 1;
-            if (k >= sc->edge_nlanes[e]) k = 0;
-            const int dl = sc->edge_lane0[e] + k;
-            if (lane_dep[dl] < 0) lane_dep[dl] = (int16_t)n_dep++;
-            routes[r].start = (uint32_t)rs; routes[r].depart_lane = (uint16_t)dl; routes[r].depart_arr = lane_dep[dl];
-            routes[r].depart_cell0 = lanes[dl].cell0; routes[r].depart_len = sc->lane_len[dl];
-            {   // choose_link(departure lane, first route step) + the approach-register flag, as cache_link() computes it
-                int link = -1;
-                if (re - rs >= 2) {
-                    const int ne = sc->route_edge[rs + 1];
-                    const uint32_t pref = sc->route_mask2[rs + 1], okm = sc->route_mask1[rs + 1];
-                    int best = -1, any = -1;
-                    for (int l = sc->lane_link_start[dl]; l < sc->lane_link_start[dl] + sc->lane_link_cnt[dl]; ++l) {
-                        if (sc->link_to_edge[l] != ne) continue;
-                        const int kk = sc->link_dest_lane[l] - sc->edge_lane0[ne];
-                        if ((pref >> kk) & 1u) { link = l; break; }
-                        if (best < 0 && ((okm >> kk) & 1u)) best = l;
-                        if (any < 0) any = l;
-                    }
-                    if (link < 0) link = best >= 0 ? best : any;
-                }
-                routes[r].first_link = link < 0 ? (uint16_t)NLINK_NONE : (uint16_t)(link | (link_arr[link] >= 0 ? NLINK_ARR : 0));
-            }
-        }
-        std::vector<uint16_t> trip_route((size_t)sc->n_trips);
-        std::vector<uint8_t> trip_vtype((size_t)sc->n_trips);
-        for (int k = 0; k < sc->n_trips; ++k) { trip_route[k] = (uint16_t)sc->trip_route[k]; trip_vtype[k] = (uint8_t)sc->trip_vtype[k]; }
-        // choose_link() of every (route step, lane of that step's edge): the look-ahead and the lane hand-over read it
-        int kmax = 1;
-        for (int e = 0; e < sc->n_edges; ++e) if (sc->edge_nlanes[e] > kmax) kmax = sc->edge_nlanes[e];
-        std::vector<uint16_t> next_link((size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1) * kmax, (uint16_t)0xFFFF);
-        for (int r = 0; r < sc->n_routes; ++r) {
-            const int rs = sc->route_start[r], re = sc->route_start[r + 1];
-            for (int q = rs; q + 1 < re; ++q) {
-                const int e = sc->route_edge[q], ne = sc->route_edge[q + 1];
-                const uint32_t pref = sc->route_mask2[q + 1], okm = sc->route_mask1[q + 1];
-                for (int k = 0; k < sc->edge_nlanes[e]; ++k) {
-                    const int ln = sc->edge_lane0[e] + k;
-                    int link = -1, best = -1, any = -1;
-                    for (int l = sc->lane_link_start[ln]; l < sc->lane_link_start[ln] + sc->lane_link_cnt[ln]; ++l) {
-                        if (sc->link_to_edge[l] != ne) continue;
-                        const int kk = sc->link_dest_lane[l] - sc->edge_lane0[ne];
-                        if ((pref >> kk) & 1u) { link = l; break; }
-                        if (best < 0 && ((okm >> kk) & 1u)) best = l;
-                        if (any < 0) any = l;
-                    }
-                    if (link < 0) link = best >= 0 ? best : any;
-                    if (link >= 0) next_link[(size_t)q * kmax + k] = (uint16_t)link;
-                }
-            }
-        }
-        std::vector<uint8_t> tls8((size_t)(sc->n_tls_states > 0 ? sc->n_tls_states : 1)), fix8((size_t)(sc->n_fix_states > 0 ? sc->n_fix_states : 1));
-        for (int i = 0; i < sc->n_tls_states; ++i) tls8[i] = (uint8_t)sc->tls_states[i];
-        for (int i = 0; i < sc->n_fix_states; ++i) fix8[i] = (uint8_t)sc->fix_states[i];
-        KTab &K = h->K;
-        const int16_t *lane_obs_dev = nullptr;
-        const uint8_t *tls8_dev = nullptr, *fix8_dev = nullptr;
-        if ((rc = dev_upload<LaneRec>(h, &K.lanes, lanes.data(), lanes.size())) || (rc = dev_upload<LinkRec>(h, &K.links, links.data(), links.size())) ||
-            (rc = dev_upload<FoeRec>(h, &K.foes, foes.data(), foes.size())) || (rc = dev_upload<RStep>(h, &K.rsteps, rsteps.data(), rsteps.size())) ||
-            (rc = dev_upload<RouteRec>(h, &K.routes, routes.data(), routes.size())) ||
-            (rc = dev_upload<uint16_t>(h, &K.next_link, next_link.data(), next_link.size())) ||
-            (rc = dev_upload<uint16_t>(h, &K.trip_route, trip_route.data(), trip_route.size())) ||
-            (rc = dev_upload<uint8_t>(h, &K.trip_vtype, trip_vtype.data(), trip_vtype.size())) ||
-            (rc = dev_upload<int16_t>(h, &lane_obs_dev, lane_obs16.data(), lane_obs16.size())) ||
-            (rc = dev_upload<uint8_t>(h, &tls8_dev, tls8.data(), tls8.size())) || (rc = dev_upload<uint8_t>(h, &fix8_dev, fix8.data(), fix8.size())))
-            return fail(rc);
-        K.route_mask2 = T.route_mask2;
-        K.kmax = kmax;
         KCold cold{};
-        cold.trip_depart = T.trip_depart; cold.trips_cum = T.trips_cum; cold.vtype_params = T.vtype_params;
-        cold.tls8 = tls8_dev; cold.fix8 = fix8_dev; cold.lane_obs = lane_obs_dev;
-        cold.tls_nphase = T.tls_nphase; cold.tls_ngreen = T.tls_ngreen; cold.tls_nlinks = T.tls_nlinks; cold.tls_state_off = T.tls_state_off;
-        cold.tls_dur_off = T.tls_dur_off; cold.tls_yel_off = T.tls_yel_off; cold.tls_dur = T.tls_dur; cold.tls_yellow = T.tls_yellow;
-        cold.fix_nphase = T.fix_nphase; cold.fix_state_off = T.fix_state_off; cold.fix_dur_off = T.fix_dur_off; cold.fix_dur = T.fix_dur;
-        cold.obs_sig = T.obs_sig; cold.sig_obs_start = T.sig_obs_start; cold.mv_in_start = T.mv_in_start; cold.mv_in_idx = T.mv_in_idx;
-        cold.mv_out_start = T.mv_out_start; cold.mv_out_idx = T.mv_out_idx; cold.pr_out_start = T.pr_out_start; cold.pr_out_idx = T.pr_out_idx;
-        if ((rc = dev_upload<KCold>(h, &K.cold, &cold, 1))) return fail(rc);
-        K.n_trips = sc->n_trips; K.tls_maxl = tls_maxl;
-        K.n_lanes = sc->n_lanes; K.n_cells = n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes; K.horizon = sc->horizon;
-        K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = lmax;
-        K.n_arr = n_foe_targets > 0 ? n_foe_targets : 1;
-        K.n_dep = n_dep > 0 ? n_dep : 1;
-        T.n_arr = K.n_arr;
+#define UP(dst, type, src, count) if ((rc = dev_upload<type>(h, &dst, src, (size_t)(count)))) return fail(rc);
+        UP(K.lanes, LaneRec, PT.lanes.data(), PT.lanes.size()) UP(K.links, LinkRec, PT.links.data(), PT.links.size())
+        UP(K.foes, FoeRec, PT.foes.data(), PT.foes.size()) UP(K.rsteps, RStep, PT.rsteps.data(), PT.rsteps.size())
+        UP(K.routes, RouteRec, PT.routes.data(), PT.routes.size()) UP(K.next_link, uint16_t, PT.next_link.data(), PT.next_link.size())
+        UP(K.trip_route, uint16_t, PT.trip_route.data(), PT.trip_route.size()) UP(K.trip_vtype, uint8_t, PT.trip_vtype.data(), PT.trip_vtype.size())
+        UP(K.route_cont, float, sc->route_cont, (size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1) * sc->kmax)
+        UP(cold.trip_depart, int32_t, sc->trip_depart, sc->n_trips) UP(cold.trip_next, uint16_t, PT.trip_next.data(), PT.trip_next.size())
+        UP(cold.dep_lane, uint16_t, PT.dep_lane.data(), PT.dep_lane.size()) UP(cold.dep_first, uint16_t, PT.dep_first.data(), PT.dep_first.size())
+        UP(cold.vtype_params, float, sc->vtype_params, sc->n_vtypes * VT_COLS)
+        UP(cold.tls8, uint8_t, PT.tls8.data(), PT.tls8.size()) UP(cold.fix8, uint8_t, PT.fix8.data(), PT.fix8.size())
+        UP(cold.tls_nphase, int32_t, sc->tls_nphase, sc->n_signals) UP(cold.tls_ngreen, int32_t, sc->tls_ngreen, sc->n_signals)
+        UP(cold.tls_nlinks, int32_t, sc->tls_nlinks, sc->n_signals) UP(cold.tls_state_off, int32_t, sc->tls_state_off, sc->n_signals)
+        UP(cold.tls_dur_off, int32_t, sc->tls_dur_off, sc->n_signals) UP(cold.tls_yel_off, int32_t, sc->tls_yel_off, sc->n_signals)
+        UP(cold.tls_dur, int32_t, sc->tls_dur, sc->n_tls_dur) UP(cold.tls_yellow, int32_t, sc->tls_yellow, sc->n_tls_yellow)
+        UP(cold.tls_init_phase, int32_t, sc->tls_init_phase, sc->n_signals)
+        UP(cold.fix_nphase, int32_t, sc->fix_nphase, sc->n_signals) UP(cold.fix_state_off, int32_t, sc->fix_state_off, sc->n_signals)
+        UP(cold.fix_dur_off, int32_t, sc->fix_dur_off, sc->n_signals) UP(cold.fix_dur, int32_t, sc->fix_dur, sc->n_fix_dur)
+        UP(cold.fix_init_phase, int32_t, sc->fix_init_phase, sc->n_signals) UP(cold.fix_init_left, int32_t, sc->fix_init_left, sc->n_signals)
+        UP(cold.lane_obs, int16_t, PT.lane_obs16.data(), PT.lane_obs16.size()) UP(cold.obs_sig, int32_t, PT.obs_sig.data(), PT.obs_sig.size())
+        UP(cold.sig_obs_start, int32_t, sc->sig_obs_start, sc->n_signals + 1)
+        UP(cold.mv_in_start, int32_t, sc->mv_in_start, sc->n_signals * 12 + 1) UP(cold.mv_in_idx, int32_t, sc->mv_in_idx, sc->n_mv_in)
+        UP(cold.mv_out_start, int32_t, sc->mv_out_start, sc->n_signals * 12 + 1) UP(cold.mv_out_idx, int32_t, sc->mv_out_idx, sc->n_mv_out)
+        UP(cold.pr_out_start, int32_t, sc->pr_out_start, sc->n_signals + 1) UP(cold.pr_out_idx, int32_t, sc->pr_out_idx, sc->n_pr_out)
+        UP(cold.trips_cum, int32_t, sc->trips_cum, sc->horizon + 2)
+        UP(K.cold, KCold, &cold, 1)
+#undef UP
+        K.maxlen = PT.maxlen;
+        K.n_trips = sc->n_trips; K.tls_maxl = PT.tls_maxl; K.kmax = sc->kmax;
+        K.n_lanes = sc->n_lanes; K.n_cells = PT.n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes;
+        K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = PT.lmax;
+        K.n_arr = PT.n_arr; K.n_dep = PT.n_dep;
     }
-
+    const int lmax = PT.lmax;
 
     h->P.seed = p->seed; h->P.env_base = env_base; h->P.max_distance = p->max_distance; h->P.sigma = p->sigma;
     h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.n_envs = n_envs;
@@ -373,6 +290,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         O.n = n_envs; O.o = sc->n_obs; O.s = sc->n_signals; O.lm = lmax;
         if ((rc = dev_alloc(h, &slab, State::bytes(NC))) || (rc = dev_alloc(h, &outb, O.bytes())) ||
             (rc = dev_alloc(h, &G.env, N * 4)) || (rc = dev_alloc(h, &G.tls, N * S * 3)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
+            (rc = dev_alloc(h, &G.dep_next, N * (size_t)h->K.n_dep)) ||
             (rc = dev_alloc(h, &h->actions, N * S)))
             return fail(rc);
         G.base = slab; O.base = outb;
@@ -410,13 +328,20 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     G.trip_log = nullptr;
     if (p->trip_log && (rc = dev_alloc(h, &G.trip_log, N * (size_t)sc->n_trips * 4))) return fail(rc);
     set_buf(h, RS_BUF_TRIP_LOG, G.trip_log, RS_I32, 3, n, p->trip_log ? sc->n_trips : 0, 4);
+    set_buf(h, RS_BUF_DEP_NEXT, G.dep_next, RS_U16, 2, n, h->K.n_dep);
+    set_buf(h, RS_BUF_VEH_COOP, G.coop(), RS_U32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_COOPLEAD, G.cooplead(), RS_U32, 2, n, c);
+    set_buf(h, RS_BUF_ARRIVALS, O.arrivals(), RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_DEPARTURES, O.departures(), RS_I32, 2, n, s);
+    set_buf(h, RS_BUF_MPLIGHT_FULL, O.mplight_full(), RS_F32, 3, n, s, 49);
 
-    h->lds = lds_bytes_for(C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, tls_maxl);
+    h->lds = lds_carve(nullptr, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
-    if (block_threads <= 0) {
-        block_threads = C >= 512 ? 512 : (C >= 256 ? 256 : (C >= 128 ? 128 : 64));
-    }
-    if (block_threads % 64 || block_threads > 1024 || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024]"; return fail(RS_EINVAL); }
+    // block_threads: 0 = one thread per slot (at most 1024); a negative value selects the 128-VGPR build with |value|
+    // threads (<= 512) -- a tuning knob, see DESIGN.md
+    if (block_threads < 0) { h->use_v128 = 1; block_threads = -block_threads; }
+    if (block_threads == 0) block_threads = C > 1024 ? 1024 : C;
+    if (block_threads % 64 || block_threads > (h->use_v128 ? 512 : 1024) || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024] ([64, 512] for the 128-VGPR build)"; return fail(RS_EINVAL); }
     h->block = block_threads;
     {
         // the dynamic-LDS ceiling is an attribute of the kernel (per device), not of a launch: only ever raise it,
@@ -426,10 +351,11 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         std::lock_guard<std::mutex> lock(mu);
         size_t &cur = max_lds[device_id & 63];
         if (h->lds > cur) {
-            for (int c : kStepCaps)        // every instantiation: the ceiling is per kernel function
-                if (hipFuncSetAttribute((const void *)step_kernel_for(c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
-                    h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
-                }
+            for (int v = 0; v < 2; ++v)
+                for (int cp : kStepCaps)        // every instantiation: the ceiling is per kernel function
+                    if (hipFuncSetAttribute((const void *)step_kernel_for(v, cp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+                        h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
+                    }
             cur = h->lds;
         }
     }
@@ -443,30 +369,6 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
 extern "C" void rs_destroy(rs_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-#ifdef RS_BARWAIT
-    {
-        unsigned long long b[64];
-        int ln[56];
-        (void)hipDeviceSynchronize();
-        if (hipMemcpyFromSymbol(b, HIP_SYMBOL(g_bar), sizeof(b)) == hipSuccess && hipMemcpyFromSymbol(ln, HIP_SYMBOL(g_bar_line), sizeof(ln)) == hipSuccess) {
-            fprintf(stderr, "RS_BARWAIT barrier wait %llu  wave lifetime %llu  (%.1f %%)  barriers per wave %llu\n", b[0], b[1], 100.0 * (double)b[0] / (double)(b[1] ? b[1] : 1), b[2]);
-            for (int i = 0; i < 32; ++i) if (b[8 + i]) fprintf(stderr, "RS_BARWAIT   barrier at resco_kernels.h:%d  %.1f %% of the wave lifetime\n", ln[i], 100.0 * (double)b[8 + i] / (double)(b[1] ? b[1] : 1));
-        }
-    }
-#endif
-#ifdef RS_COUNT
-    {
-        unsigned long long c[32];
-        (void)hipDeviceSynchronize();
-        if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_count), sizeof(c)) == hipSuccess) {
-            static const char *nm[] = {"leader_of calls", "leader_of own-cell nodes", "leader_of further cells", "leader_of further nodes", "rearmost calls",
-                                       "rearmost cells", "rearmost nodes", "neighbours calls", "neighbours nodes", "list_push calls", "list_push CAS rounds",
-                                       "hop iterations", "foe records", "mover-flag cells", "move lane hand-overs", "choose_link records", "lane-change candidates",
-                                       "vehicle-ticks (plan)", "vehicles entering the hop loop"};
-            for (int i = 0; i < 19; ++i) fprintf(stderr, "RS_COUNT %-32s %llu\n", nm[i], c[i]);
-        }
-    }
-#endif
     if (h->stream) { (void)wait_idle(h); (void)hipStreamDestroy(h->stream); }
     for (auto &e : h->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void *p : h->allocs) (void)hipFree(p);
@@ -478,13 +380,6 @@ extern "C" const char *rs_last_error(rs_handle h) { return h ? h->err.c_str() : 
 static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
     KParams P = h->P;
     P.n_ticks = n_ticks; P.do_fsm = do_fsm; P.prof = h->prof;
-#ifdef RS_DIAG
-    {   // skip mask applied only after RS_DIAG_AFTER launches, so that the traffic state is the real one
-        static int n_launch = 0;
-        const char *e = getenv("RS_DIAG_SKIP"), *a = getenv("RS_DIAG_AFTER");
-        P.diag = (e && ++n_launch > (a ? atoi(a) : 0)) ? atoi(e) : 0;
-    }
-#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         if (h->ev_used == h->events.size()) {
@@ -497,7 +392,7 @@ static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
         h->ev_used += 1;
         HIPCHK(h, hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(step_kernel_for(h->K.capacity), dim3(h->n_envs), dim3(h->block), h->lds, st, h->K, h->G, h->O, P, (const int32_t *)h->actions);
+    hipLaunchKernelGGL(step_kernel_for(h->use_v128, h->K.capacity), dim3(h->n_envs), dim3(h->block), h->lds, st, h->K, h->G, h->O, P, (const int32_t *)h->actions);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     return RS_OK;
@@ -508,7 +403,7 @@ extern "C" int rs_reset(rs_handle h, void *stream) {
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     h->last = st;
-    hipLaunchKernelGGL(rs_reset_kernel, dim3(h->n_envs), dim3(256), 0, st, h->T, h->G, h->P);
+    hipLaunchKernelGGL(rs_reset_kernel, dim3(h->n_envs), dim3(256), 0, st, h->K, h->G, h->P);
     HIPCHK(h, hipGetLastError());
     bool tm = h->timing;
     h->timing = false;
@@ -523,12 +418,12 @@ extern "C" int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_d
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     h->last = st;
     if (actions) {
-        size_t bytes = (size_t)h->n_envs * h->T.n_signals * sizeof(int32_t);
+        size_t bytes = (size_t)h->n_envs * h->K.n_signals * sizeof(int32_t);
         HIPCHK(h, hipMemcpyAsync(h->actions, actions, bytes, actions_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         // a pageable host source may be read after the call returns: make the caller's buffer reusable
         if (!actions_on_device) HIPCHK(h, hipStreamSynchronize(st));
     }
-    return launch_step(h, st, h->T.step_length, 1);
+    return launch_step(h, st, h->K.step_length, 1);
 }
 
 extern "C" int rs_sync(rs_handle h) {
@@ -543,8 +438,8 @@ extern "C" int rs_act_random(rs_handle h, uint32_t step_key, void *stream) {
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     h->last = st;
-    int total = h->n_envs * h->T.n_signals;
-    hipLaunchKernelGGL(rs_act_random_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->T, h->P, step_key, h->actions);
+    int total = h->n_envs * h->K.n_signals;
+    hipLaunchKernelGGL(rs_act_random_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->K, h->P, step_key, h->actions);
     HIPCHK(h, hipGetLastError());
     return RS_OK;
 }
@@ -558,15 +453,15 @@ extern "C" int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n
     if (!h->pairs) {
         if (!phase_pairs || !valid || !order) { h->err = "rs_act_maxwave: tables required on first use"; return RS_EINVAL; }
         int rc;
-        if ((rc = dev_alloc(h, &h->pairs, (size_t)n_pairs * 2, false)) || (rc = dev_alloc(h, &h->valid, (size_t)h->T.n_signals * n_pairs, false)) ||
-            (rc = dev_alloc(h, &h->order, (size_t)h->T.n_signals * n_pairs, false))) return rc;
-        HIPCHK(h, hipMemcpy(h->order, order, (size_t)h->T.n_signals * n_pairs * 4, hipMemcpyHostToDevice));
+        if ((rc = dev_alloc(h, &h->pairs, (size_t)n_pairs * 2, false)) || (rc = dev_alloc(h, &h->valid, (size_t)h->K.n_signals * n_pairs, false)) ||
+            (rc = dev_alloc(h, &h->order, (size_t)h->K.n_signals * n_pairs, false))) return rc;
+        HIPCHK(h, hipMemcpy(h->order, order, (size_t)h->K.n_signals * n_pairs * 4, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(h->pairs, phase_pairs, (size_t)n_pairs * 2 * 4, hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->valid, valid, (size_t)h->T.n_signals * n_pairs * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->valid, valid, (size_t)h->K.n_signals * n_pairs * 4, hipMemcpyHostToDevice));
         h->n_pairs = n_pairs;
     }
-    int total = h->n_envs * h->T.n_signals;
-    hipLaunchKernelGGL(rs_act_maxwave_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->T, h->P, (const int32_t *)h->pairs,
+    int total = h->n_envs * h->K.n_signals;
+    hipLaunchKernelGGL(rs_act_maxwave_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->K, h->P, (const int32_t *)h->pairs,
                        h->n_pairs, (const int32_t *)h->valid, (const int32_t *)h->order, (int)use_pressure, (const int32_t *)h->O.mplight(),
                        (const int32_t *)h->O.wave(), h->actions);
     HIPCHK(h, hipGetLastError());
@@ -604,7 +499,8 @@ static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, 
                                 RS_BUF_WAIT_NORM, RS_BUF_PRESSURE, RS_BUF_QUEUE_SUM, RS_BUF_QUEUE_MAX, RS_BUF_DRQ_NORM_F16,
                                 RS_BUF_ENV, RS_BUF_TLS, RS_BUF_VEH_POS, RS_BUF_VEH_SPEED, RS_BUF_VEH_ACCEL, RS_BUF_VEH_TLOSS,
                                 RS_BUF_VEH_LANE, RS_BUF_VEH_TRIP, RS_BUF_VEH_CURSOR, RS_BUF_VEH_SWAIT, RS_BUF_VEH_RWAIT,
-                                RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_VEH_SF, RS_BUF_VEH_WTOT, RS_BUF_TRIP_LOG, RS_BUF_STATS};
+                                RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_VEH_SF, RS_BUF_VEH_WTOT, RS_BUF_TRIP_LOG, RS_BUF_STATS,
+                                RS_BUF_DEP_NEXT, RS_BUF_VEH_COOP, RS_BUF_VEH_COOPLEAD, RS_BUF_ARRIVALS, RS_BUF_DEPARTURES, RS_BUF_MPLIGHT_FULL};
 extern "C" int rs_snapshot(rs_handle h, void **snap) {
     if (!h || !snap) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
@@ -679,7 +575,7 @@ extern "C" int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int
     if (n_envs) *n_envs = h->n_envs;
     if (block_threads) *block_threads = h->block;
     if (lds_bytes) *lds_bytes = (int32_t)h->lds;
-    if (max_lanes_per_signal) *max_lanes_per_signal = h->T.lmax;
+    if (max_lanes_per_signal) *max_lanes_per_signal = h->K.lmax;
     return RS_OK;
 }
 

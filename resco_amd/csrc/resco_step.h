@@ -1,0 +1,1068 @@
+// resco_step.h -- the fused MultiSignal.step() of one environment: FSM + step_length one-second ticks of the
+// microsimulation + Signal.observe + states / rewards, as a sequence of PHASES over the vehicle slots of the environment.
+//
+// The body is written against a small execution interface (`Exec`):
+//   ex.phase(f)   runs f(tid) for every thread of the workgroup and ends with a workgroup barrier
+// On the GPU (resco_sim.hip) one workgroup = one environment, a thread owns the slots tid, tid + B, ...; the state lives
+// in LDS for the whole env-step and phase() is `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same
+// source for the host (tests/hostemu), where phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never
+// reads what another thread writes in the same phase, except through the order-independent atomics below).
+//
+// Including file provides: RS_DEV / RS_HD / RS_CARVE (function qualifiers; RS_CARVE must force inlining on the device), the atomics rs_atomic_min/max/add/or/and/cas on 32-bit words of
+// the working memory, RS_SMEM (its base, see LPtr), rs_f2h (float -> half bits), and <math.h> sqrtf/floorf.
+#pragma once
+#include "resco_tables.h"
+
+// ------------------------------------------------------------------------------------------------ HBM layout
+// Kernel arguments are kept SMALL on purpose: every pointer passed by value costs two SGPRs for the whole kernel.  The
+// per-slot state and the outputs are therefore ONE allocation each, with field addresses computed from (base, N*C).
+struct State {      // env-major SoA in HBM: field[env][slot]
+    char *base;
+    size_t nc;          // N * C
+    int32_t *trip_log;  // [N][n_trips][4] or NULL
+    int32_t *env;       // [N][4] t, n_inserted, hw, n_active
+    int32_t *tls;       // [N][S][3] phase, left, next_phase
+    long long *stats;   // [N][10]
+    uint16_t *dep_next; // [N][n_dep] head of every departure lane's backlog (TRIP_NONE: exhausted)
+    RS_HD float *pos() const { return (float *)base; }
+    RS_HD float *speed() const { return (float *)(base + 4 * nc); }
+    RS_HD float *accel() const { return (float *)(base + 8 * nc); }
+    RS_HD float *tloss() const { return (float *)(base + 12 * nc); }
+    RS_HD float *sf() const { return (float *)(base + 16 * nc); }
+    RS_HD uint32_t *coop() const { return (uint32_t *)(base + 20 * nc); }
+    RS_HD uint32_t *cooplead() const { return (uint32_t *)(base + 24 * nc); }
+    RS_HD uint16_t *lane() const { return (uint16_t *)(base + 28 * nc); }
+    RS_HD uint16_t *trip() const { return (uint16_t *)(base + 30 * nc); }
+    RS_HD uint16_t *cursor() const { return (uint16_t *)(base + 32 * nc); }
+    RS_HD uint16_t *swait() const { return (uint16_t *)(base + 34 * nc); }
+    RS_HD uint16_t *rwait() const { return (uint16_t *)(base + 36 * nc); }
+    RS_HD uint16_t *depart() const { return (uint16_t *)(base + 38 * nc); }
+    RS_HD uint16_t *wtot() const { return (uint16_t *)(base + 40 * nc); }
+    RS_HD uint8_t *owner() const { return (uint8_t *)(base + 42 * nc); }
+    static size_t bytes(size_t nc_) { return 43 * nc_; }
+};
+
+struct Out {        // one allocation; n = N, o = n_obs, s = n_signals, lm = lanes of the largest signal
+    char *base;
+    int32_t n, o, s, lm;
+    RS_HD size_t a5() const { return (size_t)n * o * 5 * 4; }      // one [N][n_obs][5] f32 block
+    RS_HD size_t ns() const { return (size_t)n * s * 4; }          // one [N][S] 4-byte block
+    RS_HD float *lane_agg() const { return (float *)base; }
+    RS_HD float *drq_norm() const { return (float *)(base + a5()); }
+    RS_HD float *wait() const { return (float *)(base + 2 * a5()); }
+    RS_HD float *wait_norm() const { return (float *)(base + 2 * a5() + ns()); }
+    RS_HD int32_t *phase() const { return (int32_t *)(base + 2 * a5() + 2 * ns()); }
+    RS_HD int32_t *pressure() const { return (int32_t *)(base + 2 * a5() + 3 * ns()); }
+    RS_HD int32_t *queue_sum() const { return (int32_t *)(base + 2 * a5() + 4 * ns()); }
+    RS_HD int32_t *queue_max() const { return (int32_t *)(base + 2 * a5() + 5 * ns()); }
+    RS_HD int32_t *mplight() const { return (int32_t *)(base + 2 * a5() + 6 * ns()); }
+    RS_HD int32_t *wave() const { return (int32_t *)(base + 2 * a5() + 19 * ns()); }
+    RS_HD int32_t *arrivals() const { return (int32_t *)(base + 2 * a5() + 31 * ns()); }      // [N][S] |Signal.arrivals| of the last observe
+    RS_HD int32_t *departures() const { return (int32_t *)(base + 2 * a5() + 32 * ns()); }    // [N][S] |Signal.departures|
+    RS_HD float *mplight_full() const { return (float *)(base + 2 * a5() + 33 * ns()); }      // [N][S][49]
+    RS_HD uint16_t *drq_f16() const { return (uint16_t *)(base + 2 * a5() + 82 * ns()); }
+    RS_HD size_t bytes() const { return 2 * a5() + 82 * ns() + (size_t)n * s * lm * 5 * 2 + 64; }
+};
+
+// ------------------------------------------------------------------------------------------------ device math
+RS_DEV uint32_t rs_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+RS_DEV uint32_t d_hash(uint32_t seed, uint32_t env, uint32_t trip, uint32_t tick, uint32_t stream) {
+    uint32_t h = seed;
+    const uint32_t w[4] = {env, trip, tick, stream};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t k = w[i];
+        k *= 0xcc9e2d51u; k = rs_rotl32(k, 15); k *= 0x1b873593u;
+        h ^= k; h = rs_rotl32(h, 13); h = h * 5u + 0xe6546b64u;
+    }
+    h ^= 16u;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+RS_DEV float d_u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+// Krauss (SUMO MSCFModel, Euler update, dt = 1 s) [SUMO-K]
+RS_DEV float d_brake_gap(float v, float b) {
+    const int steps = (int)(v / b);
+    const float fs = (float)steps;
+    return fs * v - b * fs * (fs + 1.0f) * 0.5f;
+}
+RS_DEV float d_stop_speed(float gap, float b, float tau) {
+    const float g = gap - 0.001f;
+    if (g < 0.0f) return 0.0f;
+    const float q = 1.0f + 4.0f * ((2.0f * g / b - tau) + tau * tau);
+    const float n = floorf(0.5f - (tau + sqrtf(q) * -0.5f));
+    const float h = 0.5f * n * (n - 1.0f) * b + n * b * tau;
+    const float r = (g - h) / (n + tau);
+    return n * b + r;
+}
+RS_DEV float d_free_speed(float dist, float target, float b) {
+    if (dist < target) return target;
+    const float t2 = b + 2.0f * target;
+    float y = ((sqrtf(t2 * t2 + 8.0f * b * dist) - b) * 0.5f - target) / b;
+    if (y < 0.0f) y = 0.0f;
+    const float yf = floorf(y);
+    const float exact = (yf * yf + yf) * 0.5f * b + yf * target + (y > yf ? target : 0.0f);
+    float rest = dist - exact;
+    if (rest < 0.0f) rest = 0.0f;
+    return rest / (yf + 1.0f) + yf * b + target;
+}
+RS_DEV float d_follow_speed(float gap, float vl, float b, float bl, float tau) {
+    const float bm = b > bl ? b : bl;
+    return d_stop_speed(gap + d_brake_gap(vl, bm), b, tau);
+}
+RS_DEV float speed_factor(const KParams &P, int env, int trip, const float *vt) {
+    if (!P.speed_dev) return vt[VT_SF_MEAN];
+    float s = 0.0f;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) s += d_u01(d_hash(P.seed, (uint32_t)env, (uint32_t)trip, 0xFFFFFFFFu, i));
+    const float z = (s - 2.0f) * 1.7320508f;
+    float f = vt[VT_SF_MEAN] + vt[VT_SF_DEV] * z;
+    if (f < 0.2f) f = 0.2f;
+    if (f > 2.0f) f = 2.0f;
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------ working memory (LDS)
+struct __attribute__((aligned(8))) Node {
+    float pos;
+    uint16_t trip;      // TRIP_NONE: free slot
+    uint16_t nxt;       // next vehicle of the same grid cell (unordered), NIL terminated
+};
+// An array of the working memory is addressed as (RS_SMEM + offset): the including file defines RS_SMEM as THE shared
+// array of the workgroup (so that every access is provably an LDS access: ds_* instructions with immediate offsets
+// instead of flat ones through 64-bit pointers), the host emulation as a plain buffer.
+template <class Tp> struct LPtr {
+    uint32_t off;
+    RS_MEM Tp &operator[](int i) const { return ((Tp *)(RS_SMEM + off))[i]; }
+    RS_MEM operator Tp *() const { return (Tp *)(RS_SMEM + off); }
+};
+struct Lds {
+    LPtr<Node> node;            // {pos, trip, next-in-cell}: one 8-byte read per chain step
+    LPtr<float> speed, vnx, tloss, sf, vtp;
+    LPtr<uint32_t> coop;        // cooperation request addressed to this slot: trip << 16 | slot of the requester (COOP_NONE)
+    LPtr<uint32_t> cooplead;    // the target-lane leader this slot tries to fall in behind: trip << 16 | slot (COOP_NONE)
+    LPtr<uint16_t> lane, rq, swait, nlink, cell;
+    LPtr<uint16_t> grid;        // the cells (bit 15: the cell holds a moving vehicle)
+    LPtr<uint8_t> vt;
+    LPtr<int32_t> arr;          // link approach registers
+    LPtr<uint16_t> dep;         // head trip of every departure lane's backlog
+    LPtr<uint32_t> alive, insm; // bit per slot: occupied; bit per departure lane: inserts this tick
+    LPtr<int32_t> agg_q, agg_a, agg_w, agg_m;
+    LPtr<uint32_t> agg_s;
+    LPtr<int32_t> sig_arr, sig_dep;
+    LPtr<int32_t> phase, left, nextp;
+    LPtr<uint8_t> tstate;       // current link states of every signal, [S][tls_maxl]
+    LPtr<int32_t> sc;           // scalars, see SC_*
+};
+#define SC_T 0
+#define SC_NINS 1
+#define SC_HW 2
+#define SC_NACT 3
+#define SC_HWNEW 4
+#define SC_REBUILD 5
+#define SC_STATS 6
+#define CELL_NEW 0xFFFEu        // L.cell value of a slot that was filled by an insertion in this tick's A1 phase
+
+RS_CARVE size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+RS_CARVE size_t lds_scratch_bytes(int C, int n_obs) {       // vnx, later reused by the observe aggregates
+    const size_t a = (size_t)C * 4, b = align16((size_t)n_obs * 4) * 5;
+    return a > b ? a : b;
+}
+// One carve routine for both the size computation (base = NULL) and the pointer set-up.
+// The arrays whose size depends only on the capacity come first: with the capacity a template parameter of the step
+// body their offsets are compile-time constants (DS immediate offsets, no SGPR each); the scenario-sized ones follow.
+RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
+    size_t o = 0;
+#define CARVE(field, bytes) { if (L) L->field.off = (uint32_t)o; o += align16(bytes); }
+    CARVE(node, (size_t)C * 8) CARVE(speed, (size_t)C * 4) CARVE(tloss, (size_t)C * 4) CARVE(sf, (size_t)C * 4)
+    CARVE(coop, (size_t)C * 4) CARVE(cooplead, (size_t)C * 4)
+    CARVE(lane, (size_t)C * 2) CARVE(rq, (size_t)C * 2) CARVE(swait, (size_t)C * 2)
+    CARVE(nlink, (size_t)C * 2) CARVE(cell, (size_t)C * 2)
+    CARVE(vt, (size_t)C)
+    CARVE(sc, (size_t)(SC_STATS + ST_N) * 4)
+    CARVE(alive, (size_t)((C + 31) / 32) * 4)
+    {   // the per-lane aggregates of the observe phase live where vnx was (dead by then)
+        const size_t ab = align16((size_t)n_obs * 4);
+        if (L) {
+            const uint32_t p = (uint32_t)o;
+            L->vnx.off = p;
+            L->agg_q.off = p; L->agg_a.off = p + (uint32_t)ab; L->agg_w.off = p + (uint32_t)(2 * ab);
+            L->agg_m.off = p + (uint32_t)(3 * ab); L->agg_s.off = p + (uint32_t)(4 * ab);
+        }
+        o += align16(lds_scratch_bytes(C, n_obs));
+    }
+    CARVE(grid, (size_t)(n_cells + 8) * 2)
+    CARVE(insm, (size_t)((n_dep + 31) / 32) * 4)
+    CARVE(vtp, (size_t)n_vt * VT_COLS * 4)
+    CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2)
+    CARVE(phase, (size_t)S * 4) CARVE(left, (size_t)S * 4) CARVE(nextp, (size_t)S * 4)
+    CARVE(sig_arr, (size_t)S * 4) CARVE(sig_dep, (size_t)S * 4)
+    CARVE(tstate, (size_t)S * tls_maxl)
+#undef CARVE
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------ grid primitives
+RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
+RS_DEV int lane_cells(const LaneRec &LR) { return (int)(LR.len * CELL_INV) + 1; }
+RS_DEV int cell_of(float pos, int ncell) { const int c = (int)(pos * CELL_INV); return c < ncell ? c : ncell - 1; }
+
+// push slot s into cell c; returns the previous head (the new chain link).  16-bit cells, exchanged with a CAS on the
+// containing dword (LDS has no 16-bit atomics)
+RS_DEV uint16_t grid_push(uint16_t *grid, int c, int s, bool mover) {
+    uint32_t *w = (uint32_t *)grid + (c >> 1);
+    const int sh = (c & 1) * 16;
+    const uint32_t flag = mover ? 0x8000u : 0u;
+    uint32_t old = *w, assumed;
+    do {
+        assumed = old;
+        const uint32_t keep = (assumed >> sh) & 0x8000u;          // sticky mover flag of the cell
+        old = rs_atomic_cas(w, assumed, (assumed & ~(0xFFFFu << sh)) | (((uint32_t)s | keep | flag) << sh));
+    } while (old != assumed);
+    return (uint16_t)((old >> sh) & 0x7FFFu);
+}
+// occupancy mask of the 4 cells of the aligned quad starting at b: bit 16 j + 15 set iff cell b + j is occupied
+RS_DEV unsigned long long quad_occ(const uint16_t *grid, int b) {
+    const unsigned long long w = *(const unsigned long long *)(grid + b);
+    const unsigned long long x = (w & 0x7FFF7FFF7FFF7FFFull) ^ 0x7FFF7FFF7FFF7FFFull;       // 15-bit field != 0: occupied
+    return (x + 0x7FFF7FFF7FFF7FFFull) & 0x8000800080008000ull;
+}
+// first occupied cell of [c0, c1] scanning upwards, -1: none
+RS_DEV int scan_up(const uint16_t *grid, int c0, int c1) {
+    for (int b = c0 & ~3; b <= c1; b += 4) {
+        unsigned long long m = quad_occ(grid, b);
+        const int lo = c0 - b, hi = c1 - b;
+        if (lo > 0) m &= ~0ull << (16 * lo);
+        if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
+        if (m) return b + ((rs_ffsll(m) - 1) >> 4);
+    }
+    return -1;
+}
+// first occupied cell of [c0, c1] scanning downwards from c1, -1: none
+RS_DEV int scan_down(const uint16_t *grid, int c0, int c1) {
+    for (int b = c1 & ~3; b + 3 >= c0; b -= 4) {
+        unsigned long long m = quad_occ(grid, b);
+        const int lo = c0 - b, hi = c1 - b;
+        if (lo > 0) m &= ~0ull << (16 * lo);
+        if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
+        if (m) return b + ((63 - rs_clzll(m)) >> 4);
+        if (b == 0) break;
+    }
+    return -1;
+}
+// any moving vehicle in the cells [c0, c0 + nc)?
+RS_DEV bool cells_have_mover(const uint16_t *grid, int c0, int nc) {
+    const int c1 = c0 + nc - 1;
+    for (int b = c0 & ~3; b <= c1; b += 4) {
+        unsigned long long m = *(const unsigned long long *)(grid + b) & 0x8000800080008000ull;
+        const int lo = c0 - b, hi = c1 - b;
+        if (lo > 0) m &= ~0ull << (16 * lo);
+        if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
+        if (m) return true;
+    }
+    return false;
+}
+// rear-most vehicle of a cell chain (min pos, ties -> larger trip)
+RS_DEV int chain_rearmost(const Lds &L, int head) {
+    int best = NIL, bk = 0;
+    float bp = 0.0f;
+    for (int s = head & 0x7FFF; s != NIL;) {
+        const Node nd = L.node[s];
+        if (best == NIL || nd.pos < bp || (nd.pos == bp && (int)nd.trip > bk)) { best = s; bk = nd.trip; bp = nd.pos; }
+        s = nd.nxt;
+    }
+    return best;
+}
+// front-most vehicle of a cell chain (max pos, ties -> smaller trip)
+RS_DEV int chain_frontmost(const Lds &L, int head) {
+    int best = NIL, bk = 0;
+    float bp = 0.0f;
+    for (int s = head & 0x7FFF; s != NIL;) {
+        const Node nd = L.node[s];
+        if (best == NIL || ahead_of(nd.pos, nd.trip, bp, bk)) { best = s; bk = nd.trip; bp = nd.pos; }
+        s = nd.nxt;
+    }
+    return best;
+}
+// rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
+RS_DEV int rearmost_within(const Lds &L, int cell0, int ncell, float win) {
+    if (win < 0.0f) return NIL;
+    const int c = scan_up(L.grid, cell0, cell0 + cell_of(win, ncell));
+    if (c < 0) return NIL;
+    const int o = chain_rearmost(L, L.grid[c]);
+    return (o != NIL && L.node[o].pos > win) ? NIL : o;
+}
+// nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front)
+RS_DEV int leader_within(const Lds &L, int cell0, int ncell, float pos, int k, int self, float win) {
+    const int c = cell_of(pos, ncell);
+    int Ld = NIL, Lk = 0;
+    float Lp = 0.0f;
+    for (int s = L.grid[cell0 + c] & 0x7FFF; s != NIL;) {        // my own cell first
+        const Node nd = L.node[s];
+        const int cur = s;
+        s = nd.nxt;
+        if (cur == self) continue;
+        if (ahead_of(nd.pos, nd.trip, pos, k) && (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip))) { Ld = cur; Lk = nd.trip; Lp = nd.pos; }
+    }
+    if (Ld == NIL && c + 1 < ncell) {
+        const int cc = scan_up(L.grid, cell0 + c + 1, cell0 + cell_of(pos + win, ncell));
+        if (cc >= 0) { Ld = chain_rearmost(L, L.grid[cc]); Lp = L.node[Ld].pos; }
+    }
+    if (Ld != NIL && Lp - pos > win) Ld = NIL;
+    return Ld;
+}
+// nearest vehicle behind (pos, k) on the lane (not `self`), at most `win` metres away
+RS_DEV int follower_within(const Lds &L, int cell0, int ncell, float pos, int k, int self, float win) {
+    const int c = cell_of(pos, ncell);
+    int Fd = NIL, Fk = 0;
+    float Fp = 0.0f;
+    for (int s = L.grid[cell0 + c] & 0x7FFF; s != NIL;) {
+        const Node nd = L.node[s];
+        const int cur = s;
+        s = nd.nxt;
+        if (cur == self) continue;
+        if (!ahead_of(nd.pos, nd.trip, pos, k) && (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk))) { Fd = cur; Fk = nd.trip; Fp = nd.pos; }
+    }
+    if (Fd == NIL && c > 0) {
+        const float lo = pos - win;
+        const int cc = scan_down(L.grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
+        if (cc >= 0) { Fd = chain_frontmost(L, L.grid[cc]); Fp = L.node[Fd].pos; }
+    }
+    if (Fd != NIL && pos - Fp > win) Fd = NIL;
+    return Fd;
+}
+// nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
+RS_DEV int at_or_behind_within(const Lds &L, int cell0, int ncell, float back, float win) {
+    if (back < 0.0f) return NIL;
+    const int c = cell_of(back, ncell);
+    int Fd = NIL, Fk = 0;
+    float Fp = 0.0f;
+    for (int s = L.grid[cell0 + c] & 0x7FFF; s != NIL;) {
+        const Node nd = L.node[s];
+        if (!(nd.pos > back) && (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk))) { Fd = s; Fk = nd.trip; Fp = nd.pos; }
+        s = nd.nxt;
+    }
+    if (Fd == NIL && c > 0) {
+        const float lo = back - win;
+        const int cc = scan_down(L.grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
+        if (cc >= 0) { Fd = chain_frontmost(L, L.grid[cc]); Fp = L.node[Fd].pos; }
+    }
+    if (Fd != NIL && back - Fp > win) Fd = NIL;
+    return Fd;
+}
+
+// ------------------------------------------------------------------------------------------------ model helpers
+RS_DEV int tls_state(const KTab &T, const Lds &L, int tls, int pos) {
+    if (tls == 0xFF) return TLS_G;
+    return L.tstate[tls * T.tls_maxl + pos];
+}
+// the link a vehicle on lane `lane` (record LR) takes at route step rq: link index | NLINK_ARR, NLINK_NONE when there is
+// none (last edge / a dead end for this route).  For a normal lane it is a table of (route step, lane index, trip parity)
+RS_DEV uint16_t cache_link(const KTab &T, const LaneRec &LR, int lane, int rq, int trip) {
+    if (LR.link_cnt == 0) return NLINK_NONE;
+    if (LR.flags & LF_INTERNAL) { const int l = LR.link_start; return (uint16_t)(l | (T.links[l].arr_idx >= 0 ? NLINK_ARR : 0)); }
+    return T.next_link[((size_t)rq * T.kmax + (lane - (int)LR.edge_lane0)) * 2 + (trip & 1)];
+}
+RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const LinkRec &K) {
+    for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
+        const FoeRec F = T.foes[i];
+        if (F.tls != 0xFF && tls_state(T, L, F.tls, F.tls_pos) == TLS_R) continue;
+        if (F.arr_idx >= 0 && L.arr[F.arr_idx] < RM_FOE_GAP_Q) return true;
+        if (F.via1_cell0 != 0xFFFF && cells_have_mover(L.grid, F.via1_cell0, F.via1_nc)) return true;   // a moving vehicle on
+        if (F.via2_cell0 != 0xFFFF && cells_have_mover(L.grid, F.via2_cell0, F.via2_nc)) return true;   // the foe's junction lanes
+    }
+    return false;
+}
+// copy the link states of signal s in phase ph into the working memory (called by the thread that owns the signal)
+RS_DEV void tls_refresh(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
+    const uint8_t *src = (P.fixed_program ? T.cold->fix8 + T.cold->fix_state_off[s] : T.cold->tls8 + T.cold->tls_state_off[s]) + ph * T.cold->tls_nlinks[s];
+    const int n = T.cold->tls_nlinks[s];
+    for (int i = 0; i < n; ++i) L.tstate[s * T.tls_maxl + i] = src[i];
+}
+RS_DEV void set_phase(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
+    if (ph < 0 || ph >= T.cold->tls_nphase[s]) return;
+    L.phase[s] = ph;
+    L.left[s] = T.cold->tls_dur[T.cold->tls_dur_off[s] + ph];
+    tls_refresh(T, L, P, s, ph);
+}
+// TLS switch events at the beginning of tick `tick` of this launch (P0), preceded by Signal.set_phase when the yellow
+// ticks are over
+RS_DEV void tls_begin_of_tick(const KTab &T, Lds &L, const KParams &P, int s, int tick) {
+    if (P.do_fsm && !P.fixed_program && tick == T.yellow_length) set_phase(T, L, P, s, L.nextp[s]);
+    int left = L.left[s];
+    if (left == 0) {
+        const int32_t *dur = P.fixed_program ? T.cold->fix_dur + T.cold->fix_dur_off[s] : T.cold->tls_dur + T.cold->tls_dur_off[s];
+        const int Pn = P.fixed_program ? T.cold->fix_nphase[s] : T.cold->tls_nphase[s];
+        const int ph = (L.phase[s] + 1) % Pn;
+        left = dur[ph];
+        L.phase[s] = ph;
+        tls_refresh(T, L, P, s, ph);
+    }
+    L.left[s] = left - 1;
+}
+// strategic lane-change need at route step rq on lane index kk of an edge with n lanes, at position x with speed v:
+// 0 when the lane is as good as any, or the need is still far away; else the direction of the nearest best lane.
+// extra = RM_SG_EXTRA_LANES when asking whether a lane is good enough to move INTO for speed gain.  (oracle: strategic_dir_at)
+RS_DEV int strategic_dir(const KTab &T, int rq, int kk, int n, float x, float v, int extra, float &rem) {
+    const float *cn = T.route_cont + (size_t)rq * T.kmax;
+    float best = 0.0f;
+    for (int j = 0; j < n; ++j) { const float c = cn[j]; if (c > best) best = c; }
+    const float mine = cn[kk];
+    rem = mine - x;
+    if (mine >= best - RM_CONT_EPS) return 0;
+    int dl = 1000, dr = 1000;
+    for (int j = kk + 1; j < n; ++j) if (cn[j] >= best - RM_CONT_EPS) { dl = j - kk; break; }
+    for (int j = kk - 1; j >= 0; --j) if (cn[j] >= best - RM_CONT_EPS) { dr = kk - j; break; }
+    const int off = (dr <= dl ? dr : dl) + extra;
+    const float la = (v > RM_LOOK_MIN_SPEED ? v : RM_LOOK_MIN_SPEED) * RM_LOOK_TIME + RM_LOOK_BASE;
+    if (rem >= la * (float)off) return 0;
+    return (dr <= dl) ? -1 : +1;
+}
+// approach registration of slot s for the coming tick (P3): a moving vehicle whose next link somebody may have to yield
+// to registers its arrival time there
+RS_DEV void register_approach(const KTab &T, Lds &L, int s) {
+    const int lane = L.lane[s];
+    if (lane == (int)LANE_NONE) return;
+    const int nlk = L.nlink[s];
+    if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
+    const float v = L.speed[s];
+    if (v <= RM_HALT_SPEED) return;
+    const LinkRec K = T.links[nlk & 0x7FFF];
+    const int st = tls_state(T, L, K.tls, K.tls_pos);
+    if (st == TLS_R) return;
+    const float dist = T.lanes[lane].len - L.node[s].pos;
+    if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) return;
+    const float ta = dist / (v > 1.0f ? v : 1.0f);
+    const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
+    rs_atomic_min(&L.arr[K.arr_idx], q);
+}
+// follow `X` (a vehicle on a neighbouring lane of my edge) as if it were my leader, braking no harder than comfortably:
+// the cooperative part of the lane changing (oracle: plan(), coop / coop_lead).  key = trip << 16 | slot.
+RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool clamp_gap, const LaneRec &LR, int lane, float x, float v,
+                             float b, float tau, float mingap, float &vsafe) {
+    const int X = (int)(key & 0xFFFFu), kx = (int)(key >> 16);
+    if ((int)L.node[X].trip != kx) return;
+    const int lx = L.lane[X];
+    if (lx == (int)LANE_NONE || (LR.flags & LF_INTERNAL)) return;
+    const int l0 = LR.edge_lane0, n = LR.flags >> 2;
+    if (lx < l0 || lx >= l0 + n) return;            // not on my edge (lanes of an edge are consecutive; internal lanes have n = 0)
+    const float *vo = L.vtp + L.vt[X] * VT_COLS;
+    const float px = L.node[X].pos, backx = px - vo[VT_LENGTH];
+    if (clamp_gap ? !(px >= x) : !(backx >= x)) return;
+    float g = backx - x - mingap;
+    if (clamp_gap && g < 0.0f) g = 0.0f;
+    float vs = d_follow_speed(g, L.speed[X], b, vo[VT_DECEL], tau);
+    float vc = v - b; if (vc < 0.0f) vc = 0.0f;
+    if (vs < vc) vs = vc;
+    if (vs < vsafe) vsafe = vs;
+    (void)lane;
+}
+
+// ------------------------------------------------------------------------------------------------ the phases
+// P: plan (Krauss car-following + links) for slot s
+RS_DEV void phase_plan(const KTab &T, Lds &L, const KParams &P, int genv, int t, int s) {
+    const int lane = L.lane[s];
+    if (lane == (int)LANE_NONE) return;
+    const int k = L.node[s].trip;
+    const float *vt = L.vtp + L.vt[s] * VT_COLS;
+    const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
+    const float v = L.speed[s], x = L.node[s].pos;
+    const float sf = L.sf[s];
+    LaneRec LR = T.lanes[lane];
+    float vfree = v + a;
+    const float vl = LR.vmax * sf;
+    if (vl < vfree) vfree = vl;
+    if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
+    float vsafe = RM_BIGF;
+    // The look-ahead only FINDS what limits the vehicle (a leader, or a stop line = a standing leader of zero length):
+    // the Krauss safe speed is evaluated once, by all lanes together, after the walk.
+    float tgap = 0.0f, tvl = 0.0f, tbl = b;
+    bool have = false;
+    const float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
+    const int lead = leader_within(L, LR.cell0, lane_cells(LR), x, k, s, look + T.maxlen);
+    bool found = false;
+    if (lead != NIL) {
+        const float *vo = L.vtp + L.vt[lead] * VT_COLS;
+        tgap = L.node[lead].pos - vo[VT_LENGTH] - x - mingap;
+        tvl = L.speed[lead]; tbl = vo[VT_DECEL];
+        have = true; found = true;
+    }
+    {   // cooperation: requests of the last lane-change phase
+        const uint32_t c1 = L.coop[s], c2 = L.cooplead[s];
+        if (c1 != COOP_NONE) { L.coop[s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
+        if (c2 != COOP_NONE) { L.cooplead[s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
+    }
+    float seen = LR.len - x;
+    if (!found && seen < look) {
+        int rq = L.rq[s];
+        int link = (int)(L.nlink[s] & 0x7FFF);
+        int cur_lane = lane;
+        const float bgv = d_brake_gap(v, b);        // can I still stop in front of a red / yellow light?
+        for (int hop = 0; hop < RM_MAX_HOPS; ++hop) {
+            const bool cur_int = (LR.flags & LF_INTERNAL) != 0;
+            if (hop > 0) link = (int)(cache_link(T, LR, cur_lane, rq, k) & 0x7FFF);
+            bool stop_here = false;
+            LinkRec K;
+            if (link == NLINK_NONE) {
+                // last edge of the route: free run to its end; otherwise a dead end: wait for a lane change
+                if (!cur_int && T.rsteps[rq].next_edge == 0xFFFF) break;
+                stop_here = true;
+            } else {
+                K = T.links[link];
+                const int st = tls_state(T, L, K.tls, K.tls_pos);
+                if (K.tls != 0xFF && (st == TLS_R || st == TLS_Y) && seen >= bgv) stop_here = true;
+                if (!stop_here && !(K.flags & KF_CONT) && ((K.flags & KF_MINOR) || (K.tls != 0xFF && st == TLS_g))) {
+                    // a minor link is approached ready to stop until the foe lanes can be seen
+                    if (seen > RM_VIS_DIST) stop_here = true;
+                    else if (K.foe_cnt > 0 && foe_blocked(T, L, K)) stop_here = true;
+                }
+            }
+            if (stop_here) {
+                const float g = seen - RM_STOP_OFFSET;
+                tgap = g > 0.0f ? g : 0.0f; tvl = 0.0f; tbl = b;       // d_follow_speed(g, 0, b, b) == d_stop_speed(g, b)
+                have = true;
+                break;
+            }
+            LR = K.dest;
+            cur_lane = K.to_lane;
+            {   // slow down in time for a lower speed limit on the next lane
+                const float vnl = LR.vmax * sf;
+                if (vnl < vfree) {
+                    const float vs = d_free_speed(seen, vnl, b);
+                    if (vs < vsafe) vsafe = vs;
+                }
+            }
+            const int o = rearmost_within(L, LR.cell0, lane_cells(LR), look - seen + T.maxlen);
+            if (o != NIL) {
+                const float *vo = L.vtp + L.vt[o] * VT_COLS;
+                tgap = seen + L.node[o].pos - vo[VT_LENGTH] - mingap;
+                tvl = L.speed[o]; tbl = vo[VT_DECEL];
+                have = true;
+                break;
+            }
+            if (!cur_int) rq += 1;
+            seen += LR.len;
+            if (!(seen < look)) break;
+        }
+    }
+    if (have) {
+        const float vs = d_follow_speed(tgap, tvl, b, tbl, tau);
+        if (vs < vsafe) vsafe = vs;
+    }
+    float vmin_n = v - b; if (vmin_n < 0.0f) vmin_n = 0.0f;
+    float vmin_e = v - vt[VT_EMERGENCY]; if (vmin_e < 0.0f) vmin_e = 0.0f;
+    const float lo = vsafe > vmin_e ? vsafe : vmin_e;
+    const float vmin = vmin_n < lo ? vmin_n : lo;
+    float vmax = vfree < vsafe ? vfree : vsafe;
+    if (vmax < vmin) vmax = vmin;
+    const float sigma = P.sigma >= 0.0f ? P.sigma : vt[VT_SIGMA];
+    float vd = vmax;
+    if (sigma > 0.0f) {
+        const float r = d_u01(d_hash(P.seed, (uint32_t)genv, (uint32_t)k, (uint32_t)t, 0u));
+        if (vd < a) vd -= sigma * vd * r; else vd -= sigma * a * r;
+        if (vd < 0.0f) vd = 0.0f;
+    }
+    L.vnx[s] = vd > vmin ? vd : vmin;
+}
+
+// M: move slot s, hand it over to the next lanes, let it arrive; register it in the grid of the moved state
+RS_DEV void phase_move(const KTab &T, Lds &L, const State &G, const KParams &P, int env, size_t eo, int t, bool last_tick, int s,
+                       int &active, int &halted, int &top) {
+    int lane = L.lane[s];
+    if (lane == (int)LANE_NONE) return;
+    const int k = L.node[s].trip;
+    int link = (int)(L.nlink[s] & 0x7FFF);
+    LaneRec LR = T.lanes[lane];
+    const float vn = L.vnx[s];
+    const float vref = LR.vmax * L.sf[s];
+    if (last_tick) G.accel()[eo + s] = vn - L.speed[s];
+    L.speed[s] = vn;
+    if (vn <= RM_HALT_SPEED) {
+        const int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1);
+        halted += 1;
+        if (G.trip_log) { const int wt = G.wtot()[eo + s]; if (wt < 65535) G.wtot()[eo + s] = (uint16_t)(wt + 1); }
+    } else L.swait[s] = 0;
+    float tl = L.tloss[s];
+    if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; L.tloss[s] = tl; }
+    float x = L.node[s].pos + vn;
+    int rq = L.rq[s];
+    bool arrived = false, moved = false;
+    for (int it = 0; it < 16; ++it) {
+        if (!(x > LR.len)) break;
+        const bool li = (LR.flags & LF_INTERNAL) != 0;
+        if (moved) link = (int)(cache_link(T, LR, lane, rq, k) & 0x7FFF);
+        if (link == NLINK_NONE) {
+            if (!li && T.rsteps[rq].next_edge == 0xFFFF) arrived = true; else x = LR.len;
+            break;
+        }
+        x -= LR.len;
+        if (!li) rq += 1;
+        {
+            const LinkRec Km = T.links[link];
+            lane = Km.to_lane;
+            LR = Km.dest;
+        }
+        moved = true;
+    }
+    if (arrived) {
+        L.lane[s] = LANE_NONE; L.node[s].trip = TRIP_NONE; L.cell[s] = 0xFFFF;
+        L.coop[s] = COOP_NONE; L.cooplead[s] = COOP_NONE;
+        rs_atomic_and(&L.alive[s >> 5], ~(1u << (s & 31)));
+        {   // Signal.departures of the signal that observed the vehicle last (traffic_signal.py:226-232)
+            const int ow = G.owner()[eo + s];
+            if (ow != (int)OWNER_NONE) rs_atomic_add(&L.sig_dep[ow], 1);
+        }
+        G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0;
+        rs_atomic_add(&L.sc[SC_NACT], -1);
+        rs_atomic_add(&L.sc[SC_STATS + ST_ARRIVED], 1);
+        rs_atomic_add(&L.sc[SC_STATS + ST_DURATION], t + 1 - (int)G.depart()[eo + s]);
+        rs_atomic_add(&L.sc[SC_STATS + ST_TLOSS], (int)(tl * 1024.0f + 0.5f));
+        if (G.trip_log) {
+            int32_t *r = G.trip_log + ((size_t)env * T.n_trips + k) * 4;
+            r[0] = (int)G.depart()[eo + s]; r[1] = t + 1; r[2] = (int)(tl * 1024.0f + 0.5f); r[3] = (int)G.wtot()[eo + s];
+        }
+        return;
+    }
+    L.node[s].pos = x;
+    if (moved) {
+        L.lane[s] = (uint16_t)lane; L.rq[s] = (uint16_t)rq;
+        L.nlink[s] = cache_link(T, LR, lane, rq, k);
+    }
+    active += 1;
+    top = s + 1;
+    const int c = LR.cell0 + cell_of(x, lane_cells(LR));
+    L.cell[s] = (uint16_t)c;
+    L.node[s].nxt = grid_push(L.grid, c, s, vn > RM_HALT_SPEED);
+    (void)P;
+}
+
+// D: lane-change decision of slot s on the moved state; returns the target lane (-1: stay).  A blocked strategic
+// changer asks for cooperation (oracle: lane_change()).
+RS_DEV int phase_lc_decide(const KTab &T, Lds &L, int t, int s) {
+    const int lane = L.lane[s];
+    if (lane == (int)LANE_NONE) return -1;
+    const LaneRec LR = T.lanes[lane];
+    const int n = LR.flags >> 2;
+    if ((LR.flags & LF_INTERNAL) || n < 2) return -1;
+    const int dir_allowed = (t & 1) ? -1 : +1;
+    const int l0 = LR.edge_lane0, kk = lane - l0;
+    const int k = L.node[s].trip, rq = L.rq[s];
+    const float *vt = L.vtp + L.vt[s] * VT_COLS;
+    const float x = L.node[s].pos, v = L.speed[s];
+    const int nc = lane_cells(LR);
+    int want = 0, dir = dir_allowed;
+    float rem;
+    const int sdir = strategic_dir(T, rq, kk, n, x, v, 0, rem);
+    if (sdir != 0) { dir = sdir; want = 2; }
+    const int tk = kk + dir;
+    if (tk < 0 || tk >= n) return -1;
+    const int tl = l0 + tk;
+    const int tcell0 = (int)LR.cell0 + dir * nc;        // lanes of an edge own consecutive, equally sized cell blocks
+    int lead_t = NIL, foll_t = NIL;
+    bool have_t = false;
+    if (!want) {
+        // speed gain between lanes that are both good: more room ahead on the neighbour.  A vehicle reconsiders only on
+        // one pair of ticks (one left, one right chance) out of four
+        if ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) return -1;
+        float rem_t;
+        if (strategic_dir(T, rq, tk, n, x, v, RM_SG_EXTRA_LANES, rem_t) != 0) return -1;
+        const int lead_c = leader_within(L, LR.cell0, nc, x, k, s, RM_NB_WINDOW);
+        if (lead_c == NIL) return -1;
+        lead_t = leader_within(L, tcell0, nc, x, k, s, RM_NB_WINDOW);
+        const float gcur = L.node[lead_c].pos - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
+        float gtgt = RM_BIGF;
+        if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
+        if (!(gcur < v * 3.0f + 15.0f && gtgt > gcur + RM_SG_ADVANTAGE)) return -1;
+        want = 1;
+        have_t = true;
+    }
+    if (!have_t) lead_t = leader_within(L, tcell0, nc, x, k, s, RM_NB_WINDOW);
+    foll_t = follower_within(L, tcell0, nc, x, k, s, RM_NB_WINDOW);
+    // urgent = strategic change close to the end of the drivable lane: accept tighter gaps (followers may have to brake
+    // with their emergency deceleration), otherwise dense queues would never let anybody in
+    const bool urgent = want == 2 && rem <= RM_URGENT_DIST;
+    bool safe = true;
+    if (lead_t != NIL) {
+        const float *vo = L.vtp + L.vt[lead_t] * VT_COLS;
+        const float gap = L.node[lead_t].pos - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
+        const float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
+        float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
+        if (gap < 0.0f || vb > d_follow_speed(gap, L.speed[lead_t], vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
+    }
+    if (safe && foll_t != NIL) {
+        const float *vo = L.vtp + L.vt[foll_t] * VT_COLS;
+        const float gap = x - vt[VT_LENGTH] - L.node[foll_t].pos - (urgent ? 0.0f : vo[VT_MINGAP]);
+        const float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
+        float vb = L.speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
+        if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
+    }
+    if (safe) return dir == dir_allowed ? tl : -1;
+    if (want == 2) {
+        // blocked: fall in behind the target-lane leader, and ask the nearest vehicle completely behind me on the target
+        // lane to let me in
+        if (lead_t != NIL) L.cooplead[s] = ((uint32_t)L.node[lead_t].trip << 16) | (uint32_t)lead_t;
+        const int R = at_or_behind_within(L, tcell0, nc, x - vt[VT_LENGTH], RM_COOP_RANGE);
+        if (R != NIL) rs_atomic_min(&L.coop[R], ((uint32_t)k << 16) | (uint32_t)s);
+    }
+    return -1;
+}
+
+// D: does the oldest waiting trip of departure lane d get onto the network at the end of tick t? (oracle: insertion_check)
+RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, int t, int d) {
+    const int k = L.dep[d];
+#ifdef RS_EMU_DEBUG
+    if (k == 312 && t >= 470) printf("t %d d %d k %d depart %d\n", t, d, k, T.cold->trip_depart[k]);
+#endif
+    if (k == (int)TRIP_NONE || T.cold->trip_depart[k] > t) return false;
+    const int dl = T.cold->dep_lane[d];
+    const LaneRec LR = T.lanes[dl];
+    const float *vt = L.vtp + T.trip_vtype[k] * VT_COLS;
+    const float mypos = vt[VT_LENGTH] < LR.len ? vt[VT_LENGTH] : LR.len;
+    // only vehicles with pos - length < mypos + minGap can be in the way
+    const int nc = lane_cells(LR);
+    const int c1 = LR.cell0 + cell_of(mypos + vt[VT_MINGAP] + T.maxlen, nc);
+    for (int c = scan_up(L.grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(L.grid, c + 1, c1) : -1))
+        for (int o = L.grid[c] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
+            const float back = L.node[o].pos - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
+#ifdef RS_EMU_DEBUG
+            if (k == 312 && t >= 470) printf("   o %d trip %d pos %f back %f lane %d (dl %d) cell %d head %d nxt %d cellof %d\n", o, L.node[o].trip, L.node[o].pos, back, L.lane[o], dl, c, L.grid[c], L.node[o].nxt, L.cell[o]);
+#endif
+            if (back - mypos - vt[VT_MINGAP] < 0.0f) return false;
+        }
+    return true;
+}
+
+// the r-th (0-based) free slot in ascending order, -1: none
+RS_DEV int nth_free_slot(const Lds &L, int C, int r) {
+    for (int w = 0; w < (C + 31) / 32; ++w) {
+        uint32_t fr = ~L.alive[w];
+        if (w == (C - 1) / 32 && (C & 31)) fr &= (1u << (C & 31)) - 1u;
+        const int c = rs_popc(fr);
+        if (r >= c) { r -= c; continue; }
+        for (int j = 0; j < r; ++j) fr &= fr - 1u;      // drop the r lowest set bits
+        return w * 32 + rs_ffs(fr) - 1;
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------ the step
+// CAP: the slot capacity as a compile-time constant (0: read it from the tables at run time)
+template <int CAP, class Exec>
+RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, const KParams &P,
+                         const int32_t *actions, int env) {
+    const int B = ex.B;
+    const int C = CAP ? CAP : T.capacity, S = T.n_signals, NO = T.n_obs;
+    const int genv = P.env_base + env;
+    Lds L;
+    lds_carve(&L, C, T.n_cells, T.n_arr, T.n_dep, NO, S, T.n_vtypes, T.tls_maxl);
+    const size_t eo = (size_t)env * C;
+    const int n_ticks = P.n_ticks;
+    const int ngw = (T.n_cells + 8 + 1) / 2;        // grid dwords
+
+    // ---- L0: scalars, tables, TLS, backlog heads
+    ex.phase([&](int tid) {
+        if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 4 ? G.env[env * 4 + tid] : 0;
+        for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold->vtype_params[i];
+        for (int i = tid; i < ngw; i += B) ((uint32_t *)(uint16_t *)L.grid)[i] = 0x7FFF7FFFu;
+        for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
+        for (int i = tid; i < (C + 31) / 32; i += B) L.alive[i] = 0u;
+        for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
+        for (int i = tid; i < T.n_dep; i += B) L.dep[i] = G.dep_next[(size_t)env * T.n_dep + i];
+        for (int i = tid; i < S; i += B) { L.sig_arr[i] = 0; L.sig_dep[i] = 0; }
+        for (int i = tid; i < S; i += B) {
+            const int ph = G.tls[(env * S + i) * 3 + 0];
+            L.phase[i] = ph;
+            L.left[i] = G.tls[(env * S + i) * 3 + 1];
+            L.nextp[i] = G.tls[(env * S + i) * 3 + 2];
+            tls_refresh(T, L, P, i, ph);
+        }
+    });
+    // ---- L1: the slab (once per env-step)
+    ex.phase([&](int tid) {
+        const int hw0 = L.sc[SC_HW];
+        for (int s = tid; s < C; s += B) {
+            uint16_t ln = LANE_NONE, tr = TRIP_NONE;
+            if (s < hw0) { ln = G.lane()[eo + s]; tr = G.trip()[eo + s]; }
+            L.lane[s] = ln; L.node[s].trip = tr; L.cell[s] = 0xFFFF;
+            L.coop[s] = COOP_NONE; L.cooplead[s] = COOP_NONE;
+            if (ln == LANE_NONE) continue;
+            const float sp = G.speed()[eo + s];
+            L.node[s].pos = G.pos()[eo + s]; L.speed[s] = sp; L.swait[s] = G.swait()[eo + s]; L.tloss[s] = G.tloss()[eo + s];
+            L.sf[s] = G.sf()[eo + s]; L.coop[s] = G.coop()[eo + s]; L.cooplead[s] = G.cooplead()[eo + s];
+            const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor()[eo + s];
+            L.rq[s] = (uint16_t)rq;
+            L.vt[s] = T.trip_vtype[tr];
+            const LaneRec LR0 = T.lanes[ln];
+            L.nlink[s] = cache_link(T, LR0, ln, rq, tr);
+            const int c = LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0));
+            L.cell[s] = (uint16_t)c;
+            L.node[s].nxt = grid_push(L.grid, c, s, sp > RM_HALT_SPEED);
+            rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
+        }
+    });
+    // ---- L2: Signal.prep_phase for every signal (traffic_signal.py:176-184), then the TLS events of tick 0
+    ex.phase([&](int tid) {
+        for (int s = B - 1 - tid; s < S; s += B) {
+            if (P.do_fsm && !P.fixed_program) {
+                const int a = actions[env * S + s], cur = L.phase[s], Gn = T.cold->tls_ngreen[s];
+                if (a < 0 || a >= T.cold->tls_nphase[s]) L.nextp[s] = cur;
+                else {
+                    L.nextp[s] = a;
+                    if (cur != a && cur < Gn && a < Gn) {
+                        const int y = T.cold->tls_yellow[T.cold->tls_yel_off[s] + cur * Gn + a];
+                        if (y >= 0) set_phase(T, L, P, s, y);
+                    }
+                }
+            }
+            if (n_ticks > 0) tls_begin_of_tick(T, L, P, s, 0);
+        }
+    });
+    // ---- L3: approach registration of the first tick (later ticks register at their end, see A2)
+    if (n_ticks > 0) ex.phase([&](int tid) {
+        const int hw = L.sc[SC_HW];
+        for (int s = tid; s < hw; s += B) register_approach(T, L, s);
+    });
+
+    for (int tick = 0; tick < n_ticks; ++tick) {
+        const int t = L.sc[SC_T], hw = L.sc[SC_HW];
+        // ---- P: plan
+        ex.phase([&](int tid) {
+            for (int s = tid; s < hw; s += B) phase_plan(T, L, P, genv, t, s);
+        });
+        // ---- C: everybody leaves the grid and drops its approach registration (nobody reads them between plan and move)
+        ex.phase([&](int tid) {
+            for (int s = tid; s < hw; s += B) {
+                const int c = L.cell[s];
+                if (c < 0xFFF0) L.grid[c] = NIL;
+                const int nlk = L.nlink[s];
+                if (L.lane[s] != LANE_NONE && (nlk & NLINK_ARR)) L.arr[T.links[nlk & 0x7FFF].arr_idx] = ARR_NONE;
+            }
+            if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_REBUILD] = 0; }
+            for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
+        });
+        // ---- M: move; build the grid of the moved state
+        ex.phase([&](int tid) {
+            int active = 0, halted = 0, top = 0;
+            for (int s = tid; s < hw; s += B) phase_move(T, L, G, P, env, eo, t, tick == n_ticks - 1, s, active, halted, top);
+            if (active) rs_atomic_add(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
+            if (halted) rs_atomic_add(&L.sc[SC_STATS + ST_WAITING], halted);
+            if (top) rs_atomic_max(&L.sc[SC_HWNEW], top);
+        });
+        const int hw2 = L.sc[SC_HWNEW];
+        // ---- D: decisions on the moved state: lane changes (+ cooperation requests), insertions, next tick's TLS events
+        ex.phase([&](int tid) {
+            for (int s = tid; s < hw2; s += B) L.vnx[s] = rs_int_as_float(phase_lc_decide(T, L, t, s));
+            for (int d = B - 1 - tid; d < T.n_dep; d += B)
+                if (phase_insert_decide(T, L, t, d)) rs_atomic_or(&L.insm[d >> 5], 1u << (d & 31));
+            if (tick + 1 < n_ticks)
+                for (int sg = B - 1 - tid; sg < S; sg += B) tls_begin_of_tick(T, L, P, sg, tick + 1);
+            if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
+        });
+        // ---- A1: lane changers leave their cell; the winners of the departure lanes fill free slots
+        ex.phase([&](int tid) {
+            for (int s = tid; s < hw2; s += B) {
+                if (L.lane[s] == LANE_NONE) continue;
+                const int target = rs_float_as_int(L.vnx[s]);
+                if (target < 0) continue;
+                const int c = L.cell[s];
+#ifdef RS_EMU_DEBUG
+                if (s == 104 && t >= 470) printf("A1 t %d slot %d lane %d -> %d cell %d head %d nxt %d\n", t, s, L.lane[s], target, c, L.grid[c], L.node[s].nxt);
+#endif
+                if ((L.grid[c] & 0x7FFF) == s && L.node[s].nxt == NIL) { L.grid[c] = NIL; L.cell[s] = 0xFFFD; }   // alone in my cell: leave it, re-register in A2
+                else L.sc[SC_REBUILD] = 1;      // shared cell: everybody leaves and re-enters the grid (my cell index stays valid for the clearing)
+                L.lane[s] = (uint16_t)target;
+                L.nlink[s] = cache_link(T, T.lanes[target], target, L.rq[s], L.node[s].trip);
+            }
+            for (int d = B - 1 - tid; d < T.n_dep; d += B) {
+                if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
+                int rank = rs_popc(L.insm[d >> 5] & ((1u << (d & 31)) - 1u));
+                for (int w = 0; w < (d >> 5); ++w) rank += rs_popc(L.insm[w]);
+                if (rank >= C - L.sc[SC_NACT]) continue;            // the network is full (lower lane index first)
+                const int s = nth_free_slot(L, C, rank);
+                if (s < 0) continue;
+                const int k = L.dep[d];
+                const int v = T.trip_vtype[k];
+                const float *vt = L.vtp + v * VT_COLS;
+                const RouteRec RR = T.routes[T.trip_route[k]];
+                L.node[s].pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
+                L.node[s].trip = (uint16_t)k; L.node[s].nxt = NIL;
+                L.speed[s] = 0.0f; L.tloss[s] = 0.0f; L.swait[s] = 0; L.vt[s] = (uint8_t)v;
+                L.lane[s] = RR.depart_lane; L.rq[s] = (uint16_t)RR.start;
+                L.coop[s] = COOP_NONE; L.cooplead[s] = COOP_NONE;
+                L.sf[s] = speed_factor(P, genv, k, vt);
+                L.nlink[s] = cache_link(T, T.lanes[RR.depart_lane], RR.depart_lane, (int)RR.start, k);
+                L.cell[s] = CELL_NEW;
+                G.sf()[eo + s] = L.sf[s];
+                G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
+                L.dep[d] = T.cold->trip_next[k];
+                rs_atomic_max(&L.sc[SC_HW], s + 1);
+                rs_atomic_add(&L.sc[SC_STATS + ST_INSERTED], 1);
+                rs_atomic_add(&L.sc[SC_STATS + ST_DEPDELAY], t - T.cold->trip_depart[k]);
+            }
+        });
+        const int hw3 = L.sc[SC_HW];
+        const bool more = tick + 1 < n_ticks;
+        if (L.sc[SC_REBUILD]) {
+            ex.phase([&](int tid) {
+                for (int s = tid; s < hw3; s += B) { const int c = L.cell[s]; if (c < 0xFFF0) L.grid[c] = NIL; }
+            });
+        }
+        const bool rebuild = L.sc[SC_REBUILD] != 0;
+        // ---- A2: changers and new vehicles enter the grid; the next tick's approach registrations (P3)
+        ex.phase([&](int tid) {
+            for (int s = tid; s < hw3; s += B) {
+                const int ln = L.lane[s];
+                if (ln == (int)LANE_NONE) continue;
+                const int c0 = L.cell[s];
+                if (c0 == (int)CELL_NEW) {
+                    rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
+                    rs_atomic_add(&L.sc[SC_NACT], 1);
+                    rs_atomic_add(&L.sc[SC_NINS], 1);
+                }
+                if (rebuild || c0 >= 0xFFF0) {
+                    const LaneRec LRn = T.lanes[ln];
+                    const int c = LRn.cell0 + cell_of(L.node[s].pos, lane_cells(LRn));
+                    L.cell[s] = (uint16_t)c;
+                    L.node[s].nxt = grid_push(L.grid, c, s, L.speed[s] > RM_HALT_SPEED);
+                }
+                if (more) register_approach(T, L, s);
+            }
+        });
+    }
+
+    // ---- Signal.observe for every signal (traffic_signal.py:189-247)
+    ex.phase([&](int tid) {
+        for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
+    });
+    ex.phase([&](int tid) {
+        const int hwf = L.sc[SC_HW], hw0 = G.env[env * 4 + 2];
+        const int top = hwf > hw0 ? hwf : hw0;
+        int hi = 0;
+        for (int s = tid; s < top; s += B) {
+            const int lane = L.lane[s];
+            const int prev_owner = G.owner()[eo + s];
+            G.lane()[eo + s] = (uint16_t)lane; G.trip()[eo + s] = L.node[s].trip;
+            if (lane == (int)LANE_NONE) continue;
+            hi = s + 1;
+            // store the slab back (once per env-step)
+            const int rq = L.rq[s];
+            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.speed[s]; G.swait()[eo + s] = L.swait[s]; G.tloss()[eo + s] = L.tloss[s];
+            G.coop()[eo + s] = L.coop[s]; G.cooplead()[eo + s] = L.cooplead[s];
+            G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.node[s].trip]].start);
+            const LaneRec LR = T.lanes[lane];
+            const int oi = T.cold->lane_obs[lane];
+            bool detect = false;
+            if (oi >= 0) {
+                const float d = (LR.len - L.node[s].pos) + T.rsteps[rq].tlsdist;
+                detect = d <= P.max_distance;
+            }
+            if (!detect) {
+                if (prev_owner != (int)OWNER_NONE) rs_atomic_add(&L.sig_dep[prev_owner], 1);
+                G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0;
+                continue;
+            }
+            const int sig = T.cold->obs_sig[oi];
+            int rw = G.rwait()[eo + s];
+            if (prev_owner != sig) {
+                rw = 0;
+                rs_atomic_add(&L.sig_arr[sig], 1);
+                if (prev_owner != (int)OWNER_NONE) rs_atomic_add(&L.sig_dep[prev_owner], 1);
+            }
+            if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
+            else if (L.swait[s] > 0) rw = L.swait[s];
+            G.rwait()[eo + s] = (uint16_t)rw;
+            G.owner()[eo + s] = (uint8_t)sig;
+            if (rw > 0) { rs_atomic_add(&L.agg_q[oi], 1); rs_atomic_add(&L.agg_w[oi], rw); rs_atomic_max(&L.agg_m[oi], rw); }
+            else rs_atomic_add(&L.agg_a[oi], 1);
+            rs_atomic_add((int32_t *)&L.agg_s[oi], (int32_t)(uint32_t)(L.speed[s] * 65536.0f + 0.5f));
+        }
+        if (hi) rs_atomic_max(&L.sc[SC_HWNEW], hi);
+    });
+    // per observed lane rows, written as flat coalesced streams; states / rewards; state write-back
+    ex.phase([&](int tid) {
+        for (int i = tid; i < NO * 5; i += B) {
+            const int oi = i / 5, c = i - oi * 5;
+            const int sg = T.cold->obs_sig[oi];
+            const float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
+            float raw, nrm;
+            if (c == 0) { raw = (float)L.agg_q[oi]; nrm = (oi - T.cold->sig_obs_start[sg]) == L.phase[sg] ? 1.0f : 0.0f; }
+            else if (c == 1) { raw = (float)L.agg_a[oi]; nrm = raw / 28.0f; }
+            else if (c == 2) { raw = (float)L.agg_w[oi]; nrm = raw / 28.0f; }
+            else if (c == 3) { raw = (float)L.agg_m[oi]; nrm = (float)L.agg_q[oi] / 28.0f; }
+            else { raw = sp; nrm = sp / 20.0f / 28.0f; }
+            O.lane_agg()[(size_t)env * NO * 5 + i] = raw;         // queue, approach, total_wait, max_wait, speed_sum
+            O.drq_norm()[(size_t)env * NO * 5 + i] = nrm;         // one-hot(lane position == phase), approach, wait, queue, speed
+        }
+        for (int i = tid; i < S * T.lmax * 5; i += B) {
+            const int sg = i / (T.lmax * 5), r = i - sg * T.lmax * 5;
+            const int l = r / 5, c = r - l * 5;
+            const int o0 = T.cold->sig_obs_start[sg];
+            float nrm = 0.0f;                                    // zero padding beyond the signal's lanes
+            if (l < T.cold->sig_obs_start[sg + 1] - o0) {
+                const int oi = o0 + l;
+                if (c == 0) nrm = l == L.phase[sg] ? 1.0f : 0.0f;
+                else if (c == 1) nrm = (float)L.agg_a[oi] / 28.0f;
+                else if (c == 2) nrm = (float)L.agg_w[oi] / 28.0f;
+                else if (c == 3) nrm = (float)L.agg_q[oi] / 28.0f;
+                else nrm = (float)L.agg_s[oi] * (1.0f / 65536.0f) / 20.0f / 28.0f;
+            }
+            O.drq_f16()[(size_t)env * S * T.lmax * 5 + i] = rs_f2h(nrm);
+        }
+        // states.mplight / wave / mplight_full: one thread per (signal, movement)
+        for (int i = tid; i < S * 12; i += B) {
+            const int sg = i / 12, m = i - sg * 12;
+            int q = 0, wv = 0, tw = 0, ap = 0;
+            float last_speed = 0.0f;
+            for (int j = T.cold->mv_in_start[i]; j < T.cold->mv_in_start[i + 1]; ++j) {
+                const int oi = T.cold->mv_in_idx[j];
+                q += L.agg_q[oi]; wv += L.agg_q[oi] + L.agg_a[oi]; tw += L.agg_w[oi]; ap += L.agg_a[oi];
+                last_speed = (float)L.agg_s[oi] * (1.0f / 65536.0f);       // states.py:97: total_speed restarts with every lane
+            }
+            for (int j = T.cold->mv_out_start[i]; j < T.cold->mv_out_start[i + 1]; ++j) q -= L.agg_q[T.cold->mv_out_idx[j]];
+            const size_t so = (size_t)env * S + sg;
+            O.mplight()[so * 13 + 1 + m] = q;
+            O.wave()[so * 12 + m] = wv;
+            float *mf = O.mplight_full() + so * 49 + 1 + m * 4;             // states.mplight_full (states.py:83-113)
+            mf[0] = (float)q; mf[1] = (float)tw / 28.0f; mf[2] = last_speed; mf[3] = (float)ap / 28.0f;
+        }
+        // per signal: phase, rewards, metrics
+        for (int sg = tid; sg < S; sg += B) {
+            const int ph = L.phase[sg];
+            const int o0 = T.cold->sig_obs_start[sg], o1 = T.cold->sig_obs_start[sg + 1];
+            int tw = 0, tq = 0, mq = 0;
+            for (int oi = o0; oi < o1; ++oi) { tw += L.agg_w[oi]; const int qq = L.agg_q[oi]; tq += qq; if (qq > mq) mq = qq; }
+            const size_t so = (size_t)env * S + sg;
+            O.phase()[so] = ph; O.queue_sum()[so] = tq; O.queue_max()[so] = mq;
+            O.wait()[so] = -(float)tw;
+            const float wn = -(float)tw / 224.0f;
+            O.wait_norm()[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
+            int pr = tq;
+            for (int i = T.cold->pr_out_start[sg]; i < T.cold->pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.cold->pr_out_idx[i]];
+            O.pressure()[so] = -pr;
+            O.mplight()[so * 13] = ph;
+            O.mplight_full()[so * 49] = (float)ph;
+            O.arrivals()[so] = L.sig_arr[sg]; O.departures()[so] = L.sig_dep[sg];
+            G.tls[(env * S + sg) * 3 + 0] = ph;
+            G.tls[(env * S + sg) * 3 + 1] = L.left[sg];
+            G.tls[(env * S + sg) * 3 + 2] = L.nextp[sg];
+        }
+        for (int i = tid; i < T.n_dep; i += B) G.dep_next[(size_t)env * T.n_dep + i] = L.dep[i];
+    });
+    ex.phase([&](int tid) {
+        if (tid == 0) {
+            G.env[env * 4 + 0] = L.sc[SC_T]; G.env[env * 4 + 1] = L.sc[SC_NINS]; G.env[env * 4 + 3] = L.sc[SC_NACT];
+            G.env[env * 4 + 2] = L.sc[SC_HWNEW];
+        }
+        if (tid < ST_N) {
+            long long *st = G.stats + (size_t)env * ST_N;
+            if (tid == ST_ACTIVE) st[tid] = L.sc[SC_NACT];
+            else if (tid == ST_PENDING) {
+                // trips whose insertion has been tried and failed so far: departed before the last tick, not on the network
+                const int t = L.sc[SC_T];
+                const int hz = t - 1 <= T.horizon ? t - 1 : T.horizon;
+                st[tid] = (t >= 1 ? T.cold->trips_cum[hz] : 0) - L.sc[SC_NINS];
+            } else st[tid] += L.sc[SC_STATS + tid];
+        }
+    });
+}

@@ -16,12 +16,14 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libresco_sim.so')
 BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure', 'queue_sum',
            'queue_max', 'actions', 'env', 'tls', 'veh_pos', 'veh_speed', 'veh_accel', 'veh_tloss', 'veh_lane',
            'veh_trip', 'veh_cursor', 'veh_swait', 'veh_rwait', 'veh_depart', 'veh_owner', 'stats', 'drq_norm_f16',
-           'veh_sf', 'veh_wtot', 'trip_log']
+           'veh_sf', 'veh_wtot', 'trip_log', 'dep_next', 'veh_coop', 'veh_cooplead', 'arrivals', 'departures',
+           'mplight_full']
 BUF_ID = {n: i for i, n in enumerate(BUFFERS)}
-_NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64]
-_TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8']
+_NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64, np.uint32]
+_TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8', '<u4']
 STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10',
              'active', 'pending', 'active_ticks', 'ticks']
+TRIP_NONE = 0xFFFF
 
 # every symbol include/resco_sim.h declares
 ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_act_random',
@@ -32,15 +34,8 @@ ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step'
 _lib = None
 
 
-def load_library():
-    """Load libresco_sim.so (fails loudly when it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError('HIP extension %s is missing: build it with `python -m resco_amd.build` '
-                           '(there is no CPU fallback)' % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+def bind(L):
+    """ctypes signatures of the C ABI (include/resco_sim.h) on an opened library."""
     vp, i32 = C.c_void_p, C.c_int32
     L.rs_create.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(vp)]
     L.rs_destroy.argtypes = [vp]
@@ -64,8 +59,19 @@ def load_library():
     L.rs_set_seed.argtypes = [vp, C.c_uint32]
     L.rs_phase_profile.argtypes = [vp, i32, vp]
     L.rs_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
-    _lib = L
     return L
+
+
+def load_library():
+    """Load libresco_sim.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('HIP extension %s is missing: build it with `python -m resco_amd.build` '
+                           '(there is no CPU fallback)' % LIB_PATH)
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
 
 
 def torch_stream(device=None):
@@ -93,7 +99,7 @@ class BatchedSim:
         self.sc = scenario
         self.n_envs = int(n_envs)
         self.device = int(device)
-        self._lib = load_library()
+        self._lib = self._load()
         self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
         self._p = ParamsStruct(int(seed) & 0xFFFFFFFF, float(max_distance), float(sigma), int(speed_dev),
                                int(fixed_program), int(trip_log))
@@ -113,6 +119,9 @@ class BatchedSim:
             self._meta[name] = (ptr.value, tuple(shape[:nd.value]), dt.value)
 
     # ------------------------------------------------------------------ plumbing
+    def _load(self):
+        return load_library()
+
     def _check(self, rc):
         if rc != 0:
             msg = self._lib.rs_last_error(self._h)
@@ -202,20 +211,39 @@ class BatchedSim:
     def time(self):
         return self.read('env')[:, 0]
 
+    def backlog(self):
+        """Trips that have departed (depart < now) but are not on the network yet, per environment: (count, seconds
+        waited so far).  Every departure lane keeps its own backlog (RS_BUF_DEP_NEXT = its next trip); utils/readXML.py:52-68
+        charges such trips end_time - depart."""
+        A = self.sc.arrays
+        dep_lane_of_trip = A['edge_lane0'][A['route_edge'][A['route_start'][A['trip_route']]]]
+        lanes = np.unique(dep_lane_of_trip)                      # departure lanes in ascending lane order
+        head = self.read('dep_next').astype(np.int64)            # [N, n_dep]
+        now = self.time().astype(np.int64)
+        depart = A['trip_depart'].astype(np.int64)
+        cnt = np.zeros(self.n_envs, np.int64)
+        waited = np.zeros(self.n_envs, np.int64)
+        for d, lane in enumerate(lanes):
+            trips = np.nonzero(dep_lane_of_trip == lane)[0]      # ascending trip index = FIFO order
+            dep = depart[trips]
+            for e in range(self.n_envs):
+                h = head[e, d]
+                first = len(trips) if h == TRIP_NONE else int(np.searchsorted(trips, h))
+                due = dep[first:][dep[first:] < now[e]]
+                cnt[e] += len(due)
+                waited[e] += int((now[e] - due).sum())
+        return cnt, waited
+
     def trip_delay(self):
         """Per-environment average trip delay as the reference's post-processing defines it (utils/readXML.py:
         timeLoss + departDelay per tripinfo entry, unfinished trips included as tripinfo-output.write-unfinished
         writes them): (time loss of arrived and of still-running vehicles + insertion delays + the waiting of trips
         still queued for insertion) / (inserted + queued trips)."""
         st = self.stats()
-        lane, trip = self.read('veh_lane'), self.read('veh_trip')
-        running = (self.read('veh_tloss') * (lane < 0xFFFE)).sum(axis=1)
-        # trips that were due but never got onto the network wait since their scheduled departure
-        # (readXML.py:52-68 charges end_time - depart for them and counts them as trips)
-        pend = lane == 0xFFFE
-        sched = np.asarray(self.sc.arrays['trip_depart'])[np.where(pend, trip, 0).astype(np.int64)]
-        waited = (np.maximum(0, self.time()[:, None] - sched) * pend).sum(axis=1)
-        trips = st['inserted'] + pend.sum(axis=1)
+        lane = self.read('veh_lane')
+        running = (self.read('veh_tloss') * (lane != 0xFFFF)).sum(axis=1)
+        cnt, waited = self.backlog()
+        trips = st['inserted'] + cnt
         return (st['sum_time_loss_q10'] / 1024.0 + running + st['sum_depart_delay'] + waited) / np.maximum(1, trips)
 
     # ------------------------------------------------------------------ snapshots / timing
