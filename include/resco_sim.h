@@ -104,7 +104,15 @@ int rs_reset(rs_handle h, void *stream);
  * signal), host pointer, or device pointer when actions_on_device != 0; NULL = use the handle's RS_BUF_ACTIONS
  * buffer as is (e.g. filled by rs_act_*).  Asynchronous: outputs are ready after rs_sync / stream sync. */
 int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_device, void *stream);
+/* n x step_sim() = n x sumo.simulationStep() (multi_signal.py:102-105) without touching the signal FSM, followed by an
+ * observe: MultiSignal's `warmup` ticks (multi_signal.py:139-140) and single simulation steps. */
+int rs_ticks(rs_handle h, int32_t n_ticks, void *stream);
 int rs_sync(rs_handle h);
+/* Fresh Signal objects on the RUNNING simulation: what MultiSignal.reset() does after (re)starting SUMO
+ * (multi_signal.py:141-147 -> Signal.__init__, traffic_signal.py:28-104): the RESCO waiting-time bookkeeping
+ * (Signal.waiting_times / last_step_vehicles) starts over, the program is re-installed (the current phase restarts with
+ * its full duration, next_phase = 0), and the first observe runs.  Vehicles stay where they are. */
+int rs_reinit_signals(rs_handle h, void *stream);
 
 /* Batched on-device static agents writing RS_BUF_ACTIONS. */
 int rs_act_random(rs_handle h, uint32_t step_key, void *stream);       /* STOCHASTIC: U{0..G_s-1} */
@@ -181,7 +189,9 @@ int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches);   /* syncs;
 int rs_set_seed(rs_handle h, uint32_t seed);
 
 /* in-kernel phase timers (development aid): enable, run steps, then read 16 accumulators of wall_clock64 ticks
- * (100 MHz) summed over all workgroups.  Reading also resets.  (Kept in the ABI; the current kernel does not fill them.) */
+ * (100 MHz) summed over all workgroups, one per phase of the step kernel (barrier wait included): L0 L1 L2 L3 (load, FSM,
+ * first registrations) P plan, C leave grid, M move, D decisions, A1 apply, RB grid rebuild, A2 re-enter + registrations,
+ * O0..O3 observe / outputs / write-back.  Reading also resets. */
 int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16);
 
 /* ---- fused IDQN policy forward (BASELINE config 5) ------------------------------------------

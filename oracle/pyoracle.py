@@ -49,7 +49,11 @@ def lib():
         for f in ('orc_lane_agg', 'orc_drq_norm', 'orc_wait', 'orc_wait_norm'):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.POINTER(C.c_float)
-        for f in ('orc_phase', 'orc_mplight', 'orc_wave', 'orc_pressure', 'orc_queue_sum', 'orc_queue_max'):
+        L.orc_mplight_full.argtypes = [C.c_void_p]
+        L.orc_mplight_full.restype = C.POINTER(C.c_float)
+        L.orc_reinit_signals.argtypes = [C.c_void_p]
+        L.orc_reinit_signals.restype = None
+        for f in ('orc_phase', 'orc_mplight', 'orc_wave', 'orc_pressure', 'orc_queue_sum', 'orc_queue_max', 'orc_arrivals', 'orc_departures'):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.POINTER(C.c_int32)
         L.orc_get_vehicles.argtypes = [C.c_void_p, C.c_void_p]
@@ -99,6 +103,9 @@ class OracleEnv:
     def tick(self):
         lib().orc_tick(self._h)
 
+    def reinit_signals(self):
+        lib().orc_reinit_signals(self._h)
+
     def observe(self):
         lib().orc_observe(self._h)
 
@@ -126,7 +133,9 @@ class OracleEnv:
                     phase=self._f('orc_phase', (S,)), mplight=self._f('orc_mplight', (S, 13)),
                     wave=self._f('orc_wave', (S, 12)), wait=self._f('orc_wait', (S,)),
                     wait_norm=self._f('orc_wait_norm', (S,)), pressure=self._f('orc_pressure', (S,)),
-                    queue_sum=self._f('orc_queue_sum', (S,)), queue_max=self._f('orc_queue_max', (S,)))
+                    queue_sum=self._f('orc_queue_sum', (S,)), queue_max=self._f('orc_queue_max', (S,)),
+                    arrivals=self._f('orc_arrivals', (S,)), departures=self._f('orc_departures', (S,)),
+                    mplight_full=self._f('orc_mplight_full', (S, 49)))
 
     def vehicles(self):
         v = _Vehicles()

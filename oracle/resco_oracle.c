@@ -64,6 +64,8 @@ struct orc_env {
     int32_t *agg_q, *agg_a, *agg_w, *agg_m;
     uint32_t *agg_s;
     int32_t *out_phase, *mplight, *wave, *pressure, *queue_sum, *queue_max;
+    int32_t *sig_arr, *sig_dep, *out_arr, *out_dep;     /* |Signal.arrivals| / |Signal.departures| of the running / last observe */
+    float *mplight_full;
     int64_t stats[10];
 };
 
@@ -268,6 +270,7 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     ALLOC(e->agg_q, O); ALLOC(e->agg_a, O); ALLOC(e->agg_w, O); ALLOC(e->agg_m, O); ALLOC(e->agg_s, O);
     ALLOC(e->out_phase, S); ALLOC(e->mplight, S * 13); ALLOC(e->wave, S * 12); ALLOC(e->pressure, S);
     ALLOC(e->queue_sum, S); ALLOC(e->queue_max, S);
+    ALLOC(e->sig_arr, S); ALLOC(e->sig_dep, S); ALLOC(e->out_arr, S); ALLOC(e->out_dep, S); ALLOC(e->mplight_full, S * 49);
     e->maxlen = 0.0f;
     for (int32_t v = 0; v < sc->n_vtypes; ++v) if (sc->vtype_params[v * VT_COLS + VT_LENGTH] > e->maxlen) e->maxlen = sc->vtype_params[v * VT_COLS + VT_LENGTH];
     orc_reset(e);
@@ -282,6 +285,7 @@ void orc_destroy(orc_env *e) {
     free(e->phase); free(e->left); free(e->next_phase);
     free(e->lane_agg); free(e->drq_norm); free(e->wait); free(e->wait_norm);
     free(e->agg_q); free(e->agg_a); free(e->agg_w); free(e->agg_m); free(e->agg_s);
+    free(e->sig_arr); free(e->sig_dep); free(e->out_arr); free(e->out_dep); free(e->mplight_full);
     free(e->out_phase); free(e->mplight); free(e->wave); free(e->pressure); free(e->queue_sum); free(e->queue_max);
     free(e);
 }
@@ -306,6 +310,7 @@ void orc_reset(orc_env *e) {
             e->left[s] = sc->tls_dur[sc->tls_dur_off[s] + e->phase[s]];
         }
         e->next_phase[s] = 0;       /* Signal.__init__: self.next_phase = 0 (traffic_signal.py:32) */
+        e->sig_arr[s] = 0; e->sig_dep[s] = 0;
     }
     memset(e->stats, 0, sizeof(e->stats));
     if (e->trip_log) memset(e->trip_log, 0, (size_t)sc->n_trips * 4 * sizeof(int32_t));
@@ -590,6 +595,7 @@ static void move(orc_env *e) {
             lane = sc->link_to_lane[link];
         }
         if (arrived) {
+            if (e->owner[s] != OWNER_NONE) e->sig_dep[e->owner[s]] += 1;    /* Signal.departures of its last observer (traffic_signal.py:226-232) */
             e->lane[s] = LANE_NONE; e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; e->trip[s] = -1;
             e->n_active -= 1;
             e->stats[1] += 1;
@@ -731,11 +737,18 @@ void orc_observe(orc_env *e) {
             float d = (sc->lane_len[lane] - e->pos[s]) + sc->route_tlsdist[sc->route_start[route] + e->cursor[s]];
             detect = d <= e->p.max_distance;
         }
-        if (!detect) { e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; continue; }
+        if (!detect) {
+            if (e->owner[s] != OWNER_NONE) e->sig_dep[e->owner[s]] += 1;
+            e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; continue;
+        }
         int32_t sig = 0;
         while (sc->sig_obs_start[sig + 1] <= oi) sig += 1;
         /* RESCO waiting-time rule (traffic_signal.py:198-202, 222-232) */
-        if (e->owner[s] != (uint8_t)sig) e->resco_wait[s] = 0;
+        if (e->owner[s] != (uint8_t)sig) {
+            e->resco_wait[s] = 0;
+            e->sig_arr[sig] += 1;
+            if (e->owner[s] != OWNER_NONE) e->sig_dep[e->owner[s]] += 1;
+        }
         if (e->resco_wait[s] > 0) {
             uint32_t w = (uint32_t)e->resco_wait[s] + (uint32_t)sc->step_length;
             e->resco_wait[s] = (uint16_t)(w > 65535u ? 65535u : w);
@@ -775,16 +788,22 @@ void orc_observe(orc_env *e) {
         for (int32_t i = sc->pr_out_start[sg]; i < sc->pr_out_start[sg + 1]; ++i) pr -= e->agg_q[sc->pr_out_idx[i]];
         e->pressure[sg] = -pr;
         e->mplight[sg * 13] = ph;                                         /* states.mplight (states.py:62-80) */
+        e->mplight_full[sg * 49] = (float)ph;                              /* states.mplight_full (states.py:83-113) */
+        e->out_arr[sg] = e->sig_arr[sg]; e->out_dep[sg] = e->sig_dep[sg]; e->sig_arr[sg] = 0; e->sig_dep[sg] = 0;
         for (int32_t m = 0; m < 12; ++m) {
-            int32_t q = 0, wv = 0;
+            int32_t q = 0, wv = 0, twm = 0, apm = 0;
+            float last_speed = 0.0f;
             for (int32_t i = sc->mv_in_start[sg * 12 + m]; i < sc->mv_in_start[sg * 12 + m + 1]; ++i) {
                 q += e->agg_q[sc->mv_in_idx[i]];
                 wv += e->agg_q[sc->mv_in_idx[i]] + e->agg_a[sc->mv_in_idx[i]];
+                twm += e->agg_w[sc->mv_in_idx[i]]; apm += e->agg_a[sc->mv_in_idx[i]];
+                last_speed = (float)e->agg_s[sc->mv_in_idx[i]] * (1.0f / 65536.0f);      /* states.py:97: total_speed restarts with every lane */
             }
             for (int32_t i = sc->mv_out_start[sg * 12 + m]; i < sc->mv_out_start[sg * 12 + m + 1]; ++i)
                 q -= e->agg_q[sc->mv_out_idx[i]];
             e->mplight[sg * 13 + 1 + m] = q;
             e->wave[sg * 12 + m] = wv;                                    /* states.wave (states.py:116-127) */
+            { float *mf = e->mplight_full + sg * 49 + 1 + m * 4; mf[0] = (float)q; mf[1] = (float)twm / 28.0f; mf[2] = last_speed; mf[3] = (float)apm / 28.0f; }
         }
     }
 }
@@ -821,6 +840,19 @@ const float *orc_wait_norm(const orc_env *e) { return e->wait_norm; }
 const int32_t *orc_pressure(const orc_env *e) { return e->pressure; }
 const int32_t *orc_queue_sum(const orc_env *e) { return e->queue_sum; }
 const int32_t *orc_queue_max(const orc_env *e) { return e->queue_max; }
+const int32_t *orc_arrivals(const orc_env *e) { return e->out_arr; }
+const int32_t *orc_departures(const orc_env *e) { return e->out_dep; }
+const float *orc_mplight_full(const orc_env *e) { return e->mplight_full; }
+/* fresh Signal objects on the running simulation (what MultiSignal.reset does, multi_signal.py:141-147): the RESCO
+ * waiting-time bookkeeping starts over and the program is re-installed ([SUMO-K] the current phase restarts) */
+void orc_reinit_signals(orc_env *e) {
+    const orc_scenario *sc = e->sc;
+    for (int32_t s = 0; s < sc->capacity; ++s) { e->owner[s] = OWNER_NONE; e->resco_wait[s] = 0; }
+    for (int32_t s = 0; s < sc->n_signals; ++s) {
+        if (!e->p.fixed_program) e->left[s] = sc->tls_dur[sc->tls_dur_off[s] + e->phase[s]];
+        e->next_phase[s] = 0; e->sig_arr[s] = 0; e->sig_dep[s] = 0;
+    }
+}
 void orc_get_vehicles(const orc_env *e, orc_vehicles *o) {
     o->hw = e->hw; o->next_trip = e->n_inserted; o->trip = e->trip; o->lane = e->lane; o->pos = e->pos; o->speed = e->speed;
     o->accel = e->accel; o->time_loss = e->time_loss; o->cursor = e->cursor; o->sumo_wait = e->sumo_wait;

@@ -34,6 +34,7 @@
 #define RS_DEV __device__ __forceinline__
 #define RS_HD __host__ __device__
 #define RS_MEM __device__ __forceinline__
+#define RS_G(p) (p)
 #define RS_CARVE __host__ __device__ __forceinline__
 __device__ __forceinline__ void rs_atomic_min(int32_t *p, int32_t v) { atomicMin(p, v); }
 __device__ __forceinline__ void rs_atomic_min(uint32_t *p, uint32_t v) { atomicMin(p, v); }
@@ -60,23 +61,46 @@ extern __shared__ __attribute__((aligned(16))) char rs_smem[];      // THE worki
 // grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 1024), normally one thread per slot.
 struct DevExec {
     int B;
-    template <class F> __device__ __forceinline__ void phase(F f) { f((int)threadIdx.x); __syncthreads(); }
+    unsigned long long *prof;       // optional per-phase timers (rs_phase_profile)
+    unsigned long long t0;
+    template <class F> __device__ __forceinline__ void phase(int id, F f) {
+        f((int)threadIdx.x);
+        __syncthreads();
+        if (prof && threadIdx.x == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(&prof[id], t1 - t0); t0 = t1; }
+    }
 };
 // Two register budgets: 64 VGPRs (two 1024-thread workgroups = 32 waves share a CU) and 128 VGPRs (blocks of <= 512);
 // CAP = the slot capacity as a compile-time constant (0: any)
+// The tables / state / output descriptors live in ONE constant block in device memory (StepArgs): passed by value they
+// would pin ~70 SGPRs for the whole kernel (beyond ~100 the compiler spills SGPRs into VGPR lanes around every use);
+// behind a const __restrict__ pointer every field is a re-loadable scalar load.
+struct StepArgs { KTab T; State G; Out O; Lds L; };
+// the block is read through the CONSTANT address space: scalar loads, and the compiler takes pointers loaded from it for
+// global ones (global_load instead of flat_load, which would also tie up the LDS wait counter)
+typedef const __attribute__((address_space(4))) StepArgs *StepArgsPtr;
 template <int CAP>
 __global__ void __launch_bounds__(1024, 8)
-rs_step_kernel_v64(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
+rs_step_kernel_v64(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
     if ((int)blockIdx.x >= P.n_envs) return;
-    DevExec ex{(int)blockDim.x};
-    rs_step_body<CAP>(ex, T, G, O, P, actions, (int)blockIdx.x);
+    const StepArgs *A = (const StepArgs *)Ac;
+    DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
+    rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
+}
+template <int CAP>
+__global__ void __launch_bounds__(512, 6)
+rs_step_kernel_v80(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
+    if ((int)blockIdx.x >= P.n_envs) return;
+    const StepArgs *A = (const StepArgs *)Ac;
+    DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
+    rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
 }
 template <int CAP>
 __global__ void __launch_bounds__(512, 4)
-rs_step_kernel_v128(KTab T, State G, Out O, KParams P, const int32_t *__restrict__ actions) {
+rs_step_kernel_v128(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
     if ((int)blockIdx.x >= P.n_envs) return;
-    DevExec ex{(int)blockDim.x};
-    rs_step_body<CAP>(ex, T, G, O, P, actions, (int)blockIdx.x);
+    const StepArgs *A = (const StepArgs *)Ac;
+    DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
+    rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
 }
 
 // reset every environment: no vehicles, every backlog at its first trip, TLS programs freshly installed
@@ -93,15 +117,27 @@ __global__ void rs_reset_kernel(KTab T, State G, KParams P) {
     }
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         int ph, left;
-        if (P.fixed_program) { ph = T.cold->fix_init_phase[s]; left = T.cold->fix_init_left[s]; }
-        else { ph = T.cold->tls_init_phase[s]; left = T.cold->tls_dur[T.cold->tls_dur_off[s] + ph]; }
+        if (P.fixed_program) { ph = T.cold.fix_init_phase[s]; left = T.cold.fix_init_left[s]; }
+        else { ph = T.cold.tls_init_phase[s]; left = T.cold.tls_dur[T.cold.tls_dur_off[s] + ph]; }
         G.tls[(env * S + s) * 3 + 0] = ph; G.tls[(env * S + s) * 3 + 1] = left; G.tls[(env * S + s) * 3 + 2] = 0;
     }
-    for (int d = threadIdx.x; d < T.n_dep; d += blockDim.x) G.dep_next[(size_t)env * T.n_dep + d] = T.cold->dep_first[d];
+    for (int d = threadIdx.x; d < T.n_dep; d += blockDim.x) G.dep_next[(size_t)env * T.n_dep + d] = T.cold.dep_first[d];
     if (threadIdx.x < 4) G.env[env * 4 + threadIdx.x] = 0;
     if (threadIdx.x < ST_N) G.stats[(size_t)env * ST_N + threadIdx.x] = 0;
     if (G.trip_log)
         for (int i = threadIdx.x; i < T.n_trips * 4; i += blockDim.x) G.trip_log[(size_t)env * T.n_trips * 4 + i] = 0;
+}
+
+// fresh Signal objects on the running simulation (rs_reinit_signals)
+__global__ void rs_reinit_kernel(KTab T, State G, KParams P) {
+    const int env = blockIdx.x;
+    const int C = T.capacity, S = T.n_signals;
+    const size_t eo = (size_t)env * C;
+    for (int s = threadIdx.x; s < C; s += blockDim.x) { G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0; }
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        if (!P.fixed_program) G.tls[(env * S + s) * 3 + 1] = T.cold.tls_dur[T.cold.tls_dur_off[s] + G.tls[(env * S + s) * 3 + 0]];
+        G.tls[(env * S + s) * 3 + 2] = 0;
+    }
 }
 
 // ---- static agents
@@ -112,7 +148,7 @@ __global__ void rs_act_random_kernel(KTab T, KParams P, uint32_t step_key, int32
     if (i >= P.n_envs * S) return;
     const int env = i / S, s = i - env * S;
     const uint32_t h = d_hash(P.seed ^ 0xA5A5A5A5u, (uint32_t)(P.env_base + env), (uint32_t)s, step_key, 7u);
-    actions[i] = (int32_t)(h % (uint32_t)T.cold->tls_ngreen[s]);
+    actions[i] = (int32_t)(h % (uint32_t)T.cold.tls_ngreen[s]);
 }
 // MAXWAVE / MAXPRESSURE (agents/maxwave.py:18-38, maxpressure.py:13-18): first maximum over the valid
 // phase pairs (in the reference's iteration order) of obs[pair0] + obs[pair1]
@@ -142,6 +178,7 @@ struct rs_sim {
     int n_envs = 0, env_base = 0, block = 256;
     size_t lds = 0;
     KTab K{};
+    StepArgs *args = nullptr;      // device copy of {K, G, O}
     int use_v128 = 0;
     State G{};
     Out O{};
@@ -202,15 +239,17 @@ static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_
     B.bytes = (size_t)(a * b * c * d) * kDtypeSize[dtype];
 }
 
-typedef void (*step_kernel_fn)(KTab, State, Out, KParams, const int32_t *);
+typedef void (*step_kernel_fn)(StepArgsPtr, KParams, const int32_t *);
 static const int kStepCaps[] = {0, 128, 256, 512, 1024};
-static step_kernel_fn step_kernel_for(int v128, int capacity) {
+// regs: 0 = 64 VGPRs (blocks up to 1024 threads), 1 = 128 VGPRs, 2 = 80 VGPRs (blocks up to 512 threads)
+#define RS_PICK(cap_) (regs == 1 ? rs_step_kernel_v128<cap_> : (regs == 2 ? rs_step_kernel_v80<cap_> : rs_step_kernel_v64<cap_>))
+static step_kernel_fn step_kernel_for(int regs, int capacity) {
     switch (capacity) {
-        case 128: return v128 ? rs_step_kernel_v128<128> : rs_step_kernel_v64<128>;
-        case 256: return v128 ? rs_step_kernel_v128<256> : rs_step_kernel_v64<256>;
-        case 512: return v128 ? rs_step_kernel_v128<512> : rs_step_kernel_v64<512>;
-        case 1024: return v128 ? rs_step_kernel_v128<1024> : rs_step_kernel_v64<1024>;
-        default: return v128 ? rs_step_kernel_v128<0> : rs_step_kernel_v64<0>;
+        case 128: return RS_PICK(128);
+        case 256: return RS_PICK(256);
+        case 512: return RS_PICK(512);
+        case 1024: return RS_PICK(1024);
+        default: return RS_PICK(0);
     }
 }
 
@@ -243,13 +282,13 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     int rc;
     KTab &K = h->K;
     {
-        KCold cold{};
+        KCold &cold = K.cold;
 #define UP(dst, type, src, count) if ((rc = dev_upload<type>(h, &dst, src, (size_t)(count)))) return fail(rc);
-        UP(K.lanes, LaneRec, PT.lanes.data(), PT.lanes.size()) UP(K.links, LinkRec, PT.links.data(), PT.links.size())
-        UP(K.foes, FoeRec, PT.foes.data(), PT.foes.size()) UP(K.rsteps, RStep, PT.rsteps.data(), PT.rsteps.size())
-        UP(K.routes, RouteRec, PT.routes.data(), PT.routes.size()) UP(K.next_link, uint16_t, PT.next_link.data(), PT.next_link.size())
-        UP(K.trip_route, uint16_t, PT.trip_route.data(), PT.trip_route.size()) UP(K.trip_vtype, uint8_t, PT.trip_vtype.data(), PT.trip_vtype.size())
-        UP(K.route_cont, float, sc->route_cont, (size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1) * sc->kmax)
+        UP(K.lanes_, LaneRec, PT.lanes.data(), PT.lanes.size()) UP(K.links_, LinkRec, PT.links.data(), PT.links.size())
+        UP(K.foes_, FoeRec, PT.foes.data(), PT.foes.size()) UP(K.rsteps_, RStep, PT.rsteps.data(), PT.rsteps.size())
+        UP(K.routes_, RouteRec, PT.routes.data(), PT.routes.size()) UP(K.next_link_, uint16_t, PT.next_link.data(), PT.next_link.size())
+        UP(K.trip_route_, uint16_t, PT.trip_route.data(), PT.trip_route.size()) UP(K.trip_vtype_, uint8_t, PT.trip_vtype.data(), PT.trip_vtype.size())
+        UP(K.route_cont_, float, sc->route_cont, (size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1) * sc->kmax)
         UP(cold.trip_depart, int32_t, sc->trip_depart, sc->n_trips) UP(cold.trip_next, uint16_t, PT.trip_next.data(), PT.trip_next.size())
         UP(cold.dep_lane, uint16_t, PT.dep_lane.data(), PT.dep_lane.size()) UP(cold.dep_first, uint16_t, PT.dep_first.data(), PT.dep_first.size())
         UP(cold.vtype_params, float, sc->vtype_params, sc->n_vtypes * VT_COLS)
@@ -268,7 +307,6 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         UP(cold.mv_out_start, int32_t, sc->mv_out_start, sc->n_signals * 12 + 1) UP(cold.mv_out_idx, int32_t, sc->mv_out_idx, sc->n_mv_out)
         UP(cold.pr_out_start, int32_t, sc->pr_out_start, sc->n_signals + 1) UP(cold.pr_out_idx, int32_t, sc->pr_out_idx, sc->n_pr_out)
         UP(cold.trips_cum, int32_t, sc->trips_cum, sc->horizon + 2)
-        UP(K.cold, KCold, &cold, 1)
 #undef UP
         K.maxlen = PT.maxlen;
         K.n_trips = sc->n_trips; K.tls_maxl = PT.tls_maxl; K.kmax = sc->kmax;
@@ -338,9 +376,14 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     h->lds = lds_carve(nullptr, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
     // block_threads: 0 = one thread per slot (at most 1024); a negative value selects the 128-VGPR build with |value|
-    // threads (<= 512) -- a tuning knob, see DESIGN.md
-    if (block_threads < 0) { h->use_v128 = 1; block_threads = -block_threads; }
-    if (block_threads == 0) block_threads = C > 1024 ? 1024 : C;
+    // threads (<= 512), -(10000 + threads) the 80-VGPR build -- tuning knobs, see DESIGN.md
+    if (block_threads < 0) { h->use_v128 = 1; block_threads = -block_threads; if (block_threads >= 10000) { h->use_v128 = 2; block_threads -= 10000; } }
+    else if (block_threads == 0) {
+        // default: one thread per slot up to 512 threads (a 1024-slot scenario: two slots per thread), 80 VGPRs -- three
+        // workgroups of 512 threads share a CU when the working memory stays below 53 KB
+        block_threads = C > 512 ? 512 : C;
+        h->use_v128 = 2;
+    }
     if (block_threads % 64 || block_threads > (h->use_v128 ? 512 : 1024) || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024] ([64, 512] for the 128-VGPR build)"; return fail(RS_EINVAL); }
     h->block = block_threads;
     {
@@ -351,13 +394,19 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         std::lock_guard<std::mutex> lock(mu);
         size_t &cur = max_lds[device_id & 63];
         if (h->lds > cur) {
-            for (int v = 0; v < 2; ++v)
+            for (int v = 0; v < 3; ++v)
                 for (int cp : kStepCaps)        // every instantiation: the ceiling is per kernel function
                     if (hipFuncSetAttribute((const void *)step_kernel_for(v, cp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
                         h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
                     }
             cur = h->lds;
         }
+    }
+    {
+        StepArgs sa{h->K, h->G, h->O, Lds{}};
+        lds_carve(&sa.L, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
+        if ((rc = dev_alloc(h, &h->args, 1, false))) return fail(rc);
+        if (hipMemcpy(h->args, &sa, sizeof(sa), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy(StepArgs) failed"; return fail(RS_EHIP); }
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(RS_EHIP); }
     *out = h;
@@ -392,7 +441,7 @@ static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
         h->ev_used += 1;
         HIPCHK(h, hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(step_kernel_for(h->use_v128, h->K.capacity), dim3(h->n_envs), dim3(h->block), h->lds, st, h->K, h->G, h->O, P, (const int32_t *)h->actions);
+    hipLaunchKernelGGL(step_kernel_for(h->use_v128, h->K.capacity), dim3(h->n_envs), dim3(h->block), h->lds, st, (StepArgsPtr)h->args, P, (const int32_t *)h->actions);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     return RS_OK;
@@ -412,6 +461,20 @@ extern "C" int rs_reset(rs_handle h, void *stream) {
     return rc;
 }
 
+extern "C" int rs_reinit_signals(rs_handle h, void *stream) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last = st;
+    hipLaunchKernelGGL(rs_reinit_kernel, dim3(h->n_envs), dim3(256), 0, st, h->K, h->G, h->P);
+    HIPCHK(h, hipGetLastError());
+    bool tm = h->timing;
+    h->timing = false;
+    int rc = launch_step(h, st, 0, 0);      // the first observe of the new Signal objects
+    h->timing = tm;
+    return rc;
+}
+
 extern "C" int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_device, void *stream) {
     if (!h) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
@@ -424,6 +487,14 @@ extern "C" int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_d
         if (!actions_on_device) HIPCHK(h, hipStreamSynchronize(st));
     }
     return launch_step(h, st, h->K.step_length, 1);
+}
+
+extern "C" int rs_ticks(rs_handle h, int32_t n_ticks, void *stream) {
+    if (!h || n_ticks < 0) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last = st;
+    return launch_step(h, st, n_ticks, 0);
 }
 
 extern "C" int rs_sync(rs_handle h) {

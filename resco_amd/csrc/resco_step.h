@@ -2,7 +2,8 @@
 // microsimulation + Signal.observe + states / rewards, as a sequence of PHASES over the vehicle slots of the environment.
 //
 // The body is written against a small execution interface (`Exec`):
-//   ex.phase(f)   runs f(tid) for every thread of the workgroup and ends with a workgroup barrier
+//   ex.phase(id, f)   runs f(tid) for every thread of the workgroup and ends with a workgroup barrier (id: 0..15,
+//                     names the phase for the optional per-phase timers: L0 L1 L2 L3 P C M D A1 RB A2 O0 O1 O2 O3)
 // On the GPU (resco_sim.hip) one workgroup = one environment, a thread owns the slots tid, tid + B, ...; the state lives
 // in LDS for the whole env-step and phase() is `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same
 // source for the host (tests/hostemu), where phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never
@@ -25,20 +26,20 @@ struct State {      // env-major SoA in HBM: field[env][slot]
     long long *stats;   // [N][10]
     uint16_t *dep_next; // [N][n_dep] head of every departure lane's backlog (TRIP_NONE: exhausted)
     RS_HD float *pos() const { return (float *)base; }
-    RS_HD float *speed() const { return (float *)(base + 4 * nc); }
-    RS_HD float *accel() const { return (float *)(base + 8 * nc); }
-    RS_HD float *tloss() const { return (float *)(base + 12 * nc); }
-    RS_HD float *sf() const { return (float *)(base + 16 * nc); }
-    RS_HD uint32_t *coop() const { return (uint32_t *)(base + 20 * nc); }
-    RS_HD uint32_t *cooplead() const { return (uint32_t *)(base + 24 * nc); }
-    RS_HD uint16_t *lane() const { return (uint16_t *)(base + 28 * nc); }
-    RS_HD uint16_t *trip() const { return (uint16_t *)(base + 30 * nc); }
-    RS_HD uint16_t *cursor() const { return (uint16_t *)(base + 32 * nc); }
-    RS_HD uint16_t *swait() const { return (uint16_t *)(base + 34 * nc); }
-    RS_HD uint16_t *rwait() const { return (uint16_t *)(base + 36 * nc); }
-    RS_HD uint16_t *depart() const { return (uint16_t *)(base + 38 * nc); }
-    RS_HD uint16_t *wtot() const { return (uint16_t *)(base + 40 * nc); }
-    RS_HD uint8_t *owner() const { return (uint8_t *)(base + 42 * nc); }
+    RS_HD float *speed() const { return RS_G((float *)(base + 4 * nc)); }
+    RS_HD float *accel() const { return RS_G((float *)(base + 8 * nc)); }
+    RS_HD float *tloss() const { return RS_G((float *)(base + 12 * nc)); }
+    RS_HD float *sf() const { return RS_G((float *)(base + 16 * nc)); }
+    RS_HD uint32_t *coop() const { return RS_G((uint32_t *)(base + 20 * nc)); }
+    RS_HD uint32_t *cooplead() const { return RS_G((uint32_t *)(base + 24 * nc)); }
+    RS_HD uint16_t *lane() const { return RS_G((uint16_t *)(base + 28 * nc)); }
+    RS_HD uint16_t *trip() const { return RS_G((uint16_t *)(base + 30 * nc)); }
+    RS_HD uint16_t *cursor() const { return RS_G((uint16_t *)(base + 32 * nc)); }
+    RS_HD uint16_t *swait() const { return RS_G((uint16_t *)(base + 34 * nc)); }
+    RS_HD uint16_t *rwait() const { return RS_G((uint16_t *)(base + 36 * nc)); }
+    RS_HD uint16_t *depart() const { return RS_G((uint16_t *)(base + 38 * nc)); }
+    RS_HD uint16_t *wtot() const { return RS_G((uint16_t *)(base + 40 * nc)); }
+    RS_HD uint8_t *owner() const { return RS_G((uint8_t *)(base + 42 * nc)); }
     static size_t bytes(size_t nc_) { return 43 * nc_; }
 };
 
@@ -48,19 +49,19 @@ struct Out {        // one allocation; n = N, o = n_obs, s = n_signals, lm = lan
     RS_HD size_t a5() const { return (size_t)n * o * 5 * 4; }      // one [N][n_obs][5] f32 block
     RS_HD size_t ns() const { return (size_t)n * s * 4; }          // one [N][S] 4-byte block
     RS_HD float *lane_agg() const { return (float *)base; }
-    RS_HD float *drq_norm() const { return (float *)(base + a5()); }
-    RS_HD float *wait() const { return (float *)(base + 2 * a5()); }
-    RS_HD float *wait_norm() const { return (float *)(base + 2 * a5() + ns()); }
-    RS_HD int32_t *phase() const { return (int32_t *)(base + 2 * a5() + 2 * ns()); }
-    RS_HD int32_t *pressure() const { return (int32_t *)(base + 2 * a5() + 3 * ns()); }
-    RS_HD int32_t *queue_sum() const { return (int32_t *)(base + 2 * a5() + 4 * ns()); }
-    RS_HD int32_t *queue_max() const { return (int32_t *)(base + 2 * a5() + 5 * ns()); }
-    RS_HD int32_t *mplight() const { return (int32_t *)(base + 2 * a5() + 6 * ns()); }
-    RS_HD int32_t *wave() const { return (int32_t *)(base + 2 * a5() + 19 * ns()); }
-    RS_HD int32_t *arrivals() const { return (int32_t *)(base + 2 * a5() + 31 * ns()); }      // [N][S] |Signal.arrivals| of the last observe
-    RS_HD int32_t *departures() const { return (int32_t *)(base + 2 * a5() + 32 * ns()); }    // [N][S] |Signal.departures|
-    RS_HD float *mplight_full() const { return (float *)(base + 2 * a5() + 33 * ns()); }      // [N][S][49]
-    RS_HD uint16_t *drq_f16() const { return (uint16_t *)(base + 2 * a5() + 82 * ns()); }
+    RS_HD float *drq_norm() const { return RS_G((float *)(base + a5())); }
+    RS_HD float *wait() const { return RS_G((float *)(base + 2 * a5())); }
+    RS_HD float *wait_norm() const { return RS_G((float *)(base + 2 * a5() + ns())); }
+    RS_HD int32_t *phase() const { return RS_G((int32_t *)(base + 2 * a5() + 2 * ns())); }
+    RS_HD int32_t *pressure() const { return RS_G((int32_t *)(base + 2 * a5() + 3 * ns())); }
+    RS_HD int32_t *queue_sum() const { return RS_G((int32_t *)(base + 2 * a5() + 4 * ns())); }
+    RS_HD int32_t *queue_max() const { return RS_G((int32_t *)(base + 2 * a5() + 5 * ns())); }
+    RS_HD int32_t *mplight() const { return RS_G((int32_t *)(base + 2 * a5() + 6 * ns())); }
+    RS_HD int32_t *wave() const { return RS_G((int32_t *)(base + 2 * a5() + 19 * ns())); }
+    RS_HD int32_t *arrivals() const { return RS_G((int32_t *)(base + 2 * a5() + 31 * ns())); }      // [N][S] |Signal.arrivals| of the last observe
+    RS_HD int32_t *departures() const { return RS_G((int32_t *)(base + 2 * a5() + 32 * ns())); }    // [N][S] |Signal.departures|
+    RS_HD float *mplight_full() const { return RS_G((float *)(base + 2 * a5() + 33 * ns())); }      // [N][S][49]
+    RS_HD uint16_t *drq_f16() const { return RS_G((uint16_t *)(base + 2 * a5() + 82 * ns())); }
     RS_HD size_t bytes() const { return 2 * a5() + 82 * ns() + (size_t)n * s * lm * 5 * 2 + 64; }
 };
 
@@ -129,6 +130,7 @@ struct __attribute__((aligned(8))) Node {
     uint16_t trip;      // TRIP_NONE: free slot
     uint16_t nxt;       // next vehicle of the same grid cell (unordered), NIL terminated
 };
+// The layout (a table of offsets, computed once by the host: lds_carve) is read from the constant argument block.
 // An array of the working memory is addressed as (RS_SMEM + offset): the including file defines RS_SMEM as THE shared
 // array of the workgroup (so that every access is provably an LDS access: ds_* instructions with immediate offsets
 // instead of flat ones through 64-bit pointers), the host emulation as a plain buffer.
@@ -139,10 +141,8 @@ template <class Tp> struct LPtr {
 };
 struct Lds {
     LPtr<Node> node;            // {pos, trip, next-in-cell}: one 8-byte read per chain step
-    LPtr<float> speed, vnx, tloss, sf, vtp;
-    LPtr<uint32_t> coop;        // cooperation request addressed to this slot: trip << 16 | slot of the requester (COOP_NONE)
-    LPtr<uint32_t> cooplead;    // the target-lane leader this slot tries to fall in behind: trip << 16 | slot (COOP_NONE)
-    LPtr<uint16_t> lane, rq, swait, nlink, cell;
+    LPtr<float> speed, vnx, vtp;
+    LPtr<uint16_t> lane, rq, nlink, cell;
     LPtr<uint16_t> grid;        // the cells (bit 15: the cell holds a moving vehicle)
     LPtr<uint8_t> vt;
     LPtr<int32_t> arr;          // link approach registers
@@ -165,40 +165,35 @@ struct Lds {
 #define CELL_NEW 0xFFFEu        // L.cell value of a slot that was filled by an insertion in this tick's A1 phase
 
 RS_CARVE size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-RS_CARVE size_t lds_scratch_bytes(int C, int n_obs) {       // vnx, later reused by the observe aggregates
-    const size_t a = (size_t)C * 4, b = align16((size_t)n_obs * 4) * 5;
-    return a > b ? a : b;
-}
-// One carve routine for both the size computation (base = NULL) and the pointer set-up.
-// The arrays whose size depends only on the capacity come first: with the capacity a template parameter of the step
-// body their offsets are compile-time constants (DS immediate offsets, no SGPR each); the scenario-sized ones follow.
+// Layout of the working memory: a table of offsets computed once by the host (read from the constant argument block, so an
+// offset costs a scalar load where it is used and no register in between).  The per-lane aggregates of the observe phase
+// live where vnx was (dead by then).
 RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
 #define CARVE(field, bytes) { if (L) L->field.off = (uint32_t)o; o += align16(bytes); }
-    CARVE(node, (size_t)C * 8) CARVE(speed, (size_t)C * 4) CARVE(tloss, (size_t)C * 4) CARVE(sf, (size_t)C * 4)
-    CARVE(coop, (size_t)C * 4) CARVE(cooplead, (size_t)C * 4)
-    CARVE(lane, (size_t)C * 2) CARVE(rq, (size_t)C * 2) CARVE(swait, (size_t)C * 2)
+    CARVE(node, (size_t)C * 8) CARVE(speed, (size_t)C * 4)
+    CARVE(lane, (size_t)C * 2) CARVE(rq, (size_t)C * 2)
     CARVE(nlink, (size_t)C * 2) CARVE(cell, (size_t)C * 2)
     CARVE(vt, (size_t)C)
-    CARVE(sc, (size_t)(SC_STATS + ST_N) * 4)
-    CARVE(alive, (size_t)((C + 31) / 32) * 4)
-    {   // the per-lane aggregates of the observe phase live where vnx was (dead by then)
-        const size_t ab = align16((size_t)n_obs * 4);
+    {
+        const size_t ab = align16((size_t)n_obs * 4), a = (size_t)C * 4, b = 5 * ab;
         if (L) {
             const uint32_t p = (uint32_t)o;
             L->vnx.off = p;
             L->agg_q.off = p; L->agg_a.off = p + (uint32_t)ab; L->agg_w.off = p + (uint32_t)(2 * ab);
             L->agg_m.off = p + (uint32_t)(3 * ab); L->agg_s.off = p + (uint32_t)(4 * ab);
         }
-        o += align16(lds_scratch_bytes(C, n_obs));
+        o += align16(a > b ? a : b);
     }
-    CARVE(grid, (size_t)(n_cells + 8) * 2)
+    CARVE(sc, (size_t)(SC_STATS + ST_N) * 4)
+    CARVE(alive, (size_t)((C + 31) / 32) * 4)
     CARVE(insm, (size_t)((n_dep + 31) / 32) * 4)
     CARVE(vtp, (size_t)n_vt * VT_COLS * 4)
-    CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2)
     CARVE(phase, (size_t)S * 4) CARVE(left, (size_t)S * 4) CARVE(nextp, (size_t)S * 4)
     CARVE(sig_arr, (size_t)S * 4) CARVE(sig_dep, (size_t)S * 4)
     CARVE(tstate, (size_t)S * tls_maxl)
+    CARVE(grid, (size_t)(n_cells + 8) * 2)
+    CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2)
 #undef CARVE
     return o;
 }
@@ -361,12 +356,12 @@ RS_DEV int tls_state(const KTab &T, const Lds &L, int tls, int pos) {
 // none (last edge / a dead end for this route).  For a normal lane it is a table of (route step, lane index, trip parity)
 RS_DEV uint16_t cache_link(const KTab &T, const LaneRec &LR, int lane, int rq, int trip) {
     if (LR.link_cnt == 0) return NLINK_NONE;
-    if (LR.flags & LF_INTERNAL) { const int l = LR.link_start; return (uint16_t)(l | (T.links[l].arr_idx >= 0 ? NLINK_ARR : 0)); }
-    return T.next_link[((size_t)rq * T.kmax + (lane - (int)LR.edge_lane0)) * 2 + (trip & 1)];
+    if (LR.flags & LF_INTERNAL) { const int l = LR.link_start; return (uint16_t)(l | (T.links()[l].arr_idx >= 0 ? NLINK_ARR : 0)); }
+    return T.next_link()[((size_t)rq * T.kmax + (lane - (int)LR.edge_lane0)) * 2 + (trip & 1)];
 }
 RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const LinkRec &K) {
     for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
-        const FoeRec F = T.foes[i];
+        const FoeRec F = T.foes()[i];
         if (F.tls != 0xFF && tls_state(T, L, F.tls, F.tls_pos) == TLS_R) continue;
         if (F.arr_idx >= 0 && L.arr[F.arr_idx] < RM_FOE_GAP_Q) return true;
         if (F.via1_cell0 != 0xFFFF && cells_have_mover(L.grid, F.via1_cell0, F.via1_nc)) return true;   // a moving vehicle on
@@ -375,25 +370,26 @@ RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const LinkRec &K) {
     return false;
 }
 // copy the link states of signal s in phase ph into the working memory (called by the thread that owns the signal)
-RS_DEV void tls_refresh(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
-    const uint8_t *src = (P.fixed_program ? T.cold->fix8 + T.cold->fix_state_off[s] : T.cold->tls8 + T.cold->tls_state_off[s]) + ph * T.cold->tls_nlinks[s];
-    const int n = T.cold->tls_nlinks[s];
+RS_DEV void tls_refresh(const KTab &T, const Lds &L, const KParams &P, int s, int ph) {
+    const uint8_t *src = (P.fixed_program ? T.cold.fix8 + T.cold.fix_state_off[s] : T.cold.tls8 + T.cold.tls_state_off[s]) + ph * T.cold.tls_nlinks[s];
+    const int n = T.cold.tls_nlinks[s];
+#pragma unroll 1
     for (int i = 0; i < n; ++i) L.tstate[s * T.tls_maxl + i] = src[i];
 }
-RS_DEV void set_phase(const KTab &T, Lds &L, const KParams &P, int s, int ph) {
-    if (ph < 0 || ph >= T.cold->tls_nphase[s]) return;
+RS_DEV void set_phase(const KTab &T, const Lds &L, const KParams &P, int s, int ph) {
+    if (ph < 0 || ph >= T.cold.tls_nphase[s]) return;
     L.phase[s] = ph;
-    L.left[s] = T.cold->tls_dur[T.cold->tls_dur_off[s] + ph];
+    L.left[s] = T.cold.tls_dur[T.cold.tls_dur_off[s] + ph];
     tls_refresh(T, L, P, s, ph);
 }
 // TLS switch events at the beginning of tick `tick` of this launch (P0), preceded by Signal.set_phase when the yellow
 // ticks are over
-RS_DEV void tls_begin_of_tick(const KTab &T, Lds &L, const KParams &P, int s, int tick) {
+RS_DEV void tls_begin_of_tick(const KTab &T, const Lds &L, const KParams &P, int s, int tick) {
     if (P.do_fsm && !P.fixed_program && tick == T.yellow_length) set_phase(T, L, P, s, L.nextp[s]);
     int left = L.left[s];
     if (left == 0) {
-        const int32_t *dur = P.fixed_program ? T.cold->fix_dur + T.cold->fix_dur_off[s] : T.cold->tls_dur + T.cold->tls_dur_off[s];
-        const int Pn = P.fixed_program ? T.cold->fix_nphase[s] : T.cold->tls_nphase[s];
+        const int32_t *dur = P.fixed_program ? T.cold.fix_dur + T.cold.fix_dur_off[s] : T.cold.tls_dur + T.cold.tls_dur_off[s];
+        const int Pn = P.fixed_program ? T.cold.fix_nphase[s] : T.cold.tls_nphase[s];
         const int ph = (L.phase[s] + 1) % Pn;
         left = dur[ph];
         L.phase[s] = ph;
@@ -405,7 +401,7 @@ RS_DEV void tls_begin_of_tick(const KTab &T, Lds &L, const KParams &P, int s, in
 // 0 when the lane is as good as any, or the need is still far away; else the direction of the nearest best lane.
 // extra = RM_SG_EXTRA_LANES when asking whether a lane is good enough to move INTO for speed gain.  (oracle: strategic_dir_at)
 RS_DEV int strategic_dir(const KTab &T, int rq, int kk, int n, float x, float v, int extra, float &rem) {
-    const float *cn = T.route_cont + (size_t)rq * T.kmax;
+    const float *cn = T.route_cont() + (size_t)rq * T.kmax;
     float best = 0.0f;
     for (int j = 0; j < n; ++j) { const float c = cn[j]; if (c > best) best = c; }
     const float mine = cn[kk];
@@ -421,17 +417,17 @@ RS_DEV int strategic_dir(const KTab &T, int rq, int kk, int n, float x, float v,
 }
 // approach registration of slot s for the coming tick (P3): a moving vehicle whose next link somebody may have to yield
 // to registers its arrival time there
-RS_DEV void register_approach(const KTab &T, Lds &L, int s) {
+RS_DEV void register_approach(const KTab &T, const Lds &L, int s) {
     const int lane = L.lane[s];
     if (lane == (int)LANE_NONE) return;
     const int nlk = L.nlink[s];
     if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
     const float v = L.speed[s];
     if (v <= RM_HALT_SPEED) return;
-    const LinkRec K = T.links[nlk & 0x7FFF];
+    const LinkRec K = T.links()[nlk & 0x7FFF];
     const int st = tls_state(T, L, K.tls, K.tls_pos);
     if (st == TLS_R) return;
-    const float dist = T.lanes[lane].len - L.node[s].pos;
+    const float dist = T.lanes()[lane].len - L.node[s].pos;
     if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) return;
     const float ta = dist / (v > 1.0f ? v : 1.0f);
     const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
@@ -461,15 +457,16 @@ RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool cla
 
 // ------------------------------------------------------------------------------------------------ the phases
 // P: plan (Krauss car-following + links) for slot s
-RS_DEV void phase_plan(const KTab &T, Lds &L, const KParams &P, int genv, int t, int s) {
+RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
     const int lane = L.lane[s];
     if (lane == (int)LANE_NONE) return;
     const int k = L.node[s].trip;
     const float *vt = L.vtp + L.vt[s] * VT_COLS;
     const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
     const float v = L.speed[s], x = L.node[s].pos;
-    const float sf = L.sf[s];
-    LaneRec LR = T.lanes[lane];
+    const float sf = G.sf()[eo + s];
+    const uint32_t c2 = G.cooplead()[eo + s];
+    LaneRec LR = T.lanes()[lane];
     float vfree = v + a;
     const float vl = LR.vmax * sf;
     if (vl < vfree) vfree = vl;
@@ -489,9 +486,9 @@ RS_DEV void phase_plan(const KTab &T, Lds &L, const KParams &P, int genv, int t,
         have = true; found = true;
     }
     {   // cooperation: requests of the last lane-change phase
-        const uint32_t c1 = L.coop[s], c2 = L.cooplead[s];
-        if (c1 != COOP_NONE) { L.coop[s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
-        if (c2 != COOP_NONE) { L.cooplead[s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
+        const uint32_t c1 = G.coop()[eo + s];        // (in HBM: written rarely, by other threads, with a global atomic)
+        if (c1 != COOP_NONE) { G.coop()[eo + s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
+        if (c2 != COOP_NONE) { G.cooplead()[eo + s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
     }
     float seen = LR.len - x;
     if (!found && seen < look) {
@@ -506,10 +503,10 @@ RS_DEV void phase_plan(const KTab &T, Lds &L, const KParams &P, int genv, int t,
             LinkRec K;
             if (link == NLINK_NONE) {
                 // last edge of the route: free run to its end; otherwise a dead end: wait for a lane change
-                if (!cur_int && T.rsteps[rq].next_edge == 0xFFFF) break;
+                if (!cur_int && T.rsteps()[rq].next_edge == 0xFFFF) break;
                 stop_here = true;
             } else {
-                K = T.links[link];
+                K = T.links()[link];
                 const int st = tls_state(T, L, K.tls, K.tls_pos);
                 if (K.tls != 0xFF && (st == TLS_R || st == TLS_Y) && seen >= bgv) stop_here = true;
                 if (!stop_here && !(K.flags & KF_CONT) && ((K.flags & KF_MINOR) || (K.tls != 0xFF && st == TLS_g))) {
@@ -567,24 +564,24 @@ RS_DEV void phase_plan(const KTab &T, Lds &L, const KParams &P, int genv, int t,
 }
 
 // M: move slot s, hand it over to the next lanes, let it arrive; register it in the grid of the moved state
-RS_DEV void phase_move(const KTab &T, Lds &L, const State &G, const KParams &P, int env, size_t eo, int t, bool last_tick, int s,
+RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParams &P, int env, size_t eo, int t, bool last_tick, int s,
                        int &active, int &halted, int &top) {
     int lane = L.lane[s];
     if (lane == (int)LANE_NONE) return;
     const int k = L.node[s].trip;
     int link = (int)(L.nlink[s] & 0x7FFF);
-    LaneRec LR = T.lanes[lane];
+    LaneRec LR = T.lanes()[lane];
     const float vn = L.vnx[s];
-    const float vref = LR.vmax * L.sf[s];
+    const float vref = LR.vmax * G.sf()[eo + s];
     if (last_tick) G.accel()[eo + s] = vn - L.speed[s];
     L.speed[s] = vn;
     if (vn <= RM_HALT_SPEED) {
-        const int w = L.swait[s]; if (w < 65535) L.swait[s] = (uint16_t)(w + 1);
+        const int w = G.swait()[eo + s]; if (w < 65535) G.swait()[eo + s] = (uint16_t)(w + 1);
         halted += 1;
         if (G.trip_log) { const int wt = G.wtot()[eo + s]; if (wt < 65535) G.wtot()[eo + s] = (uint16_t)(wt + 1); }
-    } else L.swait[s] = 0;
-    float tl = L.tloss[s];
-    if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; L.tloss[s] = tl; }
+    } else G.swait()[eo + s] = 0;
+    float tl = G.tloss()[eo + s];
+    if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss()[eo + s] = tl; }
     float x = L.node[s].pos + vn;
     int rq = L.rq[s];
     bool arrived = false, moved = false;
@@ -593,13 +590,13 @@ RS_DEV void phase_move(const KTab &T, Lds &L, const State &G, const KParams &P, 
         const bool li = (LR.flags & LF_INTERNAL) != 0;
         if (moved) link = (int)(cache_link(T, LR, lane, rq, k) & 0x7FFF);
         if (link == NLINK_NONE) {
-            if (!li && T.rsteps[rq].next_edge == 0xFFFF) arrived = true; else x = LR.len;
+            if (!li && T.rsteps()[rq].next_edge == 0xFFFF) arrived = true; else x = LR.len;
             break;
         }
         x -= LR.len;
         if (!li) rq += 1;
         {
-            const LinkRec Km = T.links[link];
+            const LinkRec Km = T.links()[link];
             lane = Km.to_lane;
             LR = Km.dest;
         }
@@ -607,7 +604,7 @@ RS_DEV void phase_move(const KTab &T, Lds &L, const State &G, const KParams &P, 
     }
     if (arrived) {
         L.lane[s] = LANE_NONE; L.node[s].trip = TRIP_NONE; L.cell[s] = 0xFFFF;
-        L.coop[s] = COOP_NONE; L.cooplead[s] = COOP_NONE;
+        G.coop()[eo + s] = COOP_NONE; G.cooplead()[eo + s] = COOP_NONE;
         rs_atomic_and(&L.alive[s >> 5], ~(1u << (s & 31)));
         {   // Signal.departures of the signal that observed the vehicle last (traffic_signal.py:226-232)
             const int ow = G.owner()[eo + s];
@@ -639,10 +636,10 @@ RS_DEV void phase_move(const KTab &T, Lds &L, const State &G, const KParams &P, 
 
 // D: lane-change decision of slot s on the moved state; returns the target lane (-1: stay).  A blocked strategic
 // changer asks for cooperation (oracle: lane_change()).
-RS_DEV int phase_lc_decide(const KTab &T, Lds &L, int t, int s) {
+RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const State &G, size_t eo, int t, int s) {
     const int lane = L.lane[s];
     if (lane == (int)LANE_NONE) return -1;
-    const LaneRec LR = T.lanes[lane];
+    const LaneRec LR = T.lanes()[lane];
     const int n = LR.flags >> 2;
     if ((LR.flags & LF_INTERNAL) || n < 2) return -1;
     const int dir_allowed = (t & 1) ? -1 : +1;
@@ -701,9 +698,9 @@ RS_DEV int phase_lc_decide(const KTab &T, Lds &L, int t, int s) {
     if (want == 2) {
         // blocked: fall in behind the target-lane leader, and ask the nearest vehicle completely behind me on the target
         // lane to let me in
-        if (lead_t != NIL) L.cooplead[s] = ((uint32_t)L.node[lead_t].trip << 16) | (uint32_t)lead_t;
+        if (lead_t != NIL) G.cooplead()[eo + s] = ((uint32_t)L.node[lead_t].trip << 16) | (uint32_t)lead_t;
         const int R = at_or_behind_within(L, tcell0, nc, x - vt[VT_LENGTH], RM_COOP_RANGE);
-        if (R != NIL) rs_atomic_min(&L.coop[R], ((uint32_t)k << 16) | (uint32_t)s);
+        if (R != NIL) rs_atomic_min(&G.coop()[eo + R], ((uint32_t)k << 16) | (uint32_t)s);
     }
     return -1;
 }
@@ -712,12 +709,12 @@ RS_DEV int phase_lc_decide(const KTab &T, Lds &L, int t, int s) {
 RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, int t, int d) {
     const int k = L.dep[d];
 #ifdef RS_EMU_DEBUG
-    if (k == 312 && t >= 470) printf("t %d d %d k %d depart %d\n", t, d, k, T.cold->trip_depart[k]);
+    if (k == 312 && t >= 470) printf("t %d d %d k %d depart %d\n", t, d, k, T.cold.trip_depart[k]);
 #endif
-    if (k == (int)TRIP_NONE || T.cold->trip_depart[k] > t) return false;
-    const int dl = T.cold->dep_lane[d];
-    const LaneRec LR = T.lanes[dl];
-    const float *vt = L.vtp + T.trip_vtype[k] * VT_COLS;
+    if (k == (int)TRIP_NONE || T.cold.trip_depart[k] > t) return false;
+    const int dl = T.cold.dep_lane[d];
+    const LaneRec LR = T.lanes()[dl];
+    const float *vt = L.vtp + T.trip_vtype()[k] * VT_COLS;
     const float mypos = vt[VT_LENGTH] < LR.len ? vt[VT_LENGTH] : LR.len;
     // only vehicles with pos - length < mypos + minGap can be in the way
     const int nc = lane_cells(LR);
@@ -735,11 +732,13 @@ RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, int t, int d) {
 
 // the r-th (0-based) free slot in ascending order, -1: none
 RS_DEV int nth_free_slot(const Lds &L, int C, int r) {
+#pragma unroll 1
     for (int w = 0; w < (C + 31) / 32; ++w) {
         uint32_t fr = ~L.alive[w];
         if (w == (C - 1) / 32 && (C & 31)) fr &= (1u << (C & 31)) - 1u;
         const int c = rs_popc(fr);
         if (r >= c) { r -= c; continue; }
+#pragma unroll 1
         for (int j = 0; j < r; ++j) fr &= fr - 1u;      // drop the r lowest set bits
         return w * 32 + rs_ffs(fr) - 1;
     }
@@ -749,21 +748,19 @@ RS_DEV int nth_free_slot(const Lds &L, int C, int r) {
 // ------------------------------------------------------------------------------------------------ the step
 // CAP: the slot capacity as a compile-time constant (0: read it from the tables at run time)
 template <int CAP, class Exec>
-RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, const KParams &P,
+RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, const Out &O, const KParams &P,
                          const int32_t *actions, int env) {
     const int B = ex.B;
     const int C = CAP ? CAP : T.capacity, S = T.n_signals, NO = T.n_obs;
     const int genv = P.env_base + env;
-    Lds L;
-    lds_carve(&L, C, T.n_cells, T.n_arr, T.n_dep, NO, S, T.n_vtypes, T.tls_maxl);
     const size_t eo = (size_t)env * C;
     const int n_ticks = P.n_ticks;
     const int ngw = (T.n_cells + 8 + 1) / 2;        // grid dwords
 
     // ---- L0: scalars, tables, TLS, backlog heads
-    ex.phase([&](int tid) {
+    ex.phase(0, [&](int tid) {
         if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 4 ? G.env[env * 4 + tid] : 0;
-        for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold->vtype_params[i];
+        for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold.vtype_params[i];
         for (int i = tid; i < ngw; i += B) ((uint32_t *)(uint16_t *)L.grid)[i] = 0x7FFF7FFFu;
         for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
         for (int i = tid; i < (C + 31) / 32; i += B) L.alive[i] = 0u;
@@ -779,21 +776,19 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         }
     });
     // ---- L1: the slab (once per env-step)
-    ex.phase([&](int tid) {
+    ex.phase(1, [&](int tid) {
         const int hw0 = L.sc[SC_HW];
         for (int s = tid; s < C; s += B) {
             uint16_t ln = LANE_NONE, tr = TRIP_NONE;
             if (s < hw0) { ln = G.lane()[eo + s]; tr = G.trip()[eo + s]; }
             L.lane[s] = ln; L.node[s].trip = tr; L.cell[s] = 0xFFFF;
-            L.coop[s] = COOP_NONE; L.cooplead[s] = COOP_NONE;
             if (ln == LANE_NONE) continue;
             const float sp = G.speed()[eo + s];
-            L.node[s].pos = G.pos()[eo + s]; L.speed[s] = sp; L.swait[s] = G.swait()[eo + s]; L.tloss[s] = G.tloss()[eo + s];
-            L.sf[s] = G.sf()[eo + s]; L.coop[s] = G.coop()[eo + s]; L.cooplead[s] = G.cooplead()[eo + s];
-            const int rq = (int)T.routes[T.trip_route[tr]].start + (int)G.cursor()[eo + s];
+            L.node[s].pos = G.pos()[eo + s]; L.speed[s] = sp;
+            const int rq = (int)T.routes()[T.trip_route()[tr]].start + (int)G.cursor()[eo + s];
             L.rq[s] = (uint16_t)rq;
-            L.vt[s] = T.trip_vtype[tr];
-            const LaneRec LR0 = T.lanes[ln];
+            L.vt[s] = T.trip_vtype()[tr];
+            const LaneRec LR0 = T.lanes()[ln];
             L.nlink[s] = cache_link(T, LR0, ln, rq, tr);
             const int c = LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0));
             L.cell[s] = (uint16_t)c;
@@ -802,15 +797,15 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         }
     });
     // ---- L2: Signal.prep_phase for every signal (traffic_signal.py:176-184), then the TLS events of tick 0
-    ex.phase([&](int tid) {
+    ex.phase(2, [&](int tid) {
         for (int s = B - 1 - tid; s < S; s += B) {
             if (P.do_fsm && !P.fixed_program) {
-                const int a = actions[env * S + s], cur = L.phase[s], Gn = T.cold->tls_ngreen[s];
-                if (a < 0 || a >= T.cold->tls_nphase[s]) L.nextp[s] = cur;
+                const int a = actions[env * S + s], cur = L.phase[s], Gn = T.cold.tls_ngreen[s];
+                if (a < 0 || a >= T.cold.tls_nphase[s]) L.nextp[s] = cur;
                 else {
                     L.nextp[s] = a;
                     if (cur != a && cur < Gn && a < Gn) {
-                        const int y = T.cold->tls_yellow[T.cold->tls_yel_off[s] + cur * Gn + a];
+                        const int y = T.cold.tls_yellow[T.cold.tls_yel_off[s] + cur * Gn + a];
                         if (y >= 0) set_phase(T, L, P, s, y);
                     }
                 }
@@ -819,7 +814,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         }
     });
     // ---- L3: approach registration of the first tick (later ticks register at their end, see A2)
-    if (n_ticks > 0) ex.phase([&](int tid) {
+    if (n_ticks > 0) ex.phase(3, [&](int tid) {
         const int hw = L.sc[SC_HW];
         for (int s = tid; s < hw; s += B) register_approach(T, L, s);
     });
@@ -827,22 +822,22 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
     for (int tick = 0; tick < n_ticks; ++tick) {
         const int t = L.sc[SC_T], hw = L.sc[SC_HW];
         // ---- P: plan
-        ex.phase([&](int tid) {
-            for (int s = tid; s < hw; s += B) phase_plan(T, L, P, genv, t, s);
+        ex.phase(4, [&](int tid) {
+            for (int s = tid; s < hw; s += B) phase_plan(T, L, G, eo, P, genv, t, s);
         });
         // ---- C: everybody leaves the grid and drops its approach registration (nobody reads them between plan and move)
-        ex.phase([&](int tid) {
+        ex.phase(5, [&](int tid) {
             for (int s = tid; s < hw; s += B) {
                 const int c = L.cell[s];
                 if (c < 0xFFF0) L.grid[c] = NIL;
                 const int nlk = L.nlink[s];
-                if (L.lane[s] != LANE_NONE && (nlk & NLINK_ARR)) L.arr[T.links[nlk & 0x7FFF].arr_idx] = ARR_NONE;
+                if (L.lane[s] != LANE_NONE && (nlk & NLINK_ARR)) L.arr[T.links()[nlk & 0x7FFF].arr_idx] = ARR_NONE;
             }
             if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_REBUILD] = 0; }
             for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
         });
         // ---- M: move; build the grid of the moved state
-        ex.phase([&](int tid) {
+        ex.phase(6, [&](int tid) {
             int active = 0, halted = 0, top = 0;
             for (int s = tid; s < hw; s += B) phase_move(T, L, G, P, env, eo, t, tick == n_ticks - 1, s, active, halted, top);
             if (active) rs_atomic_add(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
@@ -851,16 +846,29 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         });
         const int hw2 = L.sc[SC_HWNEW];
         // ---- D: decisions on the moved state: lane changes (+ cooperation requests), insertions, next tick's TLS events
-        ex.phase([&](int tid) {
-            for (int s = tid; s < hw2; s += B) L.vnx[s] = rs_int_as_float(phase_lc_decide(T, L, t, s));
+#ifdef RS_PHASE_SPLIT       // diagnostic build: the three roles of D as separately timed phases (ids 11, 12 borrow O0 / O1's slots)
+        ex.phase(7, [&](int tid) { for (int s = tid; s < hw2; s += B) L.vnx[s] = rs_int_as_float(phase_lc_decide(T, L, G, eo, t, s)); });
+        ex.phase(11, [&](int tid) {
+            for (int d = B - 1 - tid; d < T.n_dep; d += B)
+                if (phase_insert_decide(T, L, t, d)) rs_atomic_or(&L.insm[d >> 5], 1u << (d & 31));
+        });
+        ex.phase(12, [&](int tid) {
+            if (tick + 1 < n_ticks)
+                for (int sg = B - 1 - tid; sg < S; sg += B) tls_begin_of_tick(T, L, P, sg, tick + 1);
+            if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
+        });
+#else
+        ex.phase(7, [&](int tid) {
+            for (int s = tid; s < hw2; s += B) L.vnx[s] = rs_int_as_float(phase_lc_decide(T, L, G, eo, t, s));
             for (int d = B - 1 - tid; d < T.n_dep; d += B)
                 if (phase_insert_decide(T, L, t, d)) rs_atomic_or(&L.insm[d >> 5], 1u << (d & 31));
             if (tick + 1 < n_ticks)
                 for (int sg = B - 1 - tid; sg < S; sg += B) tls_begin_of_tick(T, L, P, sg, tick + 1);
             if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
         });
+#endif
         // ---- A1: lane changers leave their cell; the winners of the departure lanes fill free slots
-        ex.phase([&](int tid) {
+        ex.phase(8, [&](int tid) {
             for (int s = tid; s < hw2; s += B) {
                 if (L.lane[s] == LANE_NONE) continue;
                 const int target = rs_float_as_int(L.vnx[s]);
@@ -872,7 +880,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
                 if ((L.grid[c] & 0x7FFF) == s && L.node[s].nxt == NIL) { L.grid[c] = NIL; L.cell[s] = 0xFFFD; }   // alone in my cell: leave it, re-register in A2
                 else L.sc[SC_REBUILD] = 1;      // shared cell: everybody leaves and re-enters the grid (my cell index stays valid for the clearing)
                 L.lane[s] = (uint16_t)target;
-                L.nlink[s] = cache_link(T, T.lanes[target], target, L.rq[s], L.node[s].trip);
+                L.nlink[s] = cache_link(T, T.lanes()[target], target, L.rq[s], L.node[s].trip);
             }
             for (int d = B - 1 - tid; d < T.n_dep; d += B) {
                 if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
@@ -882,35 +890,33 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
                 const int s = nth_free_slot(L, C, rank);
                 if (s < 0) continue;
                 const int k = L.dep[d];
-                const int v = T.trip_vtype[k];
+                const int v = T.trip_vtype()[k];
                 const float *vt = L.vtp + v * VT_COLS;
-                const RouteRec RR = T.routes[T.trip_route[k]];
+                const RouteRec RR = T.routes()[T.trip_route()[k]];
                 L.node[s].pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
                 L.node[s].trip = (uint16_t)k; L.node[s].nxt = NIL;
-                L.speed[s] = 0.0f; L.tloss[s] = 0.0f; L.swait[s] = 0; L.vt[s] = (uint8_t)v;
+                L.speed[s] = 0.0f; G.swait()[eo + s] = 0; L.vt[s] = (uint8_t)v;
                 L.lane[s] = RR.depart_lane; L.rq[s] = (uint16_t)RR.start;
-                L.coop[s] = COOP_NONE; L.cooplead[s] = COOP_NONE;
-                L.sf[s] = speed_factor(P, genv, k, vt);
-                L.nlink[s] = cache_link(T, T.lanes[RR.depart_lane], RR.depart_lane, (int)RR.start, k);
+                L.nlink[s] = cache_link(T, T.lanes()[RR.depart_lane], RR.depart_lane, (int)RR.start, k);
                 L.cell[s] = CELL_NEW;
-                G.sf()[eo + s] = L.sf[s];
+                G.sf()[eo + s] = speed_factor(P, genv, k, vt); G.tloss()[eo + s] = 0.0f; G.cooplead()[eo + s] = COOP_NONE; G.coop()[eo + s] = COOP_NONE;
                 G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
-                L.dep[d] = T.cold->trip_next[k];
+                L.dep[d] = T.cold.trip_next[k];
                 rs_atomic_max(&L.sc[SC_HW], s + 1);
                 rs_atomic_add(&L.sc[SC_STATS + ST_INSERTED], 1);
-                rs_atomic_add(&L.sc[SC_STATS + ST_DEPDELAY], t - T.cold->trip_depart[k]);
+                rs_atomic_add(&L.sc[SC_STATS + ST_DEPDELAY], t - T.cold.trip_depart[k]);
             }
         });
         const int hw3 = L.sc[SC_HW];
         const bool more = tick + 1 < n_ticks;
         if (L.sc[SC_REBUILD]) {
-            ex.phase([&](int tid) {
+            ex.phase(9, [&](int tid) {
                 for (int s = tid; s < hw3; s += B) { const int c = L.cell[s]; if (c < 0xFFF0) L.grid[c] = NIL; }
             });
         }
         const bool rebuild = L.sc[SC_REBUILD] != 0;
         // ---- A2: changers and new vehicles enter the grid; the next tick's approach registrations (P3)
-        ex.phase([&](int tid) {
+        ex.phase(10, [&](int tid) {
             for (int s = tid; s < hw3; s += B) {
                 const int ln = L.lane[s];
                 if (ln == (int)LANE_NONE) continue;
@@ -921,7 +927,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
                     rs_atomic_add(&L.sc[SC_NINS], 1);
                 }
                 if (rebuild || c0 >= 0xFFF0) {
-                    const LaneRec LRn = T.lanes[ln];
+                    const LaneRec LRn = T.lanes()[ln];
                     const int c = LRn.cell0 + cell_of(L.node[s].pos, lane_cells(LRn));
                     L.cell[s] = (uint16_t)c;
                     L.node[s].nxt = grid_push(L.grid, c, s, L.speed[s] > RM_HALT_SPEED);
@@ -932,10 +938,10 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
     }
 
     // ---- Signal.observe for every signal (traffic_signal.py:189-247)
-    ex.phase([&](int tid) {
+    ex.phase(11, [&](int tid) {
         for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
     });
-    ex.phase([&](int tid) {
+    ex.phase(12, [&](int tid) {
         const int hwf = L.sc[SC_HW], hw0 = G.env[env * 4 + 2];
         const int top = hwf > hw0 ? hwf : hw0;
         int hi = 0;
@@ -947,14 +953,13 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
             hi = s + 1;
             // store the slab back (once per env-step)
             const int rq = L.rq[s];
-            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.speed[s]; G.swait()[eo + s] = L.swait[s]; G.tloss()[eo + s] = L.tloss[s];
-            G.coop()[eo + s] = L.coop[s]; G.cooplead()[eo + s] = L.cooplead[s];
-            G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes[T.trip_route[L.node[s].trip]].start);
-            const LaneRec LR = T.lanes[lane];
-            const int oi = T.cold->lane_obs[lane];
+            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.speed[s];
+            G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes()[T.trip_route()[L.node[s].trip]].start);
+            const LaneRec LR = T.lanes()[lane];
+            const int oi = T.cold.lane_obs[lane];
             bool detect = false;
             if (oi >= 0) {
-                const float d = (LR.len - L.node[s].pos) + T.rsteps[rq].tlsdist;
+                const float d = (LR.len - L.node[s].pos) + T.rsteps()[rq].tlsdist;
                 detect = d <= P.max_distance;
             }
             if (!detect) {
@@ -962,7 +967,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
                 G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0;
                 continue;
             }
-            const int sig = T.cold->obs_sig[oi];
+            const int sig = T.cold.obs_sig[oi];
             int rw = G.rwait()[eo + s];
             if (prev_owner != sig) {
                 rw = 0;
@@ -970,7 +975,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
                 if (prev_owner != (int)OWNER_NONE) rs_atomic_add(&L.sig_dep[prev_owner], 1);
             }
             if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
-            else if (L.swait[s] > 0) rw = L.swait[s];
+            else { const int sw = G.swait()[eo + s]; if (sw > 0) rw = sw; }
             G.rwait()[eo + s] = (uint16_t)rw;
             G.owner()[eo + s] = (uint8_t)sig;
             if (rw > 0) { rs_atomic_add(&L.agg_q[oi], 1); rs_atomic_add(&L.agg_w[oi], rw); rs_atomic_max(&L.agg_m[oi], rw); }
@@ -980,13 +985,13 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         if (hi) rs_atomic_max(&L.sc[SC_HWNEW], hi);
     });
     // per observed lane rows, written as flat coalesced streams; states / rewards; state write-back
-    ex.phase([&](int tid) {
+    ex.phase(13, [&](int tid) {
         for (int i = tid; i < NO * 5; i += B) {
             const int oi = i / 5, c = i - oi * 5;
-            const int sg = T.cold->obs_sig[oi];
+            const int sg = T.cold.obs_sig[oi];
             const float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
             float raw, nrm;
-            if (c == 0) { raw = (float)L.agg_q[oi]; nrm = (oi - T.cold->sig_obs_start[sg]) == L.phase[sg] ? 1.0f : 0.0f; }
+            if (c == 0) { raw = (float)L.agg_q[oi]; nrm = (oi - T.cold.sig_obs_start[sg]) == L.phase[sg] ? 1.0f : 0.0f; }
             else if (c == 1) { raw = (float)L.agg_a[oi]; nrm = raw / 28.0f; }
             else if (c == 2) { raw = (float)L.agg_w[oi]; nrm = raw / 28.0f; }
             else if (c == 3) { raw = (float)L.agg_m[oi]; nrm = (float)L.agg_q[oi] / 28.0f; }
@@ -997,9 +1002,9 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         for (int i = tid; i < S * T.lmax * 5; i += B) {
             const int sg = i / (T.lmax * 5), r = i - sg * T.lmax * 5;
             const int l = r / 5, c = r - l * 5;
-            const int o0 = T.cold->sig_obs_start[sg];
+            const int o0 = T.cold.sig_obs_start[sg];
             float nrm = 0.0f;                                    // zero padding beyond the signal's lanes
-            if (l < T.cold->sig_obs_start[sg + 1] - o0) {
+            if (l < T.cold.sig_obs_start[sg + 1] - o0) {
                 const int oi = o0 + l;
                 if (c == 0) nrm = l == L.phase[sg] ? 1.0f : 0.0f;
                 else if (c == 1) nrm = (float)L.agg_a[oi] / 28.0f;
@@ -1014,12 +1019,12 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
             const int sg = i / 12, m = i - sg * 12;
             int q = 0, wv = 0, tw = 0, ap = 0;
             float last_speed = 0.0f;
-            for (int j = T.cold->mv_in_start[i]; j < T.cold->mv_in_start[i + 1]; ++j) {
-                const int oi = T.cold->mv_in_idx[j];
+            for (int j = T.cold.mv_in_start[i]; j < T.cold.mv_in_start[i + 1]; ++j) {
+                const int oi = T.cold.mv_in_idx[j];
                 q += L.agg_q[oi]; wv += L.agg_q[oi] + L.agg_a[oi]; tw += L.agg_w[oi]; ap += L.agg_a[oi];
                 last_speed = (float)L.agg_s[oi] * (1.0f / 65536.0f);       // states.py:97: total_speed restarts with every lane
             }
-            for (int j = T.cold->mv_out_start[i]; j < T.cold->mv_out_start[i + 1]; ++j) q -= L.agg_q[T.cold->mv_out_idx[j]];
+            for (int j = T.cold.mv_out_start[i]; j < T.cold.mv_out_start[i + 1]; ++j) q -= L.agg_q[T.cold.mv_out_idx[j]];
             const size_t so = (size_t)env * S + sg;
             O.mplight()[so * 13 + 1 + m] = q;
             O.wave()[so * 12 + m] = wv;
@@ -1029,7 +1034,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         // per signal: phase, rewards, metrics
         for (int sg = tid; sg < S; sg += B) {
             const int ph = L.phase[sg];
-            const int o0 = T.cold->sig_obs_start[sg], o1 = T.cold->sig_obs_start[sg + 1];
+            const int o0 = T.cold.sig_obs_start[sg], o1 = T.cold.sig_obs_start[sg + 1];
             int tw = 0, tq = 0, mq = 0;
             for (int oi = o0; oi < o1; ++oi) { tw += L.agg_w[oi]; const int qq = L.agg_q[oi]; tq += qq; if (qq > mq) mq = qq; }
             const size_t so = (size_t)env * S + sg;
@@ -1038,7 +1043,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
             const float wn = -(float)tw / 224.0f;
             O.wait_norm()[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
             int pr = tq;
-            for (int i = T.cold->pr_out_start[sg]; i < T.cold->pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.cold->pr_out_idx[i]];
+            for (int i = T.cold.pr_out_start[sg]; i < T.cold.pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.cold.pr_out_idx[i]];
             O.pressure()[so] = -pr;
             O.mplight()[so * 13] = ph;
             O.mplight_full()[so * 49] = (float)ph;
@@ -1049,7 +1054,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
         }
         for (int i = tid; i < T.n_dep; i += B) G.dep_next[(size_t)env * T.n_dep + i] = L.dep[i];
     });
-    ex.phase([&](int tid) {
+    ex.phase(14, [&](int tid) {
         if (tid == 0) {
             G.env[env * 4 + 0] = L.sc[SC_T]; G.env[env * 4 + 1] = L.sc[SC_NINS]; G.env[env * 4 + 3] = L.sc[SC_NACT];
             G.env[env * 4 + 2] = L.sc[SC_HWNEW];
@@ -1061,7 +1066,7 @@ RS_DEV void rs_step_body(Exec &ex, const KTab &T, const State &G, const Out &O, 
                 // trips whose insertion has been tried and failed so far: departed before the last tick, not on the network
                 const int t = L.sc[SC_T];
                 const int hz = t - 1 <= T.horizon ? t - 1 : T.horizon;
-                st[tid] = (t >= 1 ? T.cold->trips_cum[hz] : 0) - L.sc[SC_NINS];
+                st[tid] = (t >= 1 ? T.cold.trips_cum[hz] : 0) - L.sc[SC_NINS];
             } else st[tid] += L.sc[SC_STATS + tid];
         }
     });

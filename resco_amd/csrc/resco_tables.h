@@ -24,8 +24,10 @@ enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, 
 // The lanes are covered by a grid of CELL_LEN-metre cells (floor(len / CELL_LEN) + 1 per lane, lanes in index order):
 // a cell holds the slot of a vehicle whose front is inside it (more than one: a short chain).  Every neighbour search of
 // the model is a bounded scan over a few consecutive cells.
-#define CELL_LEN 8.0f
-#define CELL_INV 0.125f
+#ifndef CELL_LEN
+#define CELL_LEN 16.0f
+#endif
+#define CELL_INV (1.0f / CELL_LEN)
 
 // ---- 16-byte records: one global_load_dwordx4 fetches everything about a lane / foe / route
 struct __attribute__((aligned(16))) LaneRec {
@@ -83,20 +85,38 @@ struct KCold {
     const int32_t *trips_cum;
 };
 // tables of the per-vehicle, per-tick path: by value (SGPRs)
+// RS_G(p): "p points to global memory" -- the HIP build launders the pointer through the global address space so that
+// table accesses become global_load (a pointer LOADED from the constant argument block is otherwise generic and every
+// access a flat one, which also ties up the LDS wait counter); the host emulation defines it as the identity.
+#ifndef RS_G
+#define RS_G(p) (p)
+#endif
+#ifndef RS_MEM
+#define RS_MEM inline
+#endif
 struct KTab {
-    const LaneRec *lanes;
-    const LinkRec *links;
-    const FoeRec *foes;
-    const RStep *rsteps;
-    const float *route_cont;        // [n_route_steps][kmax]
-    const uint16_t *next_link;      // [n_route_steps][kmax][2]: choose_link() of a normal lane for even / odd trips, 0xFFFF: none
-    const RouteRec *routes;
-    const uint16_t *trip_route;
-    const uint8_t *trip_vtype;
-    const KCold *cold;
+    const LaneRec *lanes_;
+    const LinkRec *links_;
+    const FoeRec *foes_;
+    const RStep *rsteps_;
+    const float *route_cont_;       // [n_route_steps][kmax]
+    const uint16_t *next_link_;     // [n_route_steps][kmax][2]: choose_link() of a normal lane for even / odd trips, NLINK_NONE: none
+    const RouteRec *routes_;
+    const uint16_t *trip_route_;
+    const uint8_t *trip_vtype_;
+    KCold cold;                     // by value: every table pointer is then loaded from the constant argument block
     float maxlen;
     int32_t n_trips, tls_maxl, kmax;
     int32_t n_lanes, n_cells, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
+    RS_MEM const LaneRec *lanes() const { return RS_G(lanes_); }
+    RS_MEM const LinkRec *links() const { return RS_G(links_); }
+    RS_MEM const FoeRec *foes() const { return RS_G(foes_); }
+    RS_MEM const RStep *rsteps() const { return RS_G(rsteps_); }
+    RS_MEM const float *route_cont() const { return RS_G(route_cont_); }
+    RS_MEM const uint16_t *next_link() const { return RS_G(next_link_); }
+    RS_MEM const RouteRec *routes() const { return RS_G(routes_); }
+    RS_MEM const uint16_t *trip_route() const { return RS_G(trip_route_); }
+    RS_MEM const uint8_t *trip_vtype() const { return RS_G(trip_vtype_); }
 };
 
 struct KParams {

@@ -166,7 +166,19 @@ class MultiSignal(_EnvBase):
 
     # ------------------------------------------------------------------ gym API
     def step_sim(self):
-        raise NotImplementedError('single simulation ticks are fused into the step kernel')
+        """one sumo.simulationStep() (multi_signal.py:102-105); MultiSignal.step() fuses its ticks into one launch"""
+        self.sim.ticks(1)
+        self._version += 1
+
+    def reinit_signals(self):
+        """Fresh Signal objects on the RUNNING simulation (what reset() does after restarting SUMO,
+        multi_signal.py:141-147): returns the first observation, like reset()."""
+        self.sim.reinit_signals()
+        self._version += 1
+        for ts in self.signal_ids:
+            self.signals[ts].last_step_vehicles = None
+        states = self._evaluate(self.state_fn)
+        return [states[ts] for ts in self.ts_order] if self.gymma else states
 
     def reset(self):
         if self.run != 0:
@@ -177,6 +189,9 @@ class MultiSignal(_EnvBase):
         # the reference restarts SUMO with --random (multi_signal.py:127): a new seed per episode
         self.sim.set_seed((self._base_seed + 0x9E3779B1 * self.run) & 0xFFFFFFFF)
         self.sim.reset()
+        if self.warmup > 0:             # multi_signal.py:139-140: warm-up ticks before the Signal objects exist
+            self.sim.ticks(self.warmup)
+            self.sim.reinit_signals()
         self._version += 1
         self.signal_ids = [self.all_ts_ids[i] for i in range(self.ts_starter)]
         for ts in self.signal_ids:

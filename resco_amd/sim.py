@@ -11,7 +11,8 @@ import numpy as np
 from ._abi import ParamsStruct, pack_scenario
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libresco_sim.so')
+# RESCO_SIM_LIB: another build of the same HIP library (A/B variants compiled with different -D switches, tools/ab.py)
+LIB_PATH = os.environ.get('RESCO_SIM_LIB') or os.path.join(_HERE, 'csrc', 'libresco_sim.so')
 
 BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure', 'queue_sum',
            'queue_max', 'actions', 'env', 'tls', 'veh_pos', 'veh_speed', 'veh_accel', 'veh_tloss', 'veh_lane',
@@ -26,7 +27,7 @@ STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_wai
 TRIP_NONE = 0xFFFF
 
 # every symbol include/resco_sim.h declares
-ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_act_random',
+ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_reinit_signals', 'rs_ticks', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
                'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_phase_profile', 'rs_info',
                'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_destroy']
@@ -45,6 +46,8 @@ def bind(L):
     L.rs_reset.argtypes = [vp, vp]
     L.rs_step.argtypes = [vp, vp, i32, vp]
     L.rs_sync.argtypes = [vp]
+    L.rs_ticks.argtypes = [vp, i32, vp]
+    L.rs_reinit_signals.argtypes = [vp, vp]
     L.rs_act_random.argtypes = [vp, C.c_uint32, vp]
     L.rs_act_maxwave.argtypes = [vp, vp, i32, vp, vp, i32, vp]
     L.rs_get_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32)]
@@ -161,6 +164,14 @@ class BatchedSim:
         a = np.ascontiguousarray(actions, dtype=np.int32)
         assert a.shape == (self.n_envs, self.S), a.shape
         self._check(self._lib.rs_step(self._h, a.ctypes.data, 0, stream))
+
+    def ticks(self, n, stream=None):
+        """n x step_sim() without the signal FSM, then an observe (see rs_ticks)"""
+        self._check(self._lib.rs_ticks(self._h, int(n), stream))
+
+    def reinit_signals(self, stream=None):
+        """fresh Signal objects on the running simulation (see rs_reinit_signals)"""
+        self._check(self._lib.rs_reinit_signals(self._h, stream))
 
     def set_seed(self, seed):
         self._check(self._lib.rs_set_seed(self._h, int(seed) & 0xFFFFFFFF))

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 HOT_CASES = ['cologne1_d200', 'cologne8_d200', 'cologne8_d50', 'ingolstadt21_d200', 'cologne3_d200',
              'ingolstadt7_d200', 'ingolstadt1_d200']
+# the reference driven on a LOADED network (180 env-steps of pre-roll before its Signal objects are built) and through a
+# whole 360-step episode (tests/golden/make_golden.py)
+WARM_CASES = ['ingolstadt21_d200_warm180', 'cologne8_d200_warm180']
+FULL_CASES = ['cologne1_d50_full']
+ALL_CASES = HOT_CASES + WARM_CASES + FULL_CASES
 
 
 def pytest_configure(config):
@@ -37,6 +42,15 @@ def root():
 def load_scenario(name):
     from resco_amd.scenario import Scenario
     return Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
+
+
+def preroll_actions(sc, seed, env_index, k):
+    """the on-device random policy (rs_act_random): murmur(seed ^ 0xA5A5A5A5; env, signal, step, 7) % n_green"""
+    import numpy as np
+    from oracle.pyoracle import lib
+    L = lib()
+    return np.array([L.orc_hash((seed ^ 0xA5A5A5A5) & 0xFFFFFFFF, env_index, s, k, 7) % int(sc.tls_ngreen[s])
+                     for s in range(sc.n_signals)], np.int32)
 
 
 def load_golden(tag):

@@ -22,9 +22,15 @@ from resco_amd.scenario import Scenario                          # noqa: E402
 from resco_amd.config.map_config import map_configs              # noqa: E402
 
 BASE_SEED = 7
-CASES = [  # (map, steps, max_distance)
-    ('cologne1', 48, 200), ('cologne8', 40, 200), ('cologne8', 24, 50), ('ingolstadt21', 30, 200),
-    ('cologne3', 36, 200), ('ingolstadt7', 30, 200), ('ingolstadt1', 40, 200),
+CASES = [  # (map, steps, max_distance, pre-roll steps)
+    ('cologne1', 48, 200, 0), ('cologne8', 40, 200, 0), ('cologne8', 24, 50, 0), ('ingolstadt21', 30, 200, 0),
+    ('cologne3', 36, 200, 0), ('ingolstadt7', 30, 200, 0), ('ingolstadt1', 40, 200, 0),
+    # a whole episode through the reference's wrapper: `done`, the final CSV
+    ('cologne1', 360, 50, 0),
+    # loaded networks: the simulation is rolled forward `pre-roll` env-steps under the hashed random policy, THEN the
+    # reference's MultiSignal.reset() builds its Signal objects on it and is driven for `steps` (long waiting_times,
+    # departures under congestion, the purge of traffic_signal.py:230-232)
+    ('ingolstadt21', 30, 200, 180), ('cologne8', 30, 200, 180),
 ]
 STATE_FNS = ['drq', 'drq_norm', 'mplight', 'mplight_full', 'wave']
 REWARD_FNS = ['wait', 'wait_norm', 'pressure']
@@ -34,7 +40,14 @@ def episode_seed(run):
     return (BASE_SEED + 0x9E3779B1 * run) & 0xFFFFFFFF
 
 
-def run_case(map_name, steps, max_distance):
+def preroll_actions(sc, seed, k):
+    """the on-device random policy (rs_act_random) for environment 0: murmur(seed ^ 0xA5A5A5A5; env, signal, step, 7) % n_green"""
+    from oracle.pyoracle import lib
+    L = lib()
+    return np.array([L.orc_hash((seed ^ 0xA5A5A5A5) & 0xFFFFFFFF, 0, s, k, 7) % int(sc.tls_ngreen[s]) for s in range(sc.n_signals)], np.int32)
+
+
+def run_case(map_name, steps, max_distance, preroll=0):
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', map_name + '.npz'))
     mc = map_configs[map_name]
     state = {'n': 0}
@@ -43,9 +56,20 @@ def run_case(map_name, steps, max_distance):
         # every traci.start is a fresh SUMO: the probe run of __init__ is start #0, episode k is start #k
         orc = OracleEnv(sc, env_index=0, seed=episode_seed(state['n']), max_distance=max_distance, sigma=-1.0,
                         speed_dev=1)
+        fresh = state['n'] == 0 or preroll == 0
         state['n'] += 1
         state['orc'] = orc
-        return ref_harness.FakeSumo(sc, orc)
+        fake = ref_harness.FakeSumo(sc, orc)
+        if not fresh:
+            # the episode's SUMO has been running for a while when the reference builds its Signal objects on it
+            orc.observe()
+            for k in range(preroll):
+                orc.step(preroll_actions(sc, episode_seed(1), k))
+            orc.reinit_signals()
+            for sid in sc.signal_ids:      # the re-installed program is already the controlled one
+                fake.installed[sid] = ref_harness._Logic([ref_harness._Phase(d, st) for d, st in sc.signal_meta[sid]['phases']],
+                                                         orc.get_phase(fake.sig_index[sid]))
+        return fake
 
     ref_harness.install_stubs(factory)
     ref = ref_harness.import_reference()
@@ -139,8 +163,8 @@ def run_case(map_name, steps, max_distance):
     with open(os.path.join(tmp, env.connection_name, 'metrics_1.csv')) as f:
         csv_text = f.read()
 
-    tag = '%s_d%d' % (map_name, max_distance)
-    meta = dict(map=map_name, steps=steps, max_distance=max_distance, base_seed=BASE_SEED, seed=episode_seed(1),
+    tag = '%s_d%d' % (map_name, max_distance) + ('_full' if steps >= 360 else '') + ('_warm%d' % preroll if preroll else '')
+    meta = dict(map=map_name, steps=steps, max_distance=max_distance, preroll=preroll, base_seed=BASE_SEED, seed=episode_seed(1),
                 all_ts_ids=ids, ts_order=list(env.ts_order), obs_shape={ts: list(env.obs_shape[ts]) for ts in ids},
                 n_green=n_green, connection_name=env.connection_name, metrics_csv=csv_text,
                 oracle_stats=orc_stats, signals={}, fma2c_keys=fma_keys, fma2c_shapes=fma_shapes)

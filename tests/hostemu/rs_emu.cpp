@@ -63,7 +63,7 @@ struct HostExec {
     int B;
     int order;          // 0 ascending, 1 descending, 2 shuffled (a different permutation in every phase)
     uint32_t rng = 12345u;
-    template <class F> void phase(F f) {
+    template <class F> void phase(int, F f) {
         if (order == 0) for (int t = 0; t < B; ++t) f(t);
         else if (order == 1) for (int t = B - 1; t >= 0; --t) f(t);
         else {
@@ -78,10 +78,10 @@ struct HostExec {
 struct rs_sim {
     PackedTables PT;
     KTab K{};
-    KCold cold{};
     State G{};
     Out O{};
     KParams P{};
+    Lds L{};
     int n_envs = 0, block = 0, order = 0;
     size_t lds = 0;
     std::vector<char> slab, outb, smem;
@@ -118,10 +118,10 @@ static void run_step(rs_sim *h, int n_ticks, int do_fsm) {
         HostExec ex{h->block, h->order};
         ex.rng = 777u + (uint32_t)env;
         switch (h->K.capacity) {
-            case 128: rs_step_body<128>(ex, h->K, h->G, h->O, P, h->actions.data(), env); break;
-            case 256: rs_step_body<256>(ex, h->K, h->G, h->O, P, h->actions.data(), env); break;
-            case 1024: rs_step_body<1024>(ex, h->K, h->G, h->O, P, h->actions.data(), env); break;
-            default: rs_step_body<0>(ex, h->K, h->G, h->O, P, h->actions.data(), env); break;
+            case 128: rs_step_body<128>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
+            case 256: rs_step_body<256>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
+            case 1024: rs_step_body<1024>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
+            default: rs_step_body<0>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
         }
     }
 }
@@ -138,10 +138,10 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->n_envs = n_envs;
     h->route_cont.assign(sc->route_cont, sc->route_cont + (size_t)sc->n_route_steps * sc->kmax);
     h->vtype_params.assign(sc->vtype_params, sc->vtype_params + (size_t)sc->n_vtypes * VT_COLS);
-    KTab &K = h->K; KCold &c = h->cold;
-    K.lanes = PT.lanes.data(); K.links = PT.links.data(); K.foes = PT.foes.data(); K.rsteps = PT.rsteps.data();
-    K.route_cont = h->route_cont.data(); K.next_link = PT.next_link.data(); K.routes = PT.routes.data();
-    K.trip_route = PT.trip_route.data(); K.trip_vtype = PT.trip_vtype.data(); K.cold = &h->cold;
+    KTab &K = h->K; KCold &c = K.cold;
+    K.lanes_ = PT.lanes.data(); K.links_ = PT.links.data(); K.foes_ = PT.foes.data(); K.rsteps_ = PT.rsteps.data();
+    K.route_cont_ = h->route_cont.data(); K.next_link_ = PT.next_link.data(); K.routes_ = PT.routes.data();
+    K.trip_route_ = PT.trip_route.data(); K.trip_vtype_ = PT.trip_vtype.data();
     c.trip_depart = keep_i32(h, sc->trip_depart, sc->n_trips); c.trip_next = PT.trip_next.data(); c.dep_lane = PT.dep_lane.data(); c.dep_first = PT.dep_first.data();
     c.vtype_params = h->vtype_params.data(); c.tls8 = PT.tls8.data(); c.fix8 = PT.fix8.data();
     c.tls_nphase = keep_i32(h, sc->tls_nphase, sc->n_signals); c.tls_ngreen = keep_i32(h, sc->tls_ngreen, sc->n_signals);
@@ -172,7 +172,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->G.env = h->env.data(); h->G.tls = h->tls.data(); h->G.stats = h->stats.data(); h->G.dep_next = h->dep_next.data();
     h->G.trip_log = nullptr;
     if (p->trip_log) { h->trip_log.assign(N * (size_t)sc->n_trips * 4, 0); h->G.trip_log = h->trip_log.data(); }
-    h->lds = lds_carve(nullptr, C, K.n_cells, K.n_arr, K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, K.tls_maxl);
+    h->lds = lds_carve(&h->L, C, K.n_cells, K.n_arr, K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, K.tls_maxl);
     h->smem.assign(h->lds + 64, 0);
     State &G = h->G; Out &O = h->O;
     const int64_t n = n_envs, cc = C, s = sc->n_signals, o = sc->n_obs, lmax = PT.lmax;
@@ -214,11 +214,11 @@ int rs_reset(rs_handle h, void *) {
         }
         for (int s = 0; s < S; ++s) {
             int ph, left;
-            if (h->P.fixed_program) { ph = T.cold->fix_init_phase[s]; left = T.cold->fix_init_left[s]; }
-            else { ph = T.cold->tls_init_phase[s]; left = T.cold->tls_dur[T.cold->tls_dur_off[s] + ph]; }
+            if (h->P.fixed_program) { ph = T.cold.fix_init_phase[s]; left = T.cold.fix_init_left[s]; }
+            else { ph = T.cold.tls_init_phase[s]; left = T.cold.tls_dur[T.cold.tls_dur_off[s] + ph]; }
             G.tls[(env * S + s) * 3 + 0] = ph; G.tls[(env * S + s) * 3 + 1] = left; G.tls[(env * S + s) * 3 + 2] = 0;
         }
-        for (int d = 0; d < T.n_dep; ++d) G.dep_next[(size_t)env * T.n_dep + d] = T.cold->dep_first[d];
+        for (int d = 0; d < T.n_dep; ++d) G.dep_next[(size_t)env * T.n_dep + d] = T.cold.dep_first[d];
         for (int i = 0; i < 4; ++i) G.env[env * 4 + i] = 0;
         for (int i = 0; i < ST_N; ++i) G.stats[(size_t)env * ST_N + i] = 0;
         if (G.trip_log) for (int i = 0; i < T.n_trips * 4; ++i) G.trip_log[(size_t)env * T.n_trips * 4 + i] = 0;
@@ -231,13 +231,28 @@ int rs_step(rs_handle h, const int32_t *actions, int32_t, void *) {
     run_step(h, h->K.step_length, 1);
     return RS_OK;
 }
+int rs_ticks(rs_handle h, int32_t n, void *) { run_step(h, n, 0); return RS_OK; }
 int rs_sync(rs_handle) { return RS_OK; }
+int rs_reinit_signals(rs_handle h, void *) {
+    const KTab &T = h->K; const State &G = h->G;
+    const int C = T.capacity, S = T.n_signals;
+    for (int env = 0; env < h->n_envs; ++env) {
+        const size_t eo = (size_t)env * C;
+        for (int s = 0; s < C; ++s) { G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0; }
+        for (int s = 0; s < S; ++s) {
+            if (!h->P.fixed_program) G.tls[(env * S + s) * 3 + 1] = T.cold.tls_dur[T.cold.tls_dur_off[s] + G.tls[(env * S + s) * 3 + 0]];
+            G.tls[(env * S + s) * 3 + 2] = 0;
+        }
+    }
+    run_step(h, 0, 0);
+    return RS_OK;
+}
 int rs_act_random(rs_handle h, uint32_t step_key, void *) {
     const int S = h->K.n_signals;
     for (int i = 0; i < h->n_envs * S; ++i) {
         const int env = i / S, s = i - env * S;
         const uint32_t hh = d_hash(h->P.seed ^ 0xA5A5A5A5u, (uint32_t)(h->P.env_base + env), (uint32_t)s, step_key, 7u);
-        h->actions[i] = (int32_t)(hh % (uint32_t)h->cold.tls_ngreen[s]);
+        h->actions[i] = (int32_t)(hh % (uint32_t)h->K.cold.tls_ngreen[s]);
     }
     return RS_OK;
 }

@@ -8,21 +8,21 @@ import pytest
 
 import sys
 
-from conftest import HOT_CASES, ROOT, load_golden, load_scenario
+from conftest import ALL_CASES, HOT_CASES, ROOT, load_golden, load_scenario, preroll_actions
 
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 pytestmark = pytest.mark.gpu
 
-INT_BUFS = ['phase', 'mplight', 'wave', 'pressure', 'queue_sum', 'queue_max']
-FLT_BUFS = ['lane_agg', 'drq_norm', 'wait', 'wait_norm']
+INT_BUFS = ['phase', 'mplight', 'wave', 'pressure', 'queue_sum', 'queue_max', 'arrivals', 'departures']
+FLT_BUFS = ['lane_agg', 'drq_norm', 'wait', 'wait_norm', 'mplight_full']
 VEH = [('veh_lane', 'lane'), ('veh_trip', 'trip'), ('veh_pos', 'pos'), ('veh_speed', 'speed'),
        ('veh_cursor', 'cursor'), ('veh_swait', 'sumo_wait'), ('veh_tloss', 'time_loss'), ('veh_rwait', 'resco_wait'),
        ('veh_owner', 'owner'), ('veh_depart', 'depart'), ('veh_accel', 'accel')]
 
 
 def assert_env_equal(sim, orcs, step):
-    out = sim.outputs()
+    out = sim.outputs(INT_BUFS + FLT_BUFS)
     vg = {g: sim.read(g) for g, _ in VEH}
     env = sim.read('env')
     for e, o in enumerate(orcs):
@@ -30,10 +30,10 @@ def assert_env_equal(sim, orcs, step):
         for b in INT_BUFS + FLT_BUFS:      # floats too: both sides are IEEE fp32 without contraction
             np.testing.assert_array_equal(out[b][e], ref[b], err_msg='%s env %d step %d' % (b, e, step))
         vo = o.vehicles()
-        assert env[e, 2] == vo['hw'] and env[e, 1] == vo['next_trip'] and env[e, 0] == o.time
+        assert env[e, 2] == vo['hw'] and env[e, 1] == vo['next_trip'] and env[e, 0] == o.time and env[e, 3] == o.stats()['active']
         hw = vo['hw']
         free = vo['lane'][:hw] == 0xFFFF
-        active = vo['lane'][:hw] < 0xFFFE
+        active = ~free
         for g, r in VEH:
             a, b_ = vg[g][e][:hw], vo[r][:hw]
             if r == 'trip':
@@ -54,7 +54,7 @@ def assert_env_equal(sim, orcs, step):
     ('cologne3', 2, 40, -1.0, 1, 0),         # <vehicle><route> demand, explicit routes
     ('ingolstadt1', 2, 40, -1.0, 1, 1),
     ('ingolstadt7', 2, 40, -1.0, 1, 0),
-    ('ingolstadt7', 2, 260, -1.0, 1, 1),     # long enough for mutual lane blocks to form and be swapped out
+    ('ingolstadt7', 2, 260, -1.0, 1, 1),     # long enough for lane-change blocks and cooperation requests
 ])
 def test_gpu_equals_oracle_bit_exact(name, n_envs, steps, sigma, speed_dev, fixed):
     from oracle.pyoracle import OracleEnv
@@ -114,7 +114,7 @@ def test_full_episode_bit_exact_ingolstadt21():
     sim.close()
 
 
-@pytest.mark.parametrize('tag', HOT_CASES)
+@pytest.mark.parametrize('tag', ALL_CASES)
 @pytest.mark.parametrize('fast', [True, False])
 def test_multisignal_matches_reference_python(tag, fast):
     """The reference's MultiSignal/Signal/states/rewards (golden) vs resco_amd.MultiSignal on the HIP path."""
@@ -136,6 +136,13 @@ def test_multisignal_matches_reference_python(tag, fast):
         assert env.signals[t].lanes == meta['signals'][t]['lanes']
         assert env.signals[t].yellow_dict == meta['signals'][t]['yellow_dict']
     obs = env.reset()
+    if meta.get('preroll'):
+        # loaded network: roll the simulation forward under the on-device random policy, then build fresh Signal objects on
+        # it -- exactly what the fixture's generator did before the reference's MultiSignal took over
+        for k in range(meta['preroll']):
+            env.sim.act_random(k)
+            env.sim.step(None)
+        obs = env.reinit_signals()
     assert list(obs.keys()) == ids
 
     def check(k):
@@ -171,7 +178,7 @@ def test_multisignal_matches_reference_python(tag, fast):
     env.close()
 
 
-@pytest.mark.parametrize('tag', HOT_CASES)
+@pytest.mark.parametrize('tag', HOT_CASES + ['cologne1_d50_full'])
 def test_device_agents_match_reference(tag):
     """rs_act_maxwave (MAXPRESSURE / MAXWAVE on device) vs the reference agents' actions (golden)."""
     from resco_amd.sim import BatchedSim
@@ -247,7 +254,7 @@ def test_trip_log_and_tripinfo_output():
     for e, o in enumerate(orcs):
         np.testing.assert_array_equal(log[e], o.trip_log())
         v = o.vehicles()
-        act = v['lane'][:v['hw']] < 0xFFFE
+        act = v['lane'][:v['hw']] != 0xFFFF
         np.testing.assert_array_equal(wt[e][:v['hw']][act], o.wtot()[:v['hw']][act])
     assert (log[:, :, 1] > 0).sum() == sim.stats()['arrived'].sum()
     sim.close()
@@ -258,8 +265,8 @@ def test_trip_log_and_tripinfo_output():
     for k in range(80):
         env.step({env.all_ts_ids[0]: k % 4})
     ts = env.trip_stats()
-    lane, trip = env.sim.read('veh_lane')[0], env.sim.read('veh_trip')[0]
-    queued, now, delay = trip[lane == 0xFFFE].astype(np.int64), int(env.sim.read('env')[0, 0]), env.sim.trip_delay()[0]
+    (n_queued,), (waited,) = env.sim.backlog()
+    delay = env.sim.trip_delay()[0]
     env.reset()                                   # closes episode 1: writes metrics_1.csv and tripinfo_1.xml
     root = ET.parse(os.path.join(tmp, env.connection_name, 'tripinfo_1.xml')).getroot()
     trips = list(root)
@@ -271,9 +278,8 @@ def test_trip_log_and_tripinfo_output():
     assert all(float(t.get('depart')) >= 25200 for t in trips)
     # BatchedSim.trip_delay() is utils/readXML.py's episode figure: (timeLoss + departDelay) per tripinfo entry,
     # plus the trips still queued for insertion, which the reference charges from their scheduled departure
-    total = sum(float(t.get('timeLoss')) + float(t.get('departDelay')) for t in trips) \
-        + float(np.maximum(0, now - np.asarray(env.scenario.arrays['trip_depart'])[queued]).sum())
-    assert abs(delay - total / (len(trips) + len(queued))) < 0.02
+    total = sum(float(t.get('timeLoss')) + float(t.get('departDelay')) for t in trips) + float(waited)
+    assert abs(delay - total / (len(trips) + int(n_queued))) < 0.02
     env.close()
 
 
@@ -328,7 +334,7 @@ def test_gymma_list_api_and_custom_state_fn():
 
 
 def test_sampled_envs_bit_exact_at_full_occupancy():
-    """BASELINE config 3 launch shape (4096 workgroups, 4 resident per CU): eight sampled environments stay
+    """BASELINE config 3 launch shape (4096 workgroups, several resident per CU): eight sampled environments stay
     bit-identical to the CPU oracle for 40 env-steps of the on-device random policy.  Few-environment parity runs
     leave most of the chip idle and do not exercise the timing that exposes intra-workgroup races."""
     from oracle.pyoracle import OracleEnv
@@ -385,11 +391,12 @@ def test_full_episode_invariants_at_baseline_size():
             env = sim.read('env')
             assert (env[:, 0] == 10 * (k + 1)).all()
             assert (st['inserted'] == st['arrived'] + st['active']).all()
-            assert (env[:, 1] == st['inserted'] + st['pending']).all() and (env[:, 1] <= sc.n_trips).all()
+            assert (env[:, 1] == st['inserted']).all() and (env[:, 3] == st['active']).all() and (env[:, 1] <= sc.n_trips).all()
+            assert (st['pending'] >= 0).all() and (st['inserted'] + st['pending'] <= sc.n_trips).all()
             assert (st['arrived'] >= prev_arrived).all()
             prev_arrived = st['arrived'].copy()
             lane, pos, spd = sim.read('veh_lane'), sim.read('veh_pos'), sim.read('veh_speed')
-            act = lane < 0xFFFE
+            act = lane != 0xFFFF
             assert (act.sum(axis=1) == st['active']).all() and (st['active'] <= sc.capacity).all()
             assert (pos[act] >= 0).all() and (pos[act] <= sc.lane_len[lane[act]] + 1e-3).all()
             assert (spd[act] >= 0).all() and (spd[act] <= 60.0).all()
@@ -419,12 +426,12 @@ def test_properties_at_baseline_size():
     env = sim.read('env')
     assert (env[:, 0] == 120).all()
     assert (st['inserted'] == st['arrived'] + st['active']).all()          # vehicle conservation per env
-    assert (env[:, 1] == st['inserted'] + st['pending']).all()
+    assert (env[:, 1] == st['inserted']).all()
     lane = sim.read('veh_lane')
-    assert ((lane < 0xFFFE).sum(axis=1) == st['active']).all()
+    assert ((lane != 0xFFFF).sum(axis=1) == st['active']).all()
     assert len(np.unique(st['active'])) > 8                                  # environments decorrelate
     pos, spd = sim.read('veh_pos'), sim.read('veh_speed')
-    act = lane < 0xFFFE
+    act = lane != 0xFFFF
     assert (pos[act] <= sc.lane_len[lane[act]] + 1e-3).all() and (spd[act] >= 0).all()
     agg = sim.read('lane_agg')
     q = agg[:, :, 0]
@@ -746,3 +753,191 @@ def test_fused_policy_sampling_mode_follows_the_softmax():
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and not torch.equal(w0, net.fc2_w.detach()) and learner.n_updates == 2 * 2
     env.close()
+
+
+# ------------------------------------------------------------------------------------------------ model fidelity band
+# Published delay medians of the reference (resco_benchmark/utils/avg_timeLoss.py:49-51,60-62,83-85 and the rows of the
+# other maps): average trip delay (timeLoss + departDelay, utils/readXML.py) of the static controllers under SUMO.
+# The dynamics here are this build's own model (PARITY-UNPINNED vs SUMO), calibrated against these
+# figures: the band keeps a model change from silently moving them.
+REF_DELAY = {
+    ('cologne1', 'FIXED'): 56.85, ('cologne1', 'MAXWAVE'): 27.94, ('cologne1', 'MAXPRESSURE'): 31.09,
+    ('cologne3', 'FIXED'): 39.04, ('cologne3', 'MAXWAVE'): 21.95, ('cologne3', 'MAXPRESSURE'): 28.05,
+    ('cologne8', 'FIXED'): 64.21, ('cologne8', 'MAXWAVE'): 21.85, ('cologne8', 'MAXPRESSURE'): 29.71,
+    ('ingolstadt1', 'FIXED'): 39.47, ('ingolstadt1', 'MAXWAVE'): 27.99, ('ingolstadt1', 'MAXPRESSURE'): 23.61,
+    ('ingolstadt7', 'FIXED'): 91.45, ('ingolstadt7', 'MAXWAVE'): 80.31, ('ingolstadt7', 'MAXPRESSURE'): 46.41,
+    ('ingolstadt21', 'FIXED'): 130.37, ('ingolstadt21', 'MAXWAVE'): 69.61, ('ingolstadt21', 'MAXPRESSURE'): 115.61,
+}
+BAND = 0.35
+# Known exceptions, with the evidence (DESIGN.md section 2 has the traces):
+#  * ingolstadt21 FIXED: two approaches of TLS 243641585 are over-saturated under the net's own programme (486 veh/h on one
+#    lane with 20 s of green per 86 s, 515 + part of 310 veh/h with 26 s); the queues spill back through the neighbouring
+#    junctions further than SUMO's do.  Measured ~2.0-2.5 x the published median; the test keeps it below 3 x.
+#  * ingolstadt21 MAXWAVE / MAXPRESSURE: the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2} maps the pressure of
+#    the S approach (movements S-S + S-E, 841 veh/h) to green phase 0 = 'rGgG', in which that approach is red (phase
+#    order = the tlLogic's file order, exactly as multi_signal.py:52-59 extracts it): the greedy policies starve it for
+#    the whole episode.  Not a dynamics question; excluded.
+#  * cologne3 / cologne8 MAXPRESSURE and cologne3 MAXWAVE are bimodal in the reference itself (published means 162 / 48 /
+#    91 s against medians 28 / 30 / 22 s: some of its episodes gridlock); the median over the environments is compared.
+EXCEPT = {('ingolstadt21', 'FIXED'): (1.0, 3.0), ('ingolstadt21', 'MAXWAVE'): None, ('ingolstadt21', 'MAXPRESSURE'): None}
+
+
+@pytest.mark.parametrize('name', ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'])
+def test_delay_band(name):
+    """64 environments x one whole episode of FIXED / MAXWAVE / MAXPRESSURE on the device: the median average trip delay
+    stays within +-35 % of the reference's published median (known exceptions above)."""
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario(name)
+    for policy in ('FIXED', 'MAXWAVE', 'MAXPRESSURE'):
+        band = EXCEPT.get((name, policy), (1.0 - BAND, 1.0 + BAND))
+        if band is None:
+            continue
+        md = {'FIXED': 200, 'MAXWAVE': 50, 'MAXPRESSURE': 200}[policy]
+        sim = BatchedSim(sc, 64, seed=0, max_distance=md, fixed_program=1 if policy == 'FIXED' else 0)
+        for k in range(360):
+            if policy != 'FIXED':
+                sim.act_maxwave(1 if policy == 'MAXPRESSURE' else 0)
+            sim.step(None)
+        delay = float(np.median(sim.trip_delay()))
+        ratio = delay / REF_DELAY[(name, policy)]
+        sim.close()
+        assert band[0] <= ratio <= band[1], '%s %s: delay %.1f s = %.2f x the published %.1f s' % (name, policy, delay, ratio, REF_DELAY[(name, policy)])
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs 4 and 5
+def _episode_invariants(sim, sc, k):
+    st = sim.stats()
+    env = sim.read('env')
+    assert (env[:, 0] == 10 * (k + 1)).all()
+    assert (st['inserted'] == st['arrived'] + st['active']).all() and (env[:, 1] == st['inserted']).all()
+    lane, pos, spd = sim.read('veh_lane'), sim.read('veh_pos'), sim.read('veh_speed')
+    act = lane != 0xFFFF
+    assert (act.sum(axis=1) == st['active']).all() and (st['active'] <= sc.capacity).all()
+    assert (pos[act] >= 0).all() and (pos[act] <= sc.lane_len[lane[act]] + 1e-3).all()
+    assert (spd[act] >= 0).all() and (spd[act] <= 60.0).all()
+    return st
+
+
+def _oracle_replay(sc, seed, env_index, actions, max_distance=200.0):
+    from oracle.pyoracle import OracleEnv
+    o = OracleEnv(sc, env_index=env_index, seed=seed, sigma=-1.0, speed_dev=1, max_distance=max_distance)
+    o.observe()
+    for a in actions:
+        o.step(a)
+    return o
+
+
+def test_config4_cologne8_per_gpu_share_full_episode():
+    """BASELINE config 4 at its per-GPU size: cologne8 x 2048 environments x 360 env-steps with MaxPressure ON THE DEVICE
+    (rs_act_maxwave): invariants for every environment, and two sampled environments replayed on the oracle with the
+    recorded actions -- bit-identical at the end of the episode."""
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('cologne8')
+    N, seed, picks = 2048, 4, [0, 2047]
+    sim = BatchedSim(sc, N, seed=seed)
+    rec = []
+    for k in range(360):
+        sim.act_maxwave(1)
+        sim.sync()
+        rec.append(sim.read('actions')[picks].copy())
+        sim.step(None)
+        if k in (179, 359):
+            st = _episode_invariants(sim, sc, k)
+    # (MaxPressure gridlocks cologne8 in a few environments -- the reference's own published episodes are bimodal too)
+    assert (st['ticks'] == 3600).all() and np.median(st['arrived']) > 1900 and st['arrived'].min() > 300
+    out = {b: sim.read(b) for b in ('lane_agg', 'mplight', 'pressure', 'veh_pos', 'veh_lane')}
+    for j, e in enumerate(picks):
+        o = _oracle_replay(sc, seed, e, [r[j] for r in rec])
+        ref, v = o.outputs(), o.vehicles()
+        for b in ('lane_agg', 'mplight', 'pressure'):
+            np.testing.assert_array_equal(out[b][e], ref[b])
+        np.testing.assert_array_equal(out['veh_lane'][e], v['lane'])
+        live = v['lane'] != 0xFFFF
+        np.testing.assert_array_equal(out['veh_pos'][e][live], v['pos'][live])
+    sim.close()
+
+
+def test_config5_ingolstadt21_idqn_rollout_full_episode():
+    """BASELINE config 5 at its per-GPU size: ingolstadt21 x 1024 environments x 360 env-steps with the fused IDQN policy
+    (rs_idqn_act, epsilon-greedy on the fp16 observation tensor) in the loop: invariants, the fp16 tensor against the
+    ORACLE's drq_norm for sampled environments (replayed with the recorded actions), rewards equal to the oracle's."""
+    import torch
+    from resco_amd.agents.idqn_fused import FusedIDQN
+    from resco_amd.agents.idqn_rollout import BatchedIDQN
+    from resco_amd.sim import BatchedSim, torch_stream
+    sc = load_scenario('ingolstadt21')
+    N, seed, picks = 1024, 6, [0, 511, 1023]
+    sim = BatchedSim(sc, N, seed=seed)
+    net = BatchedIDQN.from_scenario(sc, dtype=torch.float32, device='cuda')
+    net.init_like_reference(seed=5)
+    pol = FusedIDQN(net, seed=1)
+    obs = sim.tensor('drq_norm_f16')
+    actions = sim.tensor('actions')
+    rec = []
+    for k in range(360):
+        pol.act(obs, epsilon=0.3, step_key=k, out=actions)
+        torch.cuda.synchronize()
+        rec.append(actions[picks].cpu().numpy().copy())
+        sim.step(None, stream=torch_stream())
+        if k in (179, 359):
+            torch.cuda.synchronize()
+            st = _episode_invariants(sim, sc, k)
+    assert (st['ticks'] == 3600).all() and st['arrived'].min() > 1000
+    h = sim.read('drq_norm_f16').astype(np.float32)
+    wn = sim.read('wait_norm')
+    lmax = h.shape[2]
+    for j, e in enumerate(picks):
+        o = _oracle_replay(sc, seed, e, [r[j] for r in rec])
+        ref = o.outputs()
+        np.testing.assert_array_equal(wn[e], ref['wait_norm'])
+        for s_ in range(sc.n_signals):
+            o0, o1 = int(sc.sig_obs_start[s_]), int(sc.sig_obs_start[s_ + 1])
+            want = ref['drq_norm'][o0:o1].astype(np.float16).astype(np.float32)        # the kernel rounds fp32 -> fp16
+            np.testing.assert_array_equal(h[e, s_, :o1 - o0], want)
+            assert (h[e, s_, o1 - o0:lmax] == 0).all()
+    sim.close()
+
+
+def test_bench_runs_through_rccl_at_one_gpu():
+    """bench.py with RESCO_BENCH_FORCE_DIST=1: the N > 1 code path (process group on RCCL, barrier, MAX all-reduce) on one GPU"""
+    import json
+    import subprocess
+    env = dict(os.environ, RESCO_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--envs', '256',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0]          # one JSON line, and it is the last one
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['steps'] == 6 and line['value'] > 0 and line['roofline']['frac'] > 0
+    assert line['config']['episode_window'][1] - line['config']['episode_window'][0] == 6
+
+
+def test_arrival_departure_counters_and_mplight_full_batched():
+    """the batched outputs behind fma2c / mplight_full (RS_BUF_ARRIVALS / DEPARTURES / MPLIGHT_FULL) for N environments:
+    equal to the oracle's for sampled environments, and consistent with the Signal views of environment 0"""
+    from oracle.pyoracle import OracleEnv
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('cologne8')
+    N, seed = 96, 13
+    sim = BatchedSim(sc, N, seed=seed)
+    orcs = {e: OracleEnv(sc, env_index=e, seed=seed, sigma=-1.0, speed_dev=1) for e in (0, 95)}
+    for o in orcs.values():
+        o.observe()
+    for k in range(90):
+        sim.act_random(k)
+        sim.sync()
+        a = sim.read('actions')
+        sim.step(None)
+        for e, o in orcs.items():
+            o.step(a[e])
+        if k % 15 == 14:
+            arr, dep, mf = sim.read('arrivals'), sim.read('departures'), sim.read('mplight_full')
+            for e, o in orcs.items():
+                ref = o.outputs()
+                np.testing.assert_array_equal(arr[e], ref['arrivals'])
+                np.testing.assert_array_equal(dep[e], ref['departures'])
+                np.testing.assert_array_equal(mf[e], ref['mplight_full'])
+    assert sim.read('arrivals').sum() > 0 and sim.read('departures').sum() > 0
+    sim.close()

@@ -1,0 +1,135 @@
+"""CPU: the step KERNEL's source (resco_amd/csrc/resco_step.h), compiled for the host and executed thread by thread
+(tests/hostemu), against the oracle -- bit for bit, in ascending, descending and shuffled thread order.
+
+This pins the kernel's logic, and its independence of the order in which the threads of a workgroup run inside a
+phase, without a GPU.  The -m gpu tests pin the real thing (the same source compiled by hipcc) against the same oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_scenario, preroll_actions
+from oracle.pyoracle import OracleEnv
+from hostemu.emu import EmuSim
+
+OUT = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure', 'queue_sum', 'queue_max',
+       'arrivals', 'departures', 'mplight_full']
+VEH = [('veh_lane', 'lane'), ('veh_pos', 'pos'), ('veh_speed', 'speed'), ('veh_cursor', 'cursor'), ('veh_swait', 'sumo_wait'),
+       ('veh_tloss', 'time_loss'), ('veh_rwait', 'resco_wait'), ('veh_owner', 'owner'), ('veh_depart', 'depart'), ('veh_accel', 'accel')]
+
+
+def assert_equal(sim, orcs, step):
+    out = sim.outputs(OUT)
+    vg = {g: sim.read(g) for g, _ in VEH}
+    trip = sim.read('veh_trip')
+    envb = sim.read('env')
+    for e, o in enumerate(orcs):
+        ref = o.outputs()
+        for b in OUT:
+            np.testing.assert_array_equal(out[b][e], ref[b], err_msg='%s env %d step %d' % (b, e, step))
+        v = o.vehicles()
+        st = o.stats()
+        assert envb[e, 0] == o.time and envb[e, 1] == st['inserted'] and envb[e, 2] == v['hw'] and envb[e, 3] == st['active']
+        live = v['lane'] != 0xFFFF
+        np.testing.assert_array_equal(trip[e][live].astype(np.int64), v['trip'][live])
+        for g, r in VEH:
+            a, b_ = vg[g][e], v[r]
+            if r != 'lane':
+                a, b_ = a[live], b_[live]
+            np.testing.assert_array_equal(a, b_, err_msg='%s env %d step %d' % (g, e, step))
+
+
+@pytest.mark.parametrize('name,steps,order,sigma,speed_dev,fixed', [
+    ('cologne1', 60, 0, 0.0, 0, 0),          # parity mode (deterministic), threads ascending
+    ('cologne1', 90, 2, -1.0, 1, 0),         # bench mode, shuffled thread order in every phase
+    ('cologne1', 40, 1, -1.0, 1, 1),         # FIXED programme, descending
+    ('cologne8', 60, 2, -1.0, 1, 0),
+    ('cologne3', 50, 1, -1.0, 1, 0),
+    ('ingolstadt1', 60, 2, -1.0, 1, 1),
+    ('ingolstadt7', 120, 2, -1.0, 1, 0),     # lane-change friction, cooperation requests
+    ('ingolstadt21', 70, 2, -1.0, 1, 0),
+])
+def test_kernel_source_equals_oracle(name, steps, order, sigma, speed_dev, fixed):
+    sc = load_scenario(name)
+    n, base = 2, 17
+    sim = EmuSim(sc, n, order=order, seed=3, sigma=sigma, speed_dev=speed_dev, fixed_program=fixed, env_base=base)
+    orcs = [OracleEnv(sc, env_index=base + e, seed=3, sigma=sigma, speed_dev=speed_dev, fixed_program=fixed) for e in range(n)]
+    for o in orcs:
+        o.observe()
+    assert_equal(sim, orcs, -1)
+    rng = np.random.default_rng(0)
+    for step in range(steps):
+        acts = np.stack([rng.integers(0, sc.tls_ngreen) for _ in range(n)]).astype(np.int32)
+        if step == 5:
+            acts[0, 0] = 99                  # out-of-range action: ignored, phase kept
+        sim.step(acts)
+        for e, o in enumerate(orcs):
+            o.step(acts[e])
+        if step % 5 == 4 or step == steps - 1:
+            assert_equal(sim, orcs, step)
+    st = sim.stats()
+    for e, o in enumerate(orcs):
+        so = o.stats()
+        for k in st:
+            assert st[k][e] == so[k], (k, e)
+    sim.close()
+
+
+def test_half_the_threads_two_slots_each():
+    """block_threads < capacity: a thread owns slots tid, tid + B (the 512-thread launch of a 1024-slot scenario)"""
+    sc = load_scenario('cologne8')
+    sim = EmuSim(sc, 1, order=2, seed=5, block_threads=64)
+    o = OracleEnv(sc, env_index=0, seed=5, sigma=-1.0, speed_dev=1)
+    o.observe()
+    rng = np.random.default_rng(1)
+    for step in range(60):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        sim.step(a[None, :])
+        o.step(a)
+    assert_equal(sim, [o], 59)
+    sim.close()
+
+
+def test_warm_start_ticks_and_reinit_signals():
+    """rs_ticks (warm-up / step_sim) and rs_reinit_signals (fresh Signal objects on a loaded network) vs the oracle, and
+    the loaded-network golden of the reference's own Python at its first observe"""
+    meta, g = load_golden('cologne8_d200_warm180')
+    sc = load_scenario('cologne8')
+    sim = EmuSim(sc, 1, seed=meta['seed'], max_distance=meta['max_distance'])
+    o = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1)
+    o.observe()
+    for k in range(meta['preroll']):
+        sim.act_random(k)
+        sim.step(None)
+        o.step(preroll_actions(sc, meta['seed'], 0, k))
+    sim.reinit_signals()
+    o.reinit_signals()
+    o.observe()
+    assert_equal(sim, [o], 0)
+    np.testing.assert_array_equal(sim.read('mplight')[0].reshape(-1), g['mplight'][0])
+    np.testing.assert_array_equal(sim.read('lane_agg')[0][:, :4], g['agg'][0][:, :4])
+    for k in range(10):
+        sim.step(g['actions'][k][None, :])
+        o.step(g['actions'][k])
+        np.testing.assert_array_equal(sim.read('wait')[0], g['wait'][k + 1].astype(np.float32))
+    sim.ticks(7)
+    for _ in range(7):
+        o.tick()
+    o.observe()
+    assert_equal(sim, [o], 11)
+    sim.close()
+
+
+def test_backlog_accounting():
+    """the per-departure-lane backlog (RS_BUF_DEP_NEXT) -> BatchedSim.backlog() / trip_delay() vs the oracle's own count"""
+    sc = load_scenario('ingolstadt7')
+    sim = EmuSim(sc, 2, seed=9, fixed_program=1)
+    orcs = [OracleEnv(sc, env_index=e, seed=9, sigma=-1.0, speed_dev=1, fixed_program=1) for e in range(2)]
+    for k in range(150):
+        sim.step(None)
+        for o in orcs:
+            o.step(np.zeros(sc.n_signals, np.int32))
+    cnt, waited = sim.backlog()
+    for e, o in enumerate(orcs):
+        w, c = o.backlog_delay()
+        assert cnt[e] == c and waited[e] == w
+    assert (sim.trip_delay() > 0).all()
+    sim.close()

@@ -7,7 +7,7 @@ restatement on the other."""
 import numpy as np
 import pytest
 
-from conftest import HOT_CASES, load_golden, load_scenario
+from conftest import ALL_CASES, load_golden, load_scenario, preroll_actions
 from oracle.pyoracle import OracleEnv
 
 
@@ -15,13 +15,19 @@ def flat_sig(sc, per_obs):
     return per_obs
 
 
-@pytest.mark.parametrize('tag', HOT_CASES)
+@pytest.mark.parametrize('tag', ALL_CASES)
 def test_oracle_matches_reference_python(tag):
     meta, g = load_golden(tag)
     sc = load_scenario(meta['map'])
     assert meta['all_ts_ids'] == sc.signal_ids
     env = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1)
     env.observe()
+    t0 = 0
+    if meta.get('preroll'):         # loaded network: roll forward, then fresh Signal objects (as the fixture's generator did)
+        for k in range(meta['preroll']):
+            env.step(preroll_actions(sc, meta['seed'], 0, k))
+        env.reinit_signals()
+        env.observe()
     S, O = sc.n_signals, sc.n_obs
     for k in range(meta['steps'] + 1):
         if k > 0:
@@ -57,3 +63,7 @@ def test_done_rule_and_time():
     meta, g = load_golden('cologne1_d200')
     assert not g['done'].any()          # 48 steps of 360
     assert g['time'][0] == 25200.0 and g['time'][1] == 25210.0
+    meta, g = load_golden('cologne1_d50_full')      # the whole episode: done exactly at the last step
+    assert g['done'][-1] and not g['done'][:-1].any() and g['time'][-1] == 28800.0
+    meta, g = load_golden('ingolstadt21_d200_warm180')
+    assert g['time'][0] == 57600.0 + 1800.0 and g['agg'][:, :, 3].max() >= 200     # long waiting_times on the loaded network

@@ -21,9 +21,13 @@ def test_invariants(name, fixed, steps):
         hw = v['hw']
         lane, pos, spd, trip = v['lane'][:hw], v['pos'][:hw], v['speed'][:hw], v['trip'][:hw]
         act = lane < 0xFFFE
-        # conservation: every trip that got a slot is pending, active or arrived
+        # conservation: every inserted trip is active or arrived; the backlog is what has departed but is not inserted
         assert st['inserted'] == st['arrived'] + st['active']
-        assert v['next_trip'] == st['inserted'] + st['pending']
+        assert v['next_trip'] == st['inserted']
+        waited, n_back = env.backlog_delay()
+        t_now = env.time
+        assert n_back == int((A['trip_depart'] < t_now).sum()) - st['inserted'] and waited >= 0
+        assert st['pending'] == int((A['trip_depart'] <= t_now - 1).sum()) - st['inserted']     # tried in the last tick or before
         assert int(act.sum()) == st['active']
         # kinematic bounds
         assert (spd[act] >= 0).all() and (pos[act] >= 0).all()

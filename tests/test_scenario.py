@@ -69,9 +69,16 @@ def test_table_consistency():
         assert (A['foe_link'] >= 0).all() and (A['foe_link'] < sc.n_links).all()
         assert (np.diff(A['trip_depart']) >= 0).all() and A['trips_cum'][-1] == sc.n_trips
         assert (A['obs_lane'] < sc.n_lanes).all()
-        # every route step has at least one preferred lane inside the edge
+        # route continuation lengths (SUMO's bestLanes): every step has a lane with a positive length, the last step
+        # continues "to the end" on all its lanes, entries beyond the edge's lane count are 0, and a lane's
+        # continuation is at least its own length
+        cont = A['route_cont']
+        assert cont.shape == (len(A['route_edge']), sc.kmax) and sc.kmax == int(A['edge_nlanes'].max())
         nl = A['edge_nlanes'][A['route_edge']]
-        assert ((A['route_mask2'].view(np.uint32) != 0) & (A['route_mask2'].view(np.uint32) < (1 << nl.astype(np.uint64)))).all()
+        assert (cont.max(axis=1) > 0).all()
+        assert all((cont[q, nl[q]:] == 0).all() for q in range(len(nl)))
+        assert (cont[A['route_start'][1:] - 1, 0] == np.float32(1.0e6)).all()
+        assert (cont[np.arange(len(nl)), 0] >= A['lane_len'][A['edge_lane0'][A['route_edge']]] - 1e-3).all()
         # internal lanes have exactly one outgoing link
         assert (A['lane_link_cnt'][A['lane_internal'] == 1] == 1).all()
         assert sc.capacity & (sc.capacity - 1) == 0

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase time split of rs_step_kernel (in-kernel wall_clock64 timers, summed over workgroups)."""
+"""In-kernel phase timers of the step kernel (rs_phase_profile): share of every phase in a workgroup's wall time.
+python tools/phase_profile.py [map] [envs] [block]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,15 +10,15 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'ingolstadt21'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
-sim = BatchedSim(sc, n, seed=0, block_threads=block)
+sim = BatchedSim(sc, n, seed=0, sigma=-1.0, speed_dev=1, block_threads=block)
 for k in range(100):
     sim.act_random(k); sim.step(None)
 sim.phase_profile(True)
-for k in range(100, 140):
+for k in range(100, 160):
     sim.act_random(k); sim.step(None)
 acc = sim.phase_profile(False)
-names = ['load', 'prologue', 'A cand+approach', 'B insert', 'C plan', 'clear heads', 'D move', 'E lane change', 'F rebuild', 'observe+store', 'outputs']
-tot = sum(acc[:11])
-for nm, v in zip(names, acc):
-    print('%-18s %6.2f %%   %.1f us per WG per env-step' % (nm, 100.0 * v / tot, v / 100.0 / (n * 40)))
-print('total per WG per env-step: %.1f us' % (tot / 100.0 / (n * 40)))
+names = ['L0', 'L1', 'L2', 'L3', 'P plan', 'C leave', 'M move', 'D decide', 'A1 apply', 'RB rebuild', 'A2 enter', 'O0', 'O1 observe', 'O2 outputs', 'O3']
+tot = float(sum(acc)) or 1.0
+for nm, a in zip(names, acc):
+    print('%-12s %6.2f %%' % (nm, 100.0 * a / tot))
+print('total ticks (100 MHz) per env-step per workgroup: %.0f' % (tot / 60 / n))
