@@ -41,6 +41,7 @@ __device__ __forceinline__ void rs_atomic_min(uint32_t *p, uint32_t v) { atomicM
 __device__ __forceinline__ void rs_atomic_max(int32_t *p, int32_t v) { atomicMax(p, v); }
 __device__ __forceinline__ void rs_atomic_add(int32_t *p, int32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void rs_atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+__device__ __forceinline__ int rs_atomic_inc(int32_t *p) { return atomicAdd(p, 1); }
 __device__ __forceinline__ void rs_atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
 __device__ __forceinline__ uint32_t rs_atomic_cas(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
 __device__ __forceinline__ int rs_ffsll(unsigned long long x) { return __ffsll(x); }
@@ -240,7 +241,7 @@ static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_
 }
 
 typedef void (*step_kernel_fn)(StepArgsPtr, KParams, const int32_t *);
-static const int kStepCaps[] = {0, 128, 256, 512, 1024};
+static const int kStepCaps[] = {0, 128, 256, 512, 768, 1024};
 // regs: 0 = 64 VGPRs (blocks up to 1024 threads), 1 = 128 VGPRs, 2 = 80 VGPRs (blocks up to 512 threads)
 #define RS_PICK(cap_) (regs == 1 ? rs_step_kernel_v128<cap_> : (regs == 2 ? rs_step_kernel_v80<cap_> : rs_step_kernel_v64<cap_>))
 static step_kernel_fn step_kernel_for(int regs, int capacity) {
@@ -248,6 +249,7 @@ static step_kernel_fn step_kernel_for(int regs, int capacity) {
         case 128: return RS_PICK(128);
         case 256: return RS_PICK(256);
         case 512: return RS_PICK(512);
+        case 768: return RS_PICK(768);
         case 1024: return RS_PICK(1024);
         default: return RS_PICK(0);
     }
@@ -274,7 +276,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         h->err = "need 0 <= yellow_length < step_length"; return fail(RS_EINVAL);
     }
     const int C = sc->capacity;
-    if (C < 64 || (C & (C - 1)) || C > 16384) { h->err = "capacity must be a power of two in [64, 16384]"; return fail(RS_ELIMIT); }
+    if (C < 64 || (C % 64) || C > 16384) { h->err = "capacity must be a multiple of 64 in [64, 16384]"; return fail(RS_ELIMIT); }
     if (sc->kmax < 1 || sc->kmax > 16) { h->err = "kmax (lanes per edge) must be in [1, 16]"; return fail(RS_ELIMIT); }
     PackedTables PT;
     if (!PT.build(sc)) { h->err = PT.err; return fail(RS_ELIMIT); }

@@ -125,10 +125,16 @@ RS_DEV float speed_factor(const KParams &P, int env, int trip, const float *vt) 
 }
 
 // ------------------------------------------------------------------------------------------------ working memory (LDS)
-struct __attribute__((aligned(8))) Node {
+struct __attribute__((aligned(16))) Node {      // everything a NEIGHBOUR wants to know about a vehicle: one 16-byte read
     float pos;
+    float speed;
     uint16_t trip;      // TRIP_NONE: free slot
     uint16_t nxt;       // next vehicle of the same grid cell (unordered), NIL terminated
+    uint8_t vt;         // vType
+    uint8_t pad[3];
+};
+struct __attribute__((aligned(8))) Aux {        // what only the owner reads, every tick: one 8-byte read
+    uint16_t lane, rq, nlink, cell;
 };
 // The layout (a table of offsets, computed once by the host: lds_carve) is read from the constant argument block.
 // An array of the working memory is addressed as (RS_SMEM + offset): the including file defines RS_SMEM as THE shared
@@ -140,11 +146,10 @@ template <class Tp> struct LPtr {
     RS_MEM operator Tp *() const { return (Tp *)(RS_SMEM + off); }
 };
 struct Lds {
-    LPtr<Node> node;            // {pos, trip, next-in-cell}: one 8-byte read per chain step
-    LPtr<float> speed, vnx, vtp;
-    LPtr<uint16_t> lane, rq, nlink, cell;
+    LPtr<Node> node;
+    LPtr<Aux> aux;
+    LPtr<float> vnx, vtp;
     LPtr<uint16_t> grid;        // the cells (bit 15: the cell holds a moving vehicle)
-    LPtr<uint8_t> vt;
     LPtr<int32_t> arr;          // link approach registers
     LPtr<uint16_t> dep;         // head trip of every departure lane's backlog
     LPtr<uint32_t> alive, insm; // bit per slot: occupied; bit per departure lane: inserts this tick
@@ -171,10 +176,7 @@ RS_CARVE size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
 #define CARVE(field, bytes) { if (L) L->field.off = (uint32_t)o; o += align16(bytes); }
-    CARVE(node, (size_t)C * 8) CARVE(speed, (size_t)C * 4)
-    CARVE(lane, (size_t)C * 2) CARVE(rq, (size_t)C * 2)
-    CARVE(nlink, (size_t)C * 2) CARVE(cell, (size_t)C * 2)
-    CARVE(vt, (size_t)C)
+    CARVE(node, (size_t)C * 16) CARVE(aux, (size_t)C * 8)
     {
         const size_t ab = align16((size_t)n_obs * 4), a = (size_t)C * 4, b = 5 * ab;
         if (L) {
@@ -418,17 +420,17 @@ RS_DEV int strategic_dir(const KTab &T, int rq, int kk, int n, float x, float v,
 // approach registration of slot s for the coming tick (P3): a moving vehicle whose next link somebody may have to yield
 // to registers its arrival time there
 RS_DEV void register_approach(const KTab &T, const Lds &L, int s) {
-    const int lane = L.lane[s];
+    const int lane = L.aux[s].lane;
     if (lane == (int)LANE_NONE) return;
-    const int nlk = L.nlink[s];
+    const int nlk = L.aux[s].nlink;
     if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
-    const float v = L.speed[s];
+    const float v = L.node[s].speed;
     if (v <= RM_HALT_SPEED) return;
     const LinkRec K = T.links()[nlk & 0x7FFF];
     const int st = tls_state(T, L, K.tls, K.tls_pos);
     if (st == TLS_R) return;
     const float dist = T.lanes()[lane].len - L.node[s].pos;
-    if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.vt[s] * VT_COLS + VT_DECEL])) return;
+    if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.node[s].vt * VT_COLS + VT_DECEL])) return;
     const float ta = dist / (v > 1.0f ? v : 1.0f);
     const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
     rs_atomic_min(&L.arr[K.arr_idx], q);
@@ -439,16 +441,16 @@ RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool cla
                              float b, float tau, float mingap, float &vsafe) {
     const int X = (int)(key & 0xFFFFu), kx = (int)(key >> 16);
     if ((int)L.node[X].trip != kx) return;
-    const int lx = L.lane[X];
+    const int lx = L.aux[X].lane;
     if (lx == (int)LANE_NONE || (LR.flags & LF_INTERNAL)) return;
     const int l0 = LR.edge_lane0, n = LR.flags >> 2;
     if (lx < l0 || lx >= l0 + n) return;            // not on my edge (lanes of an edge are consecutive; internal lanes have n = 0)
-    const float *vo = L.vtp + L.vt[X] * VT_COLS;
+    const float *vo = L.vtp + L.node[X].vt * VT_COLS;
     const float px = L.node[X].pos, backx = px - vo[VT_LENGTH];
     if (clamp_gap ? !(px >= x) : !(backx >= x)) return;
     float g = backx - x - mingap;
     if (clamp_gap && g < 0.0f) g = 0.0f;
-    float vs = d_follow_speed(g, L.speed[X], b, vo[VT_DECEL], tau);
+    float vs = d_follow_speed(g, L.node[X].speed, b, vo[VT_DECEL], tau);
     float vc = v - b; if (vc < 0.0f) vc = 0.0f;
     if (vs < vc) vs = vc;
     if (vs < vsafe) vsafe = vs;
@@ -458,14 +460,20 @@ RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool cla
 // ------------------------------------------------------------------------------------------------ the phases
 // P: plan (Krauss car-following + links) for slot s
 RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
-    const int lane = L.lane[s];
+    const Aux ax = L.aux[s];
+    const int lane = ax.lane;
     if (lane == (int)LANE_NONE) return;
-    const int k = L.node[s].trip;
-    const float *vt = L.vtp + L.vt[s] * VT_COLS;
+    const Node me = L.node[s];
+    const int k = me.trip;
+    const float *vt = L.vtp + me.vt * VT_COLS;
     const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
-    const float v = L.speed[s], x = L.node[s].pos;
+    const float v = me.speed, x = me.pos;
+#ifdef RS_DIAG_NOGLOBAL
+    const float sf = 1.0f; const uint32_t c2 = COOP_NONE;
+#else
     const float sf = G.sf()[eo + s];
     const uint32_t c2 = G.cooplead()[eo + s];
+#endif
     LaneRec LR = T.lanes()[lane];
     float vfree = v + a;
     const float vl = LR.vmax * sf;
@@ -480,20 +488,28 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
     const int lead = leader_within(L, LR.cell0, lane_cells(LR), x, k, s, look + T.maxlen);
     bool found = false;
     if (lead != NIL) {
-        const float *vo = L.vtp + L.vt[lead] * VT_COLS;
-        tgap = L.node[lead].pos - vo[VT_LENGTH] - x - mingap;
-        tvl = L.speed[lead]; tbl = vo[VT_DECEL];
+        const Node ld = L.node[lead];
+        const float *vo = L.vtp + ld.vt * VT_COLS;
+        tgap = ld.pos - vo[VT_LENGTH] - x - mingap;
+        tvl = ld.speed; tbl = vo[VT_DECEL];
         have = true; found = true;
     }
     {   // cooperation: requests of the last lane-change phase
+#ifdef RS_DIAG_NOGLOBAL
+        const uint32_t c1 = COOP_NONE;
+#else
         const uint32_t c1 = G.coop()[eo + s];        // (in HBM: written rarely, by other threads, with a global atomic)
+#endif
         if (c1 != COOP_NONE) { G.coop()[eo + s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
         if (c2 != COOP_NONE) { G.cooplead()[eo + s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
     }
     float seen = LR.len - x;
+#ifdef RS_DIAG_NOHOP
+    found = true;
+#endif
     if (!found && seen < look) {
-        int rq = L.rq[s];
-        int link = (int)(L.nlink[s] & 0x7FFF);
+        int rq = ax.rq;
+        int link = (int)(ax.nlink & 0x7FFF);
         int cur_lane = lane;
         const float bgv = d_brake_gap(v, b);        // can I still stop in front of a red / yellow light?
         for (int hop = 0; hop < RM_MAX_HOPS; ++hop) {
@@ -532,9 +548,10 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
             }
             const int o = rearmost_within(L, LR.cell0, lane_cells(LR), look - seen + T.maxlen);
             if (o != NIL) {
-                const float *vo = L.vtp + L.vt[o] * VT_COLS;
-                tgap = seen + L.node[o].pos - vo[VT_LENGTH] - mingap;
-                tvl = L.speed[o]; tbl = vo[VT_DECEL];
+                const Node od = L.node[o];
+                const float *vo = L.vtp + od.vt * VT_COLS;
+                tgap = seen + od.pos - vo[VT_LENGTH] - mingap;
+                tvl = od.speed; tbl = vo[VT_DECEL];
                 have = true;
                 break;
             }
@@ -566,15 +583,16 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
 // M: move slot s, hand it over to the next lanes, let it arrive; register it in the grid of the moved state
 RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParams &P, int env, size_t eo, int t, bool last_tick, int s,
                        int &active, int &halted, int &top) {
-    int lane = L.lane[s];
+    const Aux ax = L.aux[s];
+    int lane = ax.lane;
     if (lane == (int)LANE_NONE) return;
-    const int k = L.node[s].trip;
-    int link = (int)(L.nlink[s] & 0x7FFF);
+    const Node me = L.node[s];
+    const int k = me.trip;
+    int link = (int)(ax.nlink & 0x7FFF);
     LaneRec LR = T.lanes()[lane];
     const float vn = L.vnx[s];
     const float vref = LR.vmax * G.sf()[eo + s];
-    if (last_tick) G.accel()[eo + s] = vn - L.speed[s];
-    L.speed[s] = vn;
+    if (last_tick) G.accel()[eo + s] = vn - me.speed;
     if (vn <= RM_HALT_SPEED) {
         const int w = G.swait()[eo + s]; if (w < 65535) G.swait()[eo + s] = (uint16_t)(w + 1);
         halted += 1;
@@ -582,8 +600,8 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParam
     } else G.swait()[eo + s] = 0;
     float tl = G.tloss()[eo + s];
     if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss()[eo + s] = tl; }
-    float x = L.node[s].pos + vn;
-    int rq = L.rq[s];
+    float x = me.pos + vn;
+    int rq = ax.rq;
     bool arrived = false, moved = false;
     for (int it = 0; it < 16; ++it) {
         if (!(x > LR.len)) break;
@@ -603,7 +621,7 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParam
         moved = true;
     }
     if (arrived) {
-        L.lane[s] = LANE_NONE; L.node[s].trip = TRIP_NONE; L.cell[s] = 0xFFFF;
+        L.aux[s].lane = LANE_NONE; L.node[s].trip = TRIP_NONE; L.aux[s].cell = 0xFFFF;
         G.coop()[eo + s] = COOP_NONE; G.cooplead()[eo + s] = COOP_NONE;
         rs_atomic_and(&L.alive[s >> 5], ~(1u << (s & 31)));
         {   // Signal.departures of the signal that observed the vehicle last (traffic_signal.py:226-232)
@@ -621,32 +639,38 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParam
         }
         return;
     }
-    L.node[s].pos = x;
-    if (moved) {
-        L.lane[s] = (uint16_t)lane; L.rq[s] = (uint16_t)rq;
-        L.nlink[s] = cache_link(T, LR, lane, rq, k);
-    }
     active += 1;
     top = s + 1;
     const int c = LR.cell0 + cell_of(x, lane_cells(LR));
-    L.cell[s] = (uint16_t)c;
-    L.node[s].nxt = grid_push(L.grid, c, s, vn > RM_HALT_SPEED);
+    Aux na = ax;
+    if (moved) { na.lane = (uint16_t)lane; na.rq = (uint16_t)rq; na.nlink = cache_link(T, LR, lane, rq, k); }
+    na.cell = (uint16_t)c;
+    L.aux[s] = na;
+    Node nn = me;
+    nn.pos = x; nn.speed = vn;
+    nn.nxt = grid_push(L.grid, c, s, vn > RM_HALT_SPEED);
+    L.node[s] = nn;
     (void)P;
 }
 
 // D: lane-change decision of slot s on the moved state; returns the target lane (-1: stay).  A blocked strategic
 // changer asks for cooperation (oracle: lane_change()).
 RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const State &G, size_t eo, int t, int s) {
-    const int lane = L.lane[s];
+#ifdef RS_DIAG_NOLC
+    return -1;
+#endif
+    const Aux ax = L.aux[s];
+    const int lane = ax.lane;
     if (lane == (int)LANE_NONE) return -1;
     const LaneRec LR = T.lanes()[lane];
     const int n = LR.flags >> 2;
     if ((LR.flags & LF_INTERNAL) || n < 2) return -1;
     const int dir_allowed = (t & 1) ? -1 : +1;
     const int l0 = LR.edge_lane0, kk = lane - l0;
-    const int k = L.node[s].trip, rq = L.rq[s];
-    const float *vt = L.vtp + L.vt[s] * VT_COLS;
-    const float x = L.node[s].pos, v = L.speed[s];
+    const Node me = L.node[s];
+    const int k = me.trip, rq = ax.rq;
+    const float *vt = L.vtp + me.vt * VT_COLS;
+    const float x = me.pos, v = me.speed;
     const int nc = lane_cells(LR);
     int want = 0, dir = dir_allowed;
     float rem;
@@ -667,9 +691,9 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const State &G, size_t e
         const int lead_c = leader_within(L, LR.cell0, nc, x, k, s, RM_NB_WINDOW);
         if (lead_c == NIL) return -1;
         lead_t = leader_within(L, tcell0, nc, x, k, s, RM_NB_WINDOW);
-        const float gcur = L.node[lead_c].pos - L.vtp[L.vt[lead_c] * VT_COLS + VT_LENGTH] - x;
+        const float gcur = L.node[lead_c].pos - L.vtp[L.node[lead_c].vt * VT_COLS + VT_LENGTH] - x;
         float gtgt = RM_BIGF;
-        if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.vt[lead_t] * VT_COLS + VT_LENGTH] - x;
+        if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.node[lead_t].vt * VT_COLS + VT_LENGTH] - x;
         if (!(gcur < v * 3.0f + 15.0f && gtgt > gcur + RM_SG_ADVANTAGE)) return -1;
         want = 1;
         have_t = true;
@@ -681,17 +705,17 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const State &G, size_t e
     const bool urgent = want == 2 && rem <= RM_URGENT_DIST;
     bool safe = true;
     if (lead_t != NIL) {
-        const float *vo = L.vtp + L.vt[lead_t] * VT_COLS;
+        const float *vo = L.vtp + L.node[lead_t].vt * VT_COLS;
         const float gap = L.node[lead_t].pos - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
         const float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
         float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
-        if (gap < 0.0f || vb > d_follow_speed(gap, L.speed[lead_t], vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
+        if (gap < 0.0f || vb > d_follow_speed(gap, L.node[lead_t].speed, vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
     }
     if (safe && foll_t != NIL) {
-        const float *vo = L.vtp + L.vt[foll_t] * VT_COLS;
+        const float *vo = L.vtp + L.node[foll_t].vt * VT_COLS;
         const float gap = x - vt[VT_LENGTH] - L.node[foll_t].pos - (urgent ? 0.0f : vo[VT_MINGAP]);
         const float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
-        float vb = L.speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
+        float vb = L.node[foll_t].speed - dec; if (vb < 0.0f) vb = 0.0f;
         if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
     }
     if (safe) return dir == dir_allowed ? tl : -1;
@@ -721,9 +745,9 @@ RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, int t, int d) {
     const int c1 = LR.cell0 + cell_of(mypos + vt[VT_MINGAP] + T.maxlen, nc);
     for (int c = scan_up(L.grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(L.grid, c + 1, c1) : -1))
         for (int o = L.grid[c] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
-            const float back = L.node[o].pos - L.vtp[L.vt[o] * VT_COLS + VT_LENGTH];
+            const float back = L.node[o].pos - L.vtp[L.node[o].vt * VT_COLS + VT_LENGTH];
 #ifdef RS_EMU_DEBUG
-            if (k == 312 && t >= 470) printf("   o %d trip %d pos %f back %f lane %d (dl %d) cell %d head %d nxt %d cellof %d\n", o, L.node[o].trip, L.node[o].pos, back, L.lane[o], dl, c, L.grid[c], L.node[o].nxt, L.cell[o]);
+            if (k == 312 && t >= 470) printf("   o %d trip %d pos %f back %f lane %d (dl %d) cell %d head %d nxt %d cellof %d\n", o, L.node[o].trip, L.node[o].pos, back, L.aux[o].lane, dl, c, L.grid[c], L.node[o].nxt, L.aux[o].cell);
 #endif
             if (back - mypos - vt[VT_MINGAP] < 0.0f) return false;
         }
@@ -781,17 +805,17 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         for (int s = tid; s < C; s += B) {
             uint16_t ln = LANE_NONE, tr = TRIP_NONE;
             if (s < hw0) { ln = G.lane()[eo + s]; tr = G.trip()[eo + s]; }
-            L.lane[s] = ln; L.node[s].trip = tr; L.cell[s] = 0xFFFF;
+            L.aux[s].lane = ln; L.node[s].trip = tr; L.aux[s].cell = 0xFFFF;
             if (ln == LANE_NONE) continue;
             const float sp = G.speed()[eo + s];
-            L.node[s].pos = G.pos()[eo + s]; L.speed[s] = sp;
+            L.node[s].pos = G.pos()[eo + s]; L.node[s].speed = sp;
             const int rq = (int)T.routes()[T.trip_route()[tr]].start + (int)G.cursor()[eo + s];
-            L.rq[s] = (uint16_t)rq;
-            L.vt[s] = T.trip_vtype()[tr];
+            L.aux[s].rq = (uint16_t)rq;
+            L.node[s].vt = T.trip_vtype()[tr];
             const LaneRec LR0 = T.lanes()[ln];
-            L.nlink[s] = cache_link(T, LR0, ln, rq, tr);
+            L.aux[s].nlink = cache_link(T, LR0, ln, rq, tr);
             const int c = LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0));
-            L.cell[s] = (uint16_t)c;
+            L.aux[s].cell = (uint16_t)c;
             L.node[s].nxt = grid_push(L.grid, c, s, sp > RM_HALT_SPEED);
             rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
         }
@@ -828,10 +852,10 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         // ---- C: everybody leaves the grid and drops its approach registration (nobody reads them between plan and move)
         ex.phase(5, [&](int tid) {
             for (int s = tid; s < hw; s += B) {
-                const int c = L.cell[s];
+                const int c = L.aux[s].cell;
                 if (c < 0xFFF0) L.grid[c] = NIL;
-                const int nlk = L.nlink[s];
-                if (L.lane[s] != LANE_NONE && (nlk & NLINK_ARR)) L.arr[T.links()[nlk & 0x7FFF].arr_idx] = ARR_NONE;
+                const int nlk = L.aux[s].nlink;
+                if (L.aux[s].lane != LANE_NONE && (nlk & NLINK_ARR)) L.arr[T.links()[nlk & 0x7FFF].arr_idx] = ARR_NONE;
             }
             if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_REBUILD] = 0; }
             for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
@@ -870,17 +894,17 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         // ---- A1: lane changers leave their cell; the winners of the departure lanes fill free slots
         ex.phase(8, [&](int tid) {
             for (int s = tid; s < hw2; s += B) {
-                if (L.lane[s] == LANE_NONE) continue;
+                if (L.aux[s].lane == LANE_NONE) continue;
                 const int target = rs_float_as_int(L.vnx[s]);
                 if (target < 0) continue;
-                const int c = L.cell[s];
+                const int c = L.aux[s].cell;
 #ifdef RS_EMU_DEBUG
-                if (s == 104 && t >= 470) printf("A1 t %d slot %d lane %d -> %d cell %d head %d nxt %d\n", t, s, L.lane[s], target, c, L.grid[c], L.node[s].nxt);
+                if (s == 104 && t >= 470) printf("A1 t %d slot %d lane %d -> %d cell %d head %d nxt %d\n", t, s, L.aux[s].lane, target, c, L.grid[c], L.node[s].nxt);
 #endif
-                if ((L.grid[c] & 0x7FFF) == s && L.node[s].nxt == NIL) { L.grid[c] = NIL; L.cell[s] = 0xFFFD; }   // alone in my cell: leave it, re-register in A2
+                if ((L.grid[c] & 0x7FFF) == s && L.node[s].nxt == NIL) { L.grid[c] = NIL; L.aux[s].cell = 0xFFFD; }   // alone in my cell: leave it, re-register in A2
                 else L.sc[SC_REBUILD] = 1;      // shared cell: everybody leaves and re-enters the grid (my cell index stays valid for the clearing)
-                L.lane[s] = (uint16_t)target;
-                L.nlink[s] = cache_link(T, T.lanes()[target], target, L.rq[s], L.node[s].trip);
+                L.aux[s].lane = (uint16_t)target;
+                L.aux[s].nlink = cache_link(T, T.lanes()[target], target, L.aux[s].rq, L.node[s].trip);
             }
             for (int d = B - 1 - tid; d < T.n_dep; d += B) {
                 if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
@@ -895,10 +919,10 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 const RouteRec RR = T.routes()[T.trip_route()[k]];
                 L.node[s].pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
                 L.node[s].trip = (uint16_t)k; L.node[s].nxt = NIL;
-                L.speed[s] = 0.0f; G.swait()[eo + s] = 0; L.vt[s] = (uint8_t)v;
-                L.lane[s] = RR.depart_lane; L.rq[s] = (uint16_t)RR.start;
-                L.nlink[s] = cache_link(T, T.lanes()[RR.depart_lane], RR.depart_lane, (int)RR.start, k);
-                L.cell[s] = CELL_NEW;
+                L.node[s].speed = 0.0f; G.swait()[eo + s] = 0; L.node[s].vt = (uint8_t)v;
+                L.aux[s].lane = RR.depart_lane; L.aux[s].rq = (uint16_t)RR.start;
+                L.aux[s].nlink = cache_link(T, T.lanes()[RR.depart_lane], RR.depart_lane, (int)RR.start, k);
+                L.aux[s].cell = CELL_NEW;
                 G.sf()[eo + s] = speed_factor(P, genv, k, vt); G.tloss()[eo + s] = 0.0f; G.cooplead()[eo + s] = COOP_NONE; G.coop()[eo + s] = COOP_NONE;
                 G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
                 L.dep[d] = T.cold.trip_next[k];
@@ -911,16 +935,16 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         const bool more = tick + 1 < n_ticks;
         if (L.sc[SC_REBUILD]) {
             ex.phase(9, [&](int tid) {
-                for (int s = tid; s < hw3; s += B) { const int c = L.cell[s]; if (c < 0xFFF0) L.grid[c] = NIL; }
+                for (int s = tid; s < hw3; s += B) { const int c = L.aux[s].cell; if (c < 0xFFF0) L.grid[c] = NIL; }
             });
         }
         const bool rebuild = L.sc[SC_REBUILD] != 0;
         // ---- A2: changers and new vehicles enter the grid; the next tick's approach registrations (P3)
         ex.phase(10, [&](int tid) {
             for (int s = tid; s < hw3; s += B) {
-                const int ln = L.lane[s];
+                const int ln = L.aux[s].lane;
                 if (ln == (int)LANE_NONE) continue;
-                const int c0 = L.cell[s];
+                const int c0 = L.aux[s].cell;
                 if (c0 == (int)CELL_NEW) {
                     rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
                     rs_atomic_add(&L.sc[SC_NACT], 1);
@@ -929,8 +953,8 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 if (rebuild || c0 >= 0xFFF0) {
                     const LaneRec LRn = T.lanes()[ln];
                     const int c = LRn.cell0 + cell_of(L.node[s].pos, lane_cells(LRn));
-                    L.cell[s] = (uint16_t)c;
-                    L.node[s].nxt = grid_push(L.grid, c, s, L.speed[s] > RM_HALT_SPEED);
+                    L.aux[s].cell = (uint16_t)c;
+                    L.node[s].nxt = grid_push(L.grid, c, s, L.node[s].speed > RM_HALT_SPEED);
                 }
                 if (more) register_approach(T, L, s);
             }
@@ -946,14 +970,14 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         const int top = hwf > hw0 ? hwf : hw0;
         int hi = 0;
         for (int s = tid; s < top; s += B) {
-            const int lane = L.lane[s];
+            const int lane = L.aux[s].lane;
             const int prev_owner = G.owner()[eo + s];
             G.lane()[eo + s] = (uint16_t)lane; G.trip()[eo + s] = L.node[s].trip;
             if (lane == (int)LANE_NONE) continue;
             hi = s + 1;
             // store the slab back (once per env-step)
-            const int rq = L.rq[s];
-            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.speed[s];
+            const int rq = L.aux[s].rq;
+            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.node[s].speed;
             G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes()[T.trip_route()[L.node[s].trip]].start);
             const LaneRec LR = T.lanes()[lane];
             const int oi = T.cold.lane_obs[lane];
@@ -980,7 +1004,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             G.owner()[eo + s] = (uint8_t)sig;
             if (rw > 0) { rs_atomic_add(&L.agg_q[oi], 1); rs_atomic_add(&L.agg_w[oi], rw); rs_atomic_max(&L.agg_m[oi], rw); }
             else rs_atomic_add(&L.agg_a[oi], 1);
-            rs_atomic_add((int32_t *)&L.agg_s[oi], (int32_t)(uint32_t)(L.speed[s] * 65536.0f + 0.5f));
+            rs_atomic_add((int32_t *)&L.agg_s[oi], (int32_t)(uint32_t)(L.node[s].speed * 65536.0f + 0.5f));
         }
         if (hi) rs_atomic_max(&L.sc[SC_HWNEW], hi);
     });

@@ -38,6 +38,8 @@ def parity(name, steps, n=4, fixed=0, block=0):
 
 def timing(name, n, block, steps=120, warm=60):
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
+    if os.environ.get('RS_CAPACITY'):
+        sc.capacity = int(os.environ['RS_CAPACITY'])
     sim = BatchedSim(sc, n, seed=0, sigma=-1.0, speed_dev=1, block_threads=block)
     for k in range(warm):
         sim.act_random(k); sim.step(None)
