@@ -26,6 +26,9 @@
 #define RM_GOOD_CONT 200.0f       /* a connection whose destination lane can be followed this far is as good as the best one */
 #define RM_MIN_LC_LEN 5.0f        /* an edge shorter than this cannot host a lane change */
 #define RM_CONT_EPS 0.5f
+#define RM_SWAP_WAIT 20           /* a mutual block (two stationary vehicles side by side, each in the lane the other needs) is
+                                     broken up by trading places once both have stood this many seconds ... */
+#define RM_SWAP_EVERY 4           /* ... looked for on every 4th tick only */
 #define RM_BIGF 1.0e30f
 
 #endif

@@ -35,6 +35,8 @@ struct orc_env {
     int32_t env_index;
     int32_t t;              /* ticks since begin */
     float maxlen;           /* longest vehicle of the scenario */
+    int32_t room_ins;       /* free capacity when this tick's insertions were decided */
+    uint8_t *free_before;   /* per slot: free when this tick's insertions were decided */
     int32_t n_inserted;     /* trips inserted so far */
     int32_t n_active;       /* vehicles on the network */
     int32_t *dep_next;      /* per lane: the next trip that departs from it (-1: none left) -- a FIFO per departure lane */
@@ -256,7 +258,7 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     if (p->trip_log) ALLOC(e->trip_log, (size_t)sc->n_trips * 4);
     ALLOC(e->lane_head, sc->n_lanes); ALLOC(e->next_in_lane, C); ALLOC(e->link_arr, sc->n_links);
     ALLOC(e->lane_ins, sc->n_lanes);
-    ALLOC(e->dep_next, sc->n_lanes); ALLOC(e->dep_first, sc->n_lanes); ALLOC(e->trip_next, sc->n_trips); ALLOC(e->coop, C); ALLOC(e->coop_lead, C); ALLOC(e->coop_lead_trip, C);
+    ALLOC(e->dep_next, sc->n_lanes); ALLOC(e->dep_first, sc->n_lanes); ALLOC(e->trip_next, sc->n_trips); ALLOC(e->coop, C); ALLOC(e->coop_lead, C); ALLOC(e->free_before, C); ALLOC(e->coop_lead_trip, C);
     {   /* the trips of one departure lane form a FIFO in trip (= departure time) order */
         for (int32_t l = 0; l < sc->n_lanes; ++l) e->dep_first[l] = -1;
         for (int32_t k = sc->n_trips - 1; k >= 0; --k) {
@@ -281,7 +283,7 @@ void orc_destroy(orc_env *e) {
     free(e->lane); free(e->cursor); free(e->sumo_wait); free(e->resco_wait); free(e->depart); free(e->owner);
     free(e->pos); free(e->speed); free(e->accel); free(e->time_loss); free(e->vnext); free(e->lc_target); free(e->trip); free(e->dbg_reason); free(e->dbg_block); free(e->wtot); free(e->trip_log);
     free(e->lane_head); free(e->next_in_lane); free(e->link_arr); free(e->lane_ins);
-    free(e->dep_next); free(e->dep_first); free(e->trip_next); free(e->coop); free(e->coop_lead); free(e->coop_lead_trip);
+    free(e->dep_next); free(e->dep_first); free(e->trip_next); free(e->coop); free(e->coop_lead); free(e->free_before); free(e->coop_lead_trip);
     free(e->phase); free(e->left); free(e->next_phase);
     free(e->lane_agg); free(e->drq_norm); free(e->wait); free(e->wait_norm);
     free(e->agg_q); free(e->agg_a); free(e->agg_w); free(e->agg_m); free(e->agg_s);
@@ -341,8 +343,8 @@ static void tls_events(orc_env *e) {
 
 /* [SUMO-K] MSInsertionControl (emitVehicles runs at the end of a simulation step, after the lane changes): every
  * departure lane keeps its own backlog; its oldest trip is inserted (departPos "base", departSpeed 0) as soon as it has
- * departed and the space behind the rear-most vehicle suffices.  The check reads the moved state of this tick, before
- * this tick's lane changes are applied (it is evaluated side by side with the lane-change decisions). */
+ * departed and the space behind the rear-most vehicle suffices AFTER this tick's move of the vehicles that are on the lane now
+ * (their planned speeds are known; a vehicle that enters the lane in this very tick is not seen). */
 static void insertion_check(orc_env *e) {
     const orc_scenario *sc = e->sc;
     for (int32_t dl = 0; dl < sc->n_lanes; ++dl) {
@@ -354,22 +356,26 @@ static void insertion_check(orc_env *e) {
         int ok = 1;
         for (int32_t o = e->lane_head[dl]; o != NIL; o = e->next_in_lane[o]) {
             const float *vo = vt_of(e, trip_of_slot(e, o));
-            float back = e->pos[o] - vo[VT_LENGTH];
+            float back = (e->pos[o] + e->vnext[o]) - vo[VT_LENGTH];       /* where it will be after this tick's move */
             if (back - mypos - vt[VT_MINGAP] < 0.0f) ok = 0;
         }
         if (ok) e->lane_ins[dl] = k;
     }
+    /* the winners take the slots that are free NOW (before this tick's arrivals free more), lower lane index first */
+    e->room_ins = sc->capacity - e->n_active;
+    for (int32_t s = 0; s < sc->capacity; ++s) e->free_before[s] = e->lane[s] == LANE_NONE;
 }
 static void insertion_apply(orc_env *e) {
     const orc_scenario *sc = e->sc;
     int32_t C = sc->capacity;
-    int32_t room = C - e->n_active;         /* the network holds at most `capacity` vehicles */
+    int32_t room = e->room_ins;             /* the network holds at most `capacity` vehicles */
     for (int32_t dl = 0; dl < sc->n_lanes && room > 0; ++dl) {      /* lower lane index first when the network is full */
         int32_t k = e->lane_ins[dl];
         if (k < 0) continue;
         int32_t s = 0;
-        while (s < C && e->lane[s] != LANE_NONE) s += 1;           /* lowest free slot (the slot index has no meaning) */
+        while (s < C && !e->free_before[s]) s += 1;                 /* lowest slot that was free before this tick (the index has no meaning) */
         if (s >= C) break;
+        e->free_before[s] = 0;
         const float *vt = vt_of(e, k);
         e->trip[s] = k; e->lane[s] = (uint16_t)dl;
         e->pos[s] = vt[VT_LENGTH] < sc->lane_len[dl] ? vt[VT_LENGTH] : sc->lane_len[dl];
@@ -582,7 +588,7 @@ static void move(orc_env *e) {
         else e->sumo_wait[s] = 0;
         if (vref > 0.0f && vn < vref) e->time_loss[s] += (vref - vn) / vref;
         float x = e->pos[s] + vn;
-        int32_t lane = e->lane[s], cursor = e->cursor[s];
+        int32_t lane = e->lc_target[s] >= 0 ? e->lc_target[s] : e->lane[s], cursor = e->cursor[s];       /* sideways first, then forward */
         int arrived = 0;
         for (int it = 0; it < 16; ++it) {
             float len = sc->lane_len[lane];
@@ -614,6 +620,31 @@ static void move(orc_env *e) {
     while (e->hw > 0 && e->lane[e->hw - 1] == LANE_NONE) e->hw -= 1;
 }
 
+/* Mutual block (own rule; SUMO resolves the same situation with its sublane / cooperative machinery or teleports, which this
+ * model does not have): two stationary vehicles stand side by side near the end of their lanes, each in the lane the other
+ * one needs.  Neither can ever find a gap, so they trade places.  swap_dir: the strategic direction of such a vehicle (0:
+ * it is not one). */
+static int32_t swap_dir(const orc_env *e, int32_t s) {
+    const orc_scenario *sc = e->sc;
+    if (e->lane[s] >= LANE_PENDING) return 0;
+    int32_t lane = e->lane[s];
+    if (sc->lane_internal[lane] || e->speed[s] > HALT_SPEED || e->sumo_wait[s] < RM_SWAP_WAIT) return 0;
+    int32_t ed = sc->lane_edge[lane], n = sc->edge_nlanes[ed], kk = lane - sc->edge_lane0[ed];
+    if (n < 2) return 0;
+    float rem;
+    int32_t d = strategic_dir_at(e, sc->trip_route[e->trip[s]], e->cursor[s], kk, n, e->pos[s], e->speed[s], 0, &rem);
+    if (d == 0 || rem > RM_URGENT_DIST) return 0;
+    return d;
+}
+/* the vehicle on lane tl whose body overlaps mine lengthwise (the nearer one ahead first), NIL: none */
+static int32_t overlapping(const orc_env *e, int32_t s, int32_t tl) {
+    int32_t lead, foll;
+    int32_t k = e->trip[s];
+    neighbours(e, tl, e->pos[s], k, s, RM_NB_WINDOW, &lead, &foll);
+    if (lead != NIL && e->pos[lead] - vt_of(e, trip_of_slot(e, lead))[VT_LENGTH] - e->pos[s] < 0.0f) return lead;
+    if (foll != NIL && e->pos[s] - vt_of(e, k)[VT_LENGTH] - e->pos[foll] < 0.0f) return foll;
+    return NIL;
+}
 static void lane_change(orc_env *e) {
     const orc_scenario *sc = e->sc;
     int32_t dir_allowed = (e->t & 1) ? -1 : +1;
@@ -680,7 +711,12 @@ static void lane_change(orc_env *e) {
             float vb = e->speed[foll_t] - dec; if (vb < 0.0f) vb = 0.0f;
             if (gap < 0.0f || vb > orc_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = 0;
         }
-        if (safe) { if (dir == dir_allowed) e->lc_target[s] = tl; continue; }
+        if (safe) {
+            /* (a vehicle that leaves its lane in this tick changes lanes on the next edge, if at all: its plan looked at the
+             *  links of the lane it is on) */
+            if (dir == dir_allowed && !(x + e->vnext[s] > sc->lane_len[lane])) e->lc_target[s] = tl;
+            continue;
+        }
         if (want == 2 && lead_t != NIL) { e->coop_lead[s] = lead_t; e->coop_lead_trip[s] = trip_of_slot(e, lead_t); }
         if (want == 2) {
             /* blocked: ask the nearest vehicle of the target lane that is completely behind me to let me in */
@@ -697,24 +733,28 @@ static void lane_change(orc_env *e) {
             }
         }
     }
-}
-static void lane_change_apply(orc_env *e) {
-    for (int32_t s = 0; s < e->hw; ++s) {
-        if (e->lane[s] >= LANE_PENDING) continue;
-        if (e->lc_target[s] >= 0) e->lane[s] = (uint16_t)e->lc_target[s];
+    /* mutual blocks: the test is symmetric, so both vehicles reach the same verdict (whatever this tick's direction is) */
+    for (int32_t s = 0; s < e->hw && e->t % RM_SWAP_EVERY == 0; ++s) {
+        int32_t d = swap_dir(e, s);
+        if (d == 0 || e->lc_target[s] >= 0) continue;
+        int32_t lane = e->lane[s], tl = lane + d;
+        int32_t b = overlapping(e, s, tl);
+        if (b == NIL || swap_dir(e, b) != -d) continue;
+        if (overlapping(e, b, lane) != s) continue;
+        e->lc_target[s] = tl;
     }
 }
-
+/* One tick.  All decisions of a tick -- speeds, lane changes, insertions -- are taken on the state at its beginning and
+ * executed together (SUMO executes the moves before it decides the lane changes; with both on one state the data-parallel
+ * implementation needs half the synchronisation points). */
 void orc_tick(orc_env *e) {
     tls_events(e);
     build_lists(e);
     register_approaches(e);
-    plan(e);
-    move(e);
-    build_lists(e);
-    lane_change(e);         /* decisions + cooperation requests on the moved state ... */
-    insertion_check(e);     /* ... and, on the same state, which departure lanes have room */
-    lane_change_apply(e);
+    plan(e);                /* next speeds */
+    lane_change(e);         /* lane-change decisions + cooperation requests ... */
+    insertion_check(e);     /* ... and which departure lanes have room, all on the same state */
+    move(e);                /* sideways (lane change), forward, lane hand-over, arrival */
     insertion_apply(e);
     e->t += 1;
     e->stats[9] += 1;

@@ -40,7 +40,9 @@ __device__ __forceinline__ void rs_atomic_min(int32_t *p, int32_t v) { atomicMin
 __device__ __forceinline__ void rs_atomic_min(uint32_t *p, uint32_t v) { atomicMin(p, v); }
 __device__ __forceinline__ void rs_atomic_max(int32_t *p, int32_t v) { atomicMax(p, v); }
 __device__ __forceinline__ void rs_atomic_add(int32_t *p, int32_t v) { atomicAdd(p, v); }
+__device__ __forceinline__ int32_t rs_atomic_fetch_add(int32_t *p, int32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void rs_atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+__device__ __forceinline__ uint32_t rs_atomic_fetch_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 __device__ __forceinline__ int rs_atomic_inc(int32_t *p) { return atomicAdd(p, 1); }
 __device__ __forceinline__ void rs_atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
 __device__ __forceinline__ uint32_t rs_atomic_cas(uint32_t *p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
@@ -88,7 +90,7 @@ rs_step_kernel_v64(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ action
     rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
 }
 template <int CAP>
-__global__ void __launch_bounds__(512, 6)
+__global__ void __launch_bounds__(768, 6)
 rs_step_kernel_v80(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
     if ((int)blockIdx.x >= P.n_envs) return;
     const StepArgs *A = (const StepArgs *)Ac;
@@ -114,7 +116,7 @@ __global__ void rs_reset_kernel(KTab T, State G, KParams P) {
         G.lane()[eo + s] = LANE_NONE; G.trip()[eo + s] = TRIP_NONE; G.owner()[eo + s] = OWNER_NONE;
         G.rwait()[eo + s] = 0; G.swait()[eo + s] = 0; G.cursor()[eo + s] = 0; G.depart()[eo + s] = 0; G.wtot()[eo + s] = 0;
         G.pos()[eo + s] = 0.0f; G.speed()[eo + s] = 0.0f; G.accel()[eo + s] = 0.0f; G.tloss()[eo + s] = 0.0f; G.sf()[eo + s] = 1.0f;
-        G.coop()[eo + s] = COOP_NONE; G.cooplead()[eo + s] = COOP_NONE;
+        G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE;
     }
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         int ph, left;
@@ -369,8 +371,8 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     if (p->trip_log && (rc = dev_alloc(h, &G.trip_log, N * (size_t)sc->n_trips * 4))) return fail(rc);
     set_buf(h, RS_BUF_TRIP_LOG, G.trip_log, RS_I32, 3, n, p->trip_log ? sc->n_trips : 0, 4);
     set_buf(h, RS_BUF_DEP_NEXT, G.dep_next, RS_U16, 2, n, h->K.n_dep);
-    set_buf(h, RS_BUF_VEH_COOP, G.coop(), RS_U32, 2, n, c);
-    set_buf(h, RS_BUF_VEH_COOPLEAD, G.cooplead(), RS_U32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_COOP, G.coop(0), RS_U32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_COOPLEAD, G.cooplead(0), RS_U32, 2, n, c);
     set_buf(h, RS_BUF_ARRIVALS, O.arrivals(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_DEPARTURES, O.departures(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_MPLIGHT_FULL, O.mplight_full(), RS_F32, 3, n, s, 49);
@@ -386,7 +388,10 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         block_threads = C > 512 ? 512 : C;
         h->use_v128 = 2;
     }
-    if (block_threads % 64 || block_threads > (h->use_v128 ? 512 : 1024) || block_threads < 64) { h->err = "block_threads must be a multiple of 64 in [64, 1024] ([64, 512] for the 128-VGPR build)"; return fail(RS_EINVAL); }
+    if (block_threads % 64 || block_threads > (h->use_v128 == 1 ? 512 : (h->use_v128 == 2 ? 768 : 1024)) || block_threads < 64) {
+        h->err = "block_threads must be a multiple of 64 in [64, 1024] ([64, 768] for the 80-VGPR build, [64, 512] for the 128-VGPR build)";
+        return fail(RS_EINVAL);
+    }
     h->block = block_threads;
     {
         // the dynamic-LDS ceiling is an attribute of the kernel (per device), not of a launch: only ever raise it,

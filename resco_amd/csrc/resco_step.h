@@ -30,8 +30,10 @@ struct State {      // env-major SoA in HBM: field[env][slot]
     RS_HD float *accel() const { return RS_G((float *)(base + 8 * nc)); }
     RS_HD float *tloss() const { return RS_G((float *)(base + 12 * nc)); }
     RS_HD float *sf() const { return RS_G((float *)(base + 16 * nc)); }
-    RS_HD uint32_t *coop() const { return RS_G((uint32_t *)(base + 20 * nc)); }
-    RS_HD uint32_t *cooplead() const { return RS_G((uint32_t *)(base + 24 * nc)); }
+    // cooperation requests, double-buffered by tick parity: the lane-change decisions of tick t write buffer t & 1 while the
+    // plans of the same phase read (and clear) the requests of tick t - 1 in the other one
+    RS_HD uint32_t *coop(int par) const { return RS_G((uint32_t *)(base + (par ? 43 : 20) * nc)); }
+    RS_HD uint32_t *cooplead(int par) const { return RS_G((uint32_t *)(base + (par ? 47 : 24) * nc)); }      // (the same)
     RS_HD uint16_t *lane() const { return RS_G((uint16_t *)(base + 28 * nc)); }
     RS_HD uint16_t *trip() const { return RS_G((uint16_t *)(base + 30 * nc)); }
     RS_HD uint16_t *cursor() const { return RS_G((uint16_t *)(base + 32 * nc)); }
@@ -40,7 +42,7 @@ struct State {      // env-major SoA in HBM: field[env][slot]
     RS_HD uint16_t *depart() const { return RS_G((uint16_t *)(base + 38 * nc)); }
     RS_HD uint16_t *wtot() const { return RS_G((uint16_t *)(base + 40 * nc)); }
     RS_HD uint8_t *owner() const { return RS_G((uint8_t *)(base + 42 * nc)); }
-    static size_t bytes(size_t nc_) { return 43 * nc_; }
+    static size_t bytes(size_t nc_) { return 51 * nc_; }
 };
 
 struct Out {        // one allocation; n = N, o = n_obs, s = n_signals, lm = lanes of the largest signal
@@ -131,10 +133,27 @@ struct __attribute__((aligned(16))) Node {      // everything a NEIGHBOUR wants 
     uint16_t trip;      // TRIP_NONE: free slot
     uint16_t nxt;       // next vehicle of the same grid cell (unordered), NIL terminated
     uint8_t vt;         // vType
-    uint8_t pad[3];
+    uint8_t fl;         // scheduling hints, see FL_* (they decide WHICH thread handles the vehicle, never what is computed)
+    uint8_t pad[2];
 };
+// A wave executes every branch that ANY of its 64 lanes takes, so the rare, long code paths (junction look-ahead, lane-change
+// searches, hand-over / arrival) are not left scattered over all waves: the vehicles that need them are queued in short
+// lists and handled by consecutive threads, after the threads have gone through their own slots on the short path.
+#define FL_H 1          // the plan must look beyond the end of the lane (set when the vehicle is moved / loaded / inserted)
+#define FL_MH 2         // this tick's move leaves the lane, forward or sideways (even ticks)
+#define FL_LC 4         // this tick's lane-change decision needs neighbour searches
+#define FL_MH1 8        // FL_MH of odd ticks.  Two bits by tick parity: the move phase must not clear the bit it tests (a thread may
+                        // look at its own slot after the list's thread has moved the vehicle); the next plan drops the old one
+RS_DEV int fl_mh(int t) { return (t & 1) ? FL_MH1 : FL_MH; }
+// Aux.lct, the lane-change decision of the tick: a change that holds unless the vehicle leaves its lane forward in the same
+// tick (LCT_LEFT / LCT_RIGHT), and / or a swap with the vehicle alongside, which holds in any case
+#define LCT_LEFT 1
+#define LCT_RIGHT 2
+#define LCT_SWAP_LEFT 4
+#define LCT_SWAP_RIGHT 8
 struct __attribute__((aligned(8))) Aux {        // what only the owner reads, every tick: one 8-byte read
-    uint16_t lane, rq, nlink, cell;
+    uint16_t lane, rq, nlink;
+    uint16_t lct;       // lane-change decision of this tick (LCT_*, 0: stay)
 };
 // The layout (a table of offsets, computed once by the host: lds_carve) is read from the constant argument block.
 // An array of the working memory is addressed as (RS_SMEM + offset): the including file defines RS_SMEM as THE shared
@@ -149,25 +168,32 @@ struct Lds {
     LPtr<Node> node;
     LPtr<Aux> aux;
     LPtr<float> vnx, vtp;
-    LPtr<uint16_t> grid;        // the cells (bit 15: the cell holds a moving vehicle)
+    LPtr<uint16_t> grid;        // TWO grids of cells (bit 15 of a cell: it holds a moving vehicle): a tick reads the grid of its
+                                // parity and builds the other one while it moves the vehicles
+    uint32_t gstride;           // cells per grid (padded)
     LPtr<int32_t> arr;          // link approach registers
     LPtr<uint16_t> dep;         // head trip of every departure lane's backlog
-    LPtr<uint32_t> alive, insm; // bit per slot: occupied; bit per departure lane: inserts this tick
+    LPtr<uint32_t> alive, alive0, insm;     // bit per slot: occupied (now / at the beginning of the tick); bit per departure lane: inserts this tick
     LPtr<int32_t> agg_q, agg_a, agg_w, agg_m;
     LPtr<uint32_t> agg_s;
     LPtr<int32_t> sig_arr, sig_dep;
     LPtr<int32_t> phase, left, nextp;
     LPtr<uint8_t> tstate;       // current link states of every signal, [S][tls_maxl]
     LPtr<int32_t> sc;           // scalars, see SC_*
+    LPtr<uint16_t> ls_h, ls_lc, ls_mh;      // work lists (slots), `lcap` entries each; a list that overflows is ignored and
+    uint32_t lcap;                          // the phase falls back to the flags (every thread handles its own slots in full)
 };
 #define SC_T 0
 #define SC_NINS 1
 #define SC_HW 2
 #define SC_NACT 3
 #define SC_HWNEW 4
-#define SC_REBUILD 5
-#define SC_STATS 6
-#define CELL_NEW 0xFFFEu        // L.cell value of a slot that was filled by an insertion in this tick's A1 phase
+#define SC_ROOM 5
+#define SC_HWOUT 6
+#define SC_NH 7         // entries of ls_h (may exceed lcap: overflow)
+#define SC_NLC 8
+#define SC_NMH 9        // two counters, by tick parity (the plan of tick t + 1 queues while nothing separates it from the move of t)
+#define SC_STATS 11
 
 RS_CARVE size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // Layout of the working memory: a table of offsets computed once by the host (read from the constant argument block, so an
@@ -188,19 +214,34 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
         o += align16(a > b ? a : b);
     }
     CARVE(sc, (size_t)(SC_STATS + ST_N) * 4)
-    CARVE(alive, (size_t)((C + 31) / 32) * 4)
+    CARVE(alive, (size_t)((C + 31) / 32) * 4) CARVE(alive0, (size_t)((C + 31) / 32) * 4)
     CARVE(insm, (size_t)((n_dep + 31) / 32) * 4)
     CARVE(vtp, (size_t)n_vt * VT_COLS * 4)
     CARVE(phase, (size_t)S * 4) CARVE(left, (size_t)S * 4) CARVE(nextp, (size_t)S * 4)
     CARVE(sig_arr, (size_t)S * 4) CARVE(sig_dep, (size_t)S * 4)
     CARVE(tstate, (size_t)S * tls_maxl)
-    CARVE(grid, (size_t)(n_cells + 8) * 2)
+    if (L) L->gstride = (uint32_t)((n_cells + 8 + 7) & ~7);
+    CARVE(grid, (size_t)((n_cells + 8 + 7) & ~7) * 2 * 2)
     CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2)
+    {
+#ifdef RS_LIST_CAP                  // (tests: lists so short that they overflow all the time)
+        const int cap = RS_LIST_CAP;
+#else
+        const int cap = ((C / 4 + 63) / 64) * 64;
+#endif
+        if (L) L->lcap = (uint32_t)cap;
+        CARVE(ls_h, (size_t)cap * 2) CARVE(ls_lc, (size_t)cap * 2) CARVE(ls_mh, (size_t)cap * 2)
+    }
 #undef CARVE
     return o;
 }
 
 // ------------------------------------------------------------------------------------------------ grid primitives
+#ifdef RS_EMU_DEBUG         // host emulation, debug build: a chain that does not end means a vehicle entered a grid twice
+#define RS_CHAIN_GUARD if (++rs_dbg_chain > 50000000L) { printf("endless chain walk\n"); fflush(stdout); abort(); }
+#else
+#define RS_CHAIN_GUARD
+#endif
 RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
 RS_DEV int lane_cells(const LaneRec &LR) { return (int)(LR.len * CELL_INV) + 1; }
 RS_DEV int cell_of(float pos, int ncell) { const int c = (int)(pos * CELL_INV); return c < ncell ? c : ncell - 1; }
@@ -264,7 +305,7 @@ RS_DEV bool cells_have_mover(const uint16_t *grid, int c0, int nc) {
 RS_DEV int chain_rearmost(const Lds &L, int head) {
     int best = NIL, bk = 0;
     float bp = 0.0f;
-    for (int s = head & 0x7FFF; s != NIL;) {
+    for (int s = head & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         if (best == NIL || nd.pos < bp || (nd.pos == bp && (int)nd.trip > bk)) { best = s; bk = nd.trip; bp = nd.pos; }
         s = nd.nxt;
@@ -275,7 +316,7 @@ RS_DEV int chain_rearmost(const Lds &L, int head) {
 RS_DEV int chain_frontmost(const Lds &L, int head) {
     int best = NIL, bk = 0;
     float bp = 0.0f;
-    for (int s = head & 0x7FFF; s != NIL;) {
+    for (int s = head & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         if (best == NIL || ahead_of(nd.pos, nd.trip, bp, bk)) { best = s; bk = nd.trip; bp = nd.pos; }
         s = nd.nxt;
@@ -283,19 +324,19 @@ RS_DEV int chain_frontmost(const Lds &L, int head) {
     return best;
 }
 // rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
-RS_DEV int rearmost_within(const Lds &L, int cell0, int ncell, float win) {
+RS_DEV int rearmost_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float win) {
     if (win < 0.0f) return NIL;
-    const int c = scan_up(L.grid, cell0, cell0 + cell_of(win, ncell));
+    const int c = scan_up(grid, cell0, cell0 + cell_of(win, ncell));
     if (c < 0) return NIL;
-    const int o = chain_rearmost(L, L.grid[c]);
+    const int o = chain_rearmost(L, grid[c]);
     return (o != NIL && L.node[o].pos > win) ? NIL : o;
 }
 // nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front)
-RS_DEV int leader_within(const Lds &L, int cell0, int ncell, float pos, int k, int self, float win) {
+RS_DEV int leader_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(pos, ncell);
     int Ld = NIL, Lk = 0;
     float Lp = 0.0f;
-    for (int s = L.grid[cell0 + c] & 0x7FFF; s != NIL;) {        // my own cell first
+    for (int s = grid[cell0 + c] & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD        // my own cell first
         const Node nd = L.node[s];
         const int cur = s;
         s = nd.nxt;
@@ -303,18 +344,18 @@ RS_DEV int leader_within(const Lds &L, int cell0, int ncell, float pos, int k, i
         if (ahead_of(nd.pos, nd.trip, pos, k) && (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip))) { Ld = cur; Lk = nd.trip; Lp = nd.pos; }
     }
     if (Ld == NIL && c + 1 < ncell) {
-        const int cc = scan_up(L.grid, cell0 + c + 1, cell0 + cell_of(pos + win, ncell));
-        if (cc >= 0) { Ld = chain_rearmost(L, L.grid[cc]); Lp = L.node[Ld].pos; }
+        const int cc = scan_up(grid, cell0 + c + 1, cell0 + cell_of(pos + win, ncell));
+        if (cc >= 0) { Ld = chain_rearmost(L, grid[cc]); Lp = L.node[Ld].pos; }
     }
     if (Ld != NIL && Lp - pos > win) Ld = NIL;
     return Ld;
 }
 // nearest vehicle behind (pos, k) on the lane (not `self`), at most `win` metres away
-RS_DEV int follower_within(const Lds &L, int cell0, int ncell, float pos, int k, int self, float win) {
+RS_DEV int follower_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(pos, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
-    for (int s = L.grid[cell0 + c] & 0x7FFF; s != NIL;) {
+    for (int s = grid[cell0 + c] & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         const int cur = s;
         s = nd.nxt;
@@ -323,27 +364,27 @@ RS_DEV int follower_within(const Lds &L, int cell0, int ncell, float pos, int k,
     }
     if (Fd == NIL && c > 0) {
         const float lo = pos - win;
-        const int cc = scan_down(L.grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) { Fd = chain_frontmost(L, L.grid[cc]); Fp = L.node[Fd].pos; }
+        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
+        if (cc >= 0) { Fd = chain_frontmost(L, grid[cc]); Fp = L.node[Fd].pos; }
     }
     if (Fd != NIL && pos - Fp > win) Fd = NIL;
     return Fd;
 }
 // nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
-RS_DEV int at_or_behind_within(const Lds &L, int cell0, int ncell, float back, float win) {
+RS_DEV int at_or_behind_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float back, float win) {
     if (back < 0.0f) return NIL;
     const int c = cell_of(back, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
-    for (int s = L.grid[cell0 + c] & 0x7FFF; s != NIL;) {
+    for (int s = grid[cell0 + c] & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         if (!(nd.pos > back) && (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk))) { Fd = s; Fk = nd.trip; Fp = nd.pos; }
         s = nd.nxt;
     }
     if (Fd == NIL && c > 0) {
         const float lo = back - win;
-        const int cc = scan_down(L.grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) { Fd = chain_frontmost(L, L.grid[cc]); Fp = L.node[Fd].pos; }
+        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
+        if (cc >= 0) { Fd = chain_frontmost(L, grid[cc]); Fp = L.node[Fd].pos; }
     }
     if (Fd != NIL && back - Fp > win) Fd = NIL;
     return Fd;
@@ -361,13 +402,13 @@ RS_DEV uint16_t cache_link(const KTab &T, const LaneRec &LR, int lane, int rq, i
     if (LR.flags & LF_INTERNAL) { const int l = LR.link_start; return (uint16_t)(l | (T.links()[l].arr_idx >= 0 ? NLINK_ARR : 0)); }
     return T.next_link()[((size_t)rq * T.kmax + (lane - (int)LR.edge_lane0)) * 2 + (trip & 1)];
 }
-RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const LinkRec &K) {
+RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const uint16_t *grid, const LinkRec &K) {
     for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
         const FoeRec F = T.foes()[i];
         if (F.tls != 0xFF && tls_state(T, L, F.tls, F.tls_pos) == TLS_R) continue;
         if (F.arr_idx >= 0 && L.arr[F.arr_idx] < RM_FOE_GAP_Q) return true;
-        if (F.via1_cell0 != 0xFFFF && cells_have_mover(L.grid, F.via1_cell0, F.via1_nc)) return true;   // a moving vehicle on
-        if (F.via2_cell0 != 0xFFFF && cells_have_mover(L.grid, F.via2_cell0, F.via2_nc)) return true;   // the foe's junction lanes
+        if (F.via1_cell0 != 0xFFFF && cells_have_mover(grid, F.via1_cell0, F.via1_nc)) return true;   // a moving vehicle on
+        if (F.via2_cell0 != 0xFFFF && cells_have_mover(grid, F.via2_cell0, F.via2_nc)) return true;   // the foe's junction lanes
     }
     return false;
 }
@@ -417,20 +458,16 @@ RS_DEV int strategic_dir(const KTab &T, int rq, int kk, int n, float x, float v,
     if (rem >= la * (float)off) return 0;
     return (dr <= dl) ? -1 : +1;
 }
-// approach registration of slot s for the coming tick (P3): a moving vehicle whose next link somebody may have to yield
-// to registers its arrival time there
-RS_DEV void register_approach(const KTab &T, const Lds &L, int s) {
-    const int lane = L.aux[s].lane;
-    if (lane == (int)LANE_NONE) return;
-    const int nlk = L.aux[s].nlink;
+// approach registration for the coming tick (P3): a moving vehicle whose next link somebody may have to yield to registers
+// its arrival time there (v, pos, vType, lane length and next link of the vehicle AFTER this tick's move)
+RS_DEV void register_approach(const KTab &T, const Lds &L, int nlk, float v, float pos, float lane_len, int vt) {
     if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
-    const float v = L.node[s].speed;
     if (v <= RM_HALT_SPEED) return;
     const LinkRec K = T.links()[nlk & 0x7FFF];
     const int st = tls_state(T, L, K.tls, K.tls_pos);
     if (st == TLS_R) return;
-    const float dist = T.lanes()[lane].len - L.node[s].pos;
-    if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[L.node[s].vt * VT_COLS + VT_DECEL])) return;
+    const float dist = lane_len - pos;
+    if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[vt * VT_COLS + VT_DECEL])) return;
     const float ta = dist / (v > 1.0f ? v : 1.0f);
     const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
     rs_atomic_min(&L.arr[K.arr_idx], q);
@@ -457,9 +494,56 @@ RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool cla
     (void)lane;
 }
 
+// mark slot s as one whose move of tick t is a long one and queue it (the plan's thread and the lane-change thread of a
+// vehicle may both do it, at the same time: an atomic OR on the dword that holds Node.fl decides who queues it)
+RS_DEV void list_push(const Lds &L, const LPtr<uint16_t> &list, int counter, int s);
+RS_DEV void flag_mover(const Lds &L, int s, int t) {
+    uint32_t *w = (uint32_t *)((Node *)L.node + s) + 3;
+    const uint32_t bit = (uint32_t)fl_mh(t) << 8;
+    if (!(rs_atomic_fetch_or(w, bit) & bit)) list_push(L, L.ls_mh, SC_NMH + (t & 1), s);
+}
+// queue slot s in a work list (best effort: the flag in Node.fl is what counts, see the phases)
+RS_DEV void list_push(const Lds &L, const LPtr<uint16_t> &list, int counter, int s) {
+    const int i = rs_atomic_fetch_add(&L.sc[counter], 1);
+    if (i < (int)L.lcap) list[i] = (uint16_t)s;
+}
+// how far the plan of a vehicle looks ahead (speed v on a lane with limit vmax, speed factor sf): its free speed and the
+// distance within which a leader or a stop line matters
+RS_DEV float plan_vfree(const float *vt, float v, float lane_vmax, float sf) {
+    float vfree = v + vt[VT_ACCEL];
+    const float vl = lane_vmax * sf;
+    if (vl < vfree) vfree = vl;
+    if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
+    return vfree;
+}
+RS_DEV float plan_look(const float *vt, float vfree) { return d_brake_gap(vfree, vt[VT_DECEL]) + vfree * vt[VT_TAU] + vt[VT_MINGAP] + 1.0f; }
+// FL_H for a vehicle at x on a lane of length len: the end of the lane is inside its look-ahead
+RS_DEV bool looks_beyond(const float *vt, float v, float x, float lane_len, float lane_vmax, float sf) {
+    return lane_len - x < plan_look(vt, plan_vfree(vt, v, lane_vmax, sf));
+}
+// can the lane-change decision of tick t have an effect for a vehicle in this state?  (a superset: a strategic need, or its
+// turn to look for speed gain on a neighbour lane that is good enough)
+RS_DEV bool may_change_lanes(const KTab &T, const LaneRec &LR, int lane, int rq, int k, float x, float v, int t) {
+    const int n = LR.flags >> 2;
+    if ((LR.flags & LF_INTERNAL) || n < 2) return false;
+    const int kk = lane - (int)LR.edge_lane0;
+    float rem;
+    if (strategic_dir(T, rq, kk, n, x, v, 0, rem) != 0) return true;
+    if ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) return false;
+    const int tk = kk + ((t & 1) ? -1 : +1);
+    return tk >= 0 && tk < n && strategic_dir(T, rq, tk, n, x, v, RM_SG_EXTRA_LANES, rem) == 0;
+}
+// The work of tick t for the vehicle in slot s (state as of the beginning of that tick): its flags, and it is queued
+RS_DEV int classify(const KTab &T, const Lds &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, int rq, int k, float sf, int t) {
+    int fl = 0;
+    if (looks_beyond(vt, v, x, LR.len, LR.vmax, sf)) { fl |= FL_H; list_push(L, L.ls_h, SC_NH, s); }
+    if (may_change_lanes(T, LR, lane, rq, k, x, v, t)) { fl |= FL_LC; list_push(L, L.ls_lc, SC_NLC, s); }
+    return fl;
+}
+
 // ------------------------------------------------------------------------------------------------ the phases
 // P: plan (Krauss car-following + links) for slot s
-RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
+RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
     const Aux ax = L.aux[s];
     const int lane = ax.lane;
     if (lane == (int)LANE_NONE) return;
@@ -468,24 +552,18 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
     const float *vt = L.vtp + me.vt * VT_COLS;
     const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
     const float v = me.speed, x = me.pos;
-#ifdef RS_DIAG_NOGLOBAL
-    const float sf = 1.0f; const uint32_t c2 = COOP_NONE;
-#else
     const float sf = G.sf()[eo + s];
-    const uint32_t c2 = G.cooplead()[eo + s];
-#endif
-    LaneRec LR = T.lanes()[lane];
-    float vfree = v + a;
-    const float vl = LR.vmax * sf;
-    if (vl < vfree) vfree = vl;
-    if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
+    const uint32_t c2 = G.cooplead((t + 1) & 1)[eo + s];
+    const LaneRec LR0 = T.lanes()[lane];
+    LaneRec LR = LR0;
+    const float vfree = plan_vfree(vt, v, LR.vmax, sf);
     float vsafe = RM_BIGF;
     // The look-ahead only FINDS what limits the vehicle (a leader, or a stop line = a standing leader of zero length):
     // the Krauss safe speed is evaluated once, by all lanes together, after the walk.
     float tgap = 0.0f, tvl = 0.0f, tbl = b;
     bool have = false;
-    const float look = d_brake_gap(vfree, b) + vfree * tau + mingap + 1.0f;
-    const int lead = leader_within(L, LR.cell0, lane_cells(LR), x, k, s, look + T.maxlen);
+    const float look = plan_look(vt, vfree);
+    const int lead = leader_within(L, grid, LR.cell0, lane_cells(LR), x, k, s, look + T.maxlen);
     bool found = false;
     if (lead != NIL) {
         const Node ld = L.node[lead];
@@ -495,18 +573,11 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
         have = true; found = true;
     }
     {   // cooperation: requests of the last lane-change phase
-#ifdef RS_DIAG_NOGLOBAL
-        const uint32_t c1 = COOP_NONE;
-#else
-        const uint32_t c1 = G.coop()[eo + s];        // (in HBM: written rarely, by other threads, with a global atomic)
-#endif
-        if (c1 != COOP_NONE) { G.coop()[eo + s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
-        if (c2 != COOP_NONE) { G.cooplead()[eo + s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
+        const uint32_t c1 = G.coop((t + 1) & 1)[eo + s];  // (in HBM: written rarely, by other threads, with a global atomic)
+        if (c1 != COOP_NONE) { G.coop((t + 1) & 1)[eo + s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
+        if (c2 != COOP_NONE) { G.cooplead((t + 1) & 1)[eo + s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
     }
     float seen = LR.len - x;
-#ifdef RS_DIAG_NOHOP
-    found = true;
-#endif
     if (!found && seen < look) {
         int rq = ax.rq;
         int link = (int)(ax.nlink & 0x7FFF);
@@ -528,7 +599,7 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
                 if (!stop_here && !(K.flags & KF_CONT) && ((K.flags & KF_MINOR) || (K.tls != 0xFF && st == TLS_g))) {
                     // a minor link is approached ready to stop until the foe lanes can be seen
                     if (seen > RM_VIS_DIST) stop_here = true;
-                    else if (K.foe_cnt > 0 && foe_blocked(T, L, K)) stop_here = true;
+                    else if (K.foe_cnt > 0 && foe_blocked(T, L, grid, K)) stop_here = true;
                 }
             }
             if (stop_here) {
@@ -546,7 +617,7 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
                     if (vs < vsafe) vsafe = vs;
                 }
             }
-            const int o = rearmost_within(L, LR.cell0, lane_cells(LR), look - seen + T.maxlen);
+            const int o = rearmost_within(L, grid, LR.cell0, lane_cells(LR), look - seen + T.maxlen);
             if (o != NIL) {
                 const Node od = L.node[o];
                 const float *vo = L.vtp + od.vt * VT_COLS;
@@ -577,36 +648,65 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const State &G, size_t eo, c
         if (vd < a) vd -= sigma * vd * r; else vd -= sigma * a * r;
         if (vd < 0.0f) vd = 0.0f;
     }
-    L.vnx[s] = vd > vmin ? vd : vmin;
+    const float vnext = vd > vmin ? vd : vmin;
+    L.vnx[s] = vnext;
+#ifdef RS_EMU_DEBUG
+    if (s == rs_dbg_slot && (t == rs_dbg_t || rs_dbg_t < 0))
+        printf("plan t %d slot %d lane %d x %.3f v %.3f lead %d have %d tgap %.3f tvl %.3f vsafe %.3f vfree %.3f vnext %.3f nlink %x\n", t, s, lane, x, v, lead,
+               (int)have, tgap, tvl, vsafe, vfree, vnext, ax.nlink);
+#endif
+    if (x + vnext > LR0.len) flag_mover(L, s, t);
+    (void)LR;
 }
 
-// M: move slot s, hand it over to the next lanes, let it arrive; register it in the grid of the moved state
-RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParams &P, int env, size_t eo, int t, bool last_tick, int s,
-                       int &active, int &halted, int &top) {
+// M: move slot s -- sideways first (the lane change decided in the plan phase), then forward, over to the next lanes, or
+// out of the network; leave the old grid, enter the new one; register the approach of the coming tick
+RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gnew, const State &G, const KParams &P, int env, size_t eo,
+                       int t, bool last_tick, bool more, int s, int &active, int &halted, int &top) {
     const Aux ax = L.aux[s];
-    int lane = ax.lane;
-    if (lane == (int)LANE_NONE) return;
     const Node me = L.node[s];
     const int k = me.trip;
-    int link = (int)(ax.nlink & 0x7FFF);
+    int lane = ax.lane;
+#ifdef RS_EMU_DEBUG
+    {
+        static int moved_at[65536];
+        if (moved_at[s] == t + 1) { printf("slot %d moved twice in tick %d: fl %x lane %d trip %d\n", s, t, me.fl, lane, k); fflush(stdout); abort(); }
+        moved_at[s] = t + 1;
+    }
+#endif
     LaneRec LR = T.lanes()[lane];
+    const float sfv = G.sf()[eo + s];
+    float tl = G.tloss()[eo + s];
+    const int sw = G.swait()[eo + s];
     const float vn = L.vnx[s];
-    const float vref = LR.vmax * G.sf()[eo + s];
+    gold[LR.cell0 + cell_of(me.pos, lane_cells(LR))] = NIL;         // every vehicle of a cell stores the same: the old grid empties
+    int rq = ax.rq;
+    int link = (int)(ax.nlink & 0x7FFF);
+    bool relink = false;
+    int side = 0;
+    if (ax.lct) {
+        if ((ax.lct & (LCT_LEFT | LCT_RIGHT)) && !(me.pos + vn > LR.len)) side = (ax.lct & LCT_LEFT) ? +1 : -1;
+        else if (ax.lct & (LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) side = (ax.lct & LCT_SWAP_LEFT) ? +1 : -1;
+    }
+    if (side) {
+        lane += side;
+        LR = T.lanes()[lane];
+        link = (int)(cache_link(T, LR, lane, rq, k) & 0x7FFF);
+        relink = true;
+    }
+    const float vref = LR.vmax * sfv;
     if (last_tick) G.accel()[eo + s] = vn - me.speed;
     if (vn <= RM_HALT_SPEED) {
-        const int w = G.swait()[eo + s]; if (w < 65535) G.swait()[eo + s] = (uint16_t)(w + 1);
+        if (sw < 65535) G.swait()[eo + s] = (uint16_t)(sw + 1);
         halted += 1;
         if (G.trip_log) { const int wt = G.wtot()[eo + s]; if (wt < 65535) G.wtot()[eo + s] = (uint16_t)(wt + 1); }
-    } else G.swait()[eo + s] = 0;
-    float tl = G.tloss()[eo + s];
+    } else if (sw != 0) G.swait()[eo + s] = 0;
     if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss()[eo + s] = tl; }
     float x = me.pos + vn;
-    int rq = ax.rq;
-    bool arrived = false, moved = false;
+    bool arrived = false;
     for (int it = 0; it < 16; ++it) {
         if (!(x > LR.len)) break;
         const bool li = (LR.flags & LF_INTERNAL) != 0;
-        if (moved) link = (int)(cache_link(T, LR, lane, rq, k) & 0x7FFF);
         if (link == NLINK_NONE) {
             if (!li && T.rsteps()[rq].next_edge == 0xFFFF) arrived = true; else x = LR.len;
             break;
@@ -618,11 +718,14 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParam
             lane = Km.to_lane;
             LR = Km.dest;
         }
-        moved = true;
+        link = (int)(cache_link(T, LR, lane, rq, k) & 0x7FFF);
+        relink = true;
     }
     if (arrived) {
-        L.aux[s].lane = LANE_NONE; L.node[s].trip = TRIP_NONE; L.aux[s].cell = 0xFFFF;
-        G.coop()[eo + s] = COOP_NONE; G.cooplead()[eo + s] = COOP_NONE;
+        Aux na = ax; na.lane = LANE_NONE; na.lct = 0;
+        L.aux[s] = na;
+        L.node[s].trip = TRIP_NONE; L.node[s].fl = (uint8_t)(me.fl & fl_mh(t));
+        G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE;
         rs_atomic_and(&L.alive[s >> 5], ~(1u << (s & 31)));
         {   // Signal.departures of the signal that observed the vehicle last (traffic_signal.py:226-232)
             const int ow = G.owner()[eo + s];
@@ -640,34 +743,41 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, const State &G, const KParam
         return;
     }
     active += 1;
-    top = s + 1;
-    const int c = LR.cell0 + cell_of(x, lane_cells(LR));
+    if (s + 1 > top) top = s + 1;
     Aux na = ax;
-    if (moved) { na.lane = (uint16_t)lane; na.rq = (uint16_t)rq; na.nlink = cache_link(T, LR, lane, rq, k); }
-    na.cell = (uint16_t)c;
+    na.lane = (uint16_t)lane; na.rq = (uint16_t)rq; na.lct = 0;
+    if (relink) na.nlink = cache_link(T, LR, lane, rq, k);
     L.aux[s] = na;
     Node nn = me;
-    nn.pos = x; nn.speed = vn;
-    nn.nxt = grid_push(L.grid, c, s, vn > RM_HALT_SPEED);
-    L.node[s] = nn;
+    nn.pos = x; nn.speed = vn; nn.fl = (uint8_t)(me.fl & fl_mh(t));
+    nn.nxt = grid_push(gnew, LR.cell0 + cell_of(x, lane_cells(LR)), s, vn > RM_HALT_SPEED);
+    if (more) {
+        nn.fl |= classify(T, L, s, L.vtp + me.vt * VT_COLS, vn, x, LR, lane, rq, k, sfv, t + 1);
+        L.node[s] = nn;
+        register_approach(T, L, na.nlink, vn, x, LR.len, me.vt);
+    } else L.node[s] = nn;
     (void)P;
 }
 
-// D: lane-change decision of slot s on the moved state; returns the target lane (-1: stay).  A blocked strategic
-// changer asks for cooperation (oracle: lane_change()).
-RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const State &G, size_t eo, int t, int s) {
-#ifdef RS_DIAG_NOLC
-    return -1;
-#endif
-    const Aux ax = L.aux[s];
+// the vehicle on the lane with cells [cell0, cell0 + ncell) whose body overlaps the one at (pos, k) lengthwise (the nearer one
+// ahead first), NIL: none
+RS_DEV int overlapping(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float len_self) {
+    const int lead = leader_within(L, grid, cell0, ncell, pos, k, self, RM_NB_WINDOW);
+    if (lead != NIL && L.node[lead].pos - L.vtp[L.node[lead].vt * VT_COLS + VT_LENGTH] - pos < 0.0f) return lead;
+    const int foll = follower_within(L, grid, cell0, ncell, pos, k, self, RM_NB_WINDOW);
+    if (foll != NIL && pos - len_self - L.node[foll].pos < 0.0f) return foll;
+    return NIL;
+}
+
+// The lane-change decision of slot s on the state at the beginning of the tick: returns LCT_* (0: stay).  A blocked strategic
+// changer asks for cooperation; a mutual block is swapped out (oracle: lane_change())
+RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, int t, int s, const Aux &ax, const Node &me,
+                           const LaneRec &LR) {
     const int lane = ax.lane;
-    if (lane == (int)LANE_NONE) return -1;
-    const LaneRec LR = T.lanes()[lane];
     const int n = LR.flags >> 2;
-    if ((LR.flags & LF_INTERNAL) || n < 2) return -1;
+    if ((LR.flags & LF_INTERNAL) || n < 2) return 0;
     const int dir_allowed = (t & 1) ? -1 : +1;
     const int l0 = LR.edge_lane0, kk = lane - l0;
-    const Node me = L.node[s];
     const int k = me.trip, rq = ax.rq;
     const float *vt = L.vtp + me.vt * VT_COLS;
     const float x = me.pos, v = me.speed;
@@ -676,65 +786,86 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const State &G, size_t e
     float rem;
     const int sdir = strategic_dir(T, rq, kk, n, x, v, 0, rem);
     if (sdir != 0) { dir = sdir; want = 2; }
+    int code = 0;
     const int tk = kk + dir;
-    if (tk < 0 || tk >= n) return -1;
-    const int tl = l0 + tk;
-    const int tcell0 = (int)LR.cell0 + dir * nc;        // lanes of an edge own consecutive, equally sized cell blocks
-    int lead_t = NIL, foll_t = NIL;
-    bool have_t = false;
-    if (!want) {
-        // speed gain between lanes that are both good: more room ahead on the neighbour.  A vehicle reconsiders only on
-        // one pair of ticks (one left, one right chance) out of four
-        if ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) return -1;
-        float rem_t;
-        if (strategic_dir(T, rq, tk, n, x, v, RM_SG_EXTRA_LANES, rem_t) != 0) return -1;
-        const int lead_c = leader_within(L, LR.cell0, nc, x, k, s, RM_NB_WINDOW);
-        if (lead_c == NIL) return -1;
-        lead_t = leader_within(L, tcell0, nc, x, k, s, RM_NB_WINDOW);
-        const float gcur = L.node[lead_c].pos - L.vtp[L.node[lead_c].vt * VT_COLS + VT_LENGTH] - x;
-        float gtgt = RM_BIGF;
-        if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.node[lead_t].vt * VT_COLS + VT_LENGTH] - x;
-        if (!(gcur < v * 3.0f + 15.0f && gtgt > gcur + RM_SG_ADVANTAGE)) return -1;
-        want = 1;
-        have_t = true;
+    if (tk >= 0 && tk < n) {
+        const int tcell0 = (int)LR.cell0 + dir * nc;        // lanes of an edge own consecutive, equally sized cell blocks
+        int lead_t = NIL, foll_t = NIL;
+        bool have_t = false;
+        if (!want && !((((uint32_t)t >> 1) + (uint32_t)k) & 3u)) {
+            // speed gain between lanes that are both good: more room ahead on the neighbour.  A vehicle reconsiders only on
+            // one pair of ticks (one left, one right chance) out of four
+            float rem_t;
+            if (strategic_dir(T, rq, tk, n, x, v, RM_SG_EXTRA_LANES, rem_t) == 0) {
+                const int lead_c = leader_within(L, grid, LR.cell0, nc, x, k, s, RM_NB_WINDOW);
+                if (lead_c != NIL) {
+                    lead_t = leader_within(L, grid, tcell0, nc, x, k, s, RM_NB_WINDOW);
+                    have_t = true;
+                    const float gcur = L.node[lead_c].pos - L.vtp[L.node[lead_c].vt * VT_COLS + VT_LENGTH] - x;
+                    float gtgt = RM_BIGF;
+                    if (lead_t != NIL) gtgt = L.node[lead_t].pos - L.vtp[L.node[lead_t].vt * VT_COLS + VT_LENGTH] - x;
+                    if (gcur < v * 3.0f + 15.0f && gtgt > gcur + RM_SG_ADVANTAGE) want = 1;
+                }
+            }
+        }
+        if (want) {
+            if (!have_t) lead_t = leader_within(L, grid, tcell0, nc, x, k, s, RM_NB_WINDOW);
+            foll_t = follower_within(L, grid, tcell0, nc, x, k, s, RM_NB_WINDOW);
+            // urgent = strategic change close to the end of the drivable lane: accept tighter gaps (followers may have to
+            // brake with their emergency deceleration), otherwise dense queues would never let anybody in
+            const bool urgent = want == 2 && rem <= RM_URGENT_DIST;
+            bool safe = true;
+            if (lead_t != NIL) {
+                const Node ld = L.node[lead_t];
+                const float *vo = L.vtp + ld.vt * VT_COLS;
+                const float gap = ld.pos - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
+                const float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
+                float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
+                if (gap < 0.0f || vb > d_follow_speed(gap, ld.speed, vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
+            }
+            if (safe && foll_t != NIL) {
+                const Node fd = L.node[foll_t];
+                const float *vo = L.vtp + fd.vt * VT_COLS;
+                const float gap = x - vt[VT_LENGTH] - fd.pos - (urgent ? 0.0f : vo[VT_MINGAP]);
+                const float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
+                float vb = fd.speed - dec; if (vb < 0.0f) vb = 0.0f;
+                if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
+            }
+            if (safe) {
+                // (a vehicle that leaves its lane in this tick changes lanes on the next edge, if at all -- its plan looked at
+                //  the links of the lane it is on: the move phase, which knows the next speed, drops the change then)
+                if (dir == dir_allowed) code = dir > 0 ? LCT_LEFT : LCT_RIGHT;
+            } else if (want == 2) {
+                // blocked: fall in behind the target-lane leader, and ask the nearest vehicle completely behind me on the
+                // target lane to let me in
+                if (lead_t != NIL) G.cooplead(t & 1)[eo + s] = ((uint32_t)L.node[lead_t].trip << 16) | (uint32_t)lead_t;
+                const int R = at_or_behind_within(L, grid, tcell0, nc, x - vt[VT_LENGTH], RM_COOP_RANGE);
+                if (R != NIL) rs_atomic_min(&G.coop(t & 1)[eo + R], ((uint32_t)k << 16) | (uint32_t)s);
+            }
+        }
     }
-    if (!have_t) lead_t = leader_within(L, tcell0, nc, x, k, s, RM_NB_WINDOW);
-    foll_t = follower_within(L, tcell0, nc, x, k, s, RM_NB_WINDOW);
-    // urgent = strategic change close to the end of the drivable lane: accept tighter gaps (followers may have to brake
-    // with their emergency deceleration), otherwise dense queues would never let anybody in
-    const bool urgent = want == 2 && rem <= RM_URGENT_DIST;
-    bool safe = true;
-    if (lead_t != NIL) {
-        const float *vo = L.vtp + L.node[lead_t].vt * VT_COLS;
-        const float gap = L.node[lead_t].pos - vo[VT_LENGTH] - x - (urgent ? 0.0f : vt[VT_MINGAP]);
-        const float dec = urgent ? vt[VT_EMERGENCY] : vt[VT_DECEL];
-        float vb = v - dec; if (vb < 0.0f) vb = 0.0f;
-        if (gap < 0.0f || vb > d_follow_speed(gap, L.node[lead_t].speed, vt[VT_DECEL], vo[VT_DECEL], vt[VT_TAU])) safe = false;
+    // Mutual block: two vehicles that have stood side by side near the end of their lanes for RM_SWAP_WAIT seconds, each in
+    // the lane the other one needs, can never find a gap: they trade places.  The test is symmetric, so both threads reach
+    // the same verdict (whichever way this tick's changes go).
+    if (sdir != 0 && (t % RM_SWAP_EVERY) == 0 && v <= RM_HALT_SPEED && rem <= RM_URGENT_DIST &&
+        (int)G.swait()[eo + s] >= RM_SWAP_WAIT) {
+        const int b = overlapping(L, grid, (int)LR.cell0 + sdir * nc, nc, x, k, s, vt[VT_LENGTH]);
+        if (b != NIL) {
+            const Node nb = L.node[b];
+            float rem_b;
+            if (nb.speed <= RM_HALT_SPEED && (int)G.swait()[eo + b] >= RM_SWAP_WAIT &&
+                strategic_dir(T, L.aux[b].rq, kk + sdir, n, nb.pos, nb.speed, 0, rem_b) == -sdir && rem_b <= RM_URGENT_DIST &&
+                overlapping(L, grid, LR.cell0, nc, nb.pos, nb.trip, b, L.vtp[nb.vt * VT_COLS + VT_LENGTH]) == s)
+                code |= sdir > 0 ? LCT_SWAP_LEFT : LCT_SWAP_RIGHT;
+        }
     }
-    if (safe && foll_t != NIL) {
-        const float *vo = L.vtp + L.node[foll_t].vt * VT_COLS;
-        const float gap = x - vt[VT_LENGTH] - L.node[foll_t].pos - (urgent ? 0.0f : vo[VT_MINGAP]);
-        const float dec = urgent ? vo[VT_EMERGENCY] : vo[VT_DECEL];
-        float vb = L.node[foll_t].speed - dec; if (vb < 0.0f) vb = 0.0f;
-        if (gap < 0.0f || vb > d_follow_speed(gap, v, vo[VT_DECEL], vt[VT_DECEL], vo[VT_TAU])) safe = false;
-    }
-    if (safe) return dir == dir_allowed ? tl : -1;
-    if (want == 2) {
-        // blocked: fall in behind the target-lane leader, and ask the nearest vehicle completely behind me on the target
-        // lane to let me in
-        if (lead_t != NIL) G.cooplead()[eo + s] = ((uint32_t)L.node[lead_t].trip << 16) | (uint32_t)lead_t;
-        const int R = at_or_behind_within(L, tcell0, nc, x - vt[VT_LENGTH], RM_COOP_RANGE);
-        if (R != NIL) rs_atomic_min(&G.coop()[eo + R], ((uint32_t)k << 16) | (uint32_t)s);
-    }
-    return -1;
+        return code;
 }
 
-// D: does the oldest waiting trip of departure lane d get onto the network at the end of tick t? (oracle: insertion_check)
-RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, int t, int d) {
+// C: does the oldest waiting trip of departure lane d get onto the network in tick t?  The space on its lane is judged
+// AFTER this tick's move of the vehicles that are on it now -- their next speeds are known (oracle: insertion_check)
+RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, const uint16_t *grid, int t, int d) {
     const int k = L.dep[d];
-#ifdef RS_EMU_DEBUG
-    if (k == 312 && t >= 470) printf("t %d d %d k %d depart %d\n", t, d, k, T.cold.trip_depart[k]);
-#endif
     if (k == (int)TRIP_NONE || T.cold.trip_depart[k] > t) return false;
     const int dl = T.cold.dep_lane[d];
     const LaneRec LR = T.lanes()[dl];
@@ -743,22 +874,21 @@ RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, int t, int d) {
     // only vehicles with pos - length < mypos + minGap can be in the way
     const int nc = lane_cells(LR);
     const int c1 = LR.cell0 + cell_of(mypos + vt[VT_MINGAP] + T.maxlen, nc);
-    for (int c = scan_up(L.grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(L.grid, c + 1, c1) : -1))
-        for (int o = L.grid[c] & 0x7FFF; o != NIL; o = L.node[o].nxt) {
-            const float back = L.node[o].pos - L.vtp[L.node[o].vt * VT_COLS + VT_LENGTH];
-#ifdef RS_EMU_DEBUG
-            if (k == 312 && t >= 470) printf("   o %d trip %d pos %f back %f lane %d (dl %d) cell %d head %d nxt %d cellof %d\n", o, L.node[o].trip, L.node[o].pos, back, L.aux[o].lane, dl, c, L.grid[c], L.node[o].nxt, L.aux[o].cell);
-#endif
+    for (int c = scan_up(grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(grid, c + 1, c1) : -1))
+        for (int o = grid[c] & 0x7FFF; o != NIL;) { RS_CHAIN_GUARD
+            const Node od = L.node[o];
+            const float back = (od.pos + L.vnx[o]) - L.vtp[od.vt * VT_COLS + VT_LENGTH];
             if (back - mypos - vt[VT_MINGAP] < 0.0f) return false;
+            o = od.nxt;
         }
     return true;
 }
 
 // the r-th (0-based) free slot in ascending order, -1: none
-RS_DEV int nth_free_slot(const Lds &L, int C, int r) {
+RS_DEV int nth_free_slot(const Lds &L, int C, int r) {      // (in the occupancy snapshot of the beginning of the tick)
 #pragma unroll 1
     for (int w = 0; w < (C + 31) / 32; ++w) {
-        uint32_t fr = ~L.alive[w];
+        uint32_t fr = ~L.alive0[w];
         if (w == (C - 1) / 32 && (C & 31)) fr &= (1u << (C & 31)) - 1u;
         const int c = rs_popc(fr);
         if (r >= c) { r -= c; continue; }
@@ -779,13 +909,14 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
     const int genv = P.env_base + env;
     const size_t eo = (size_t)env * C;
     const int n_ticks = P.n_ticks;
-    const int ngw = (T.n_cells + 8 + 1) / 2;        // grid dwords
+
+    uint16_t *const grid0 = L.grid, *const grid1 = grid0 + L.gstride;
 
     // ---- L0: scalars, tables, TLS, backlog heads
     ex.phase(0, [&](int tid) {
         if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 4 ? G.env[env * 4 + tid] : 0;
         for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold.vtype_params[i];
-        for (int i = tid; i < ngw; i += B) ((uint32_t *)(uint16_t *)L.grid)[i] = 0x7FFF7FFFu;
+        for (int i = tid; i < (int)L.gstride; i += B) ((uint32_t *)grid0)[i] = 0x7FFF7FFFu;      // both grids: 2 * gstride cells
         for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
         for (int i = tid; i < (C + 31) / 32; i += B) L.alive[i] = 0u;
         for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
@@ -799,29 +930,28 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             tls_refresh(T, L, P, i, ph);
         }
     });
-    // ---- L1: the slab (once per env-step)
+    // ---- L1: the slab (once per env-step); Signal.prep_phase for every signal (traffic_signal.py:176-184), then the TLS
+    //          events of tick 0
     ex.phase(1, [&](int tid) {
         const int hw0 = L.sc[SC_HW];
         for (int s = tid; s < C; s += B) {
             uint16_t ln = LANE_NONE, tr = TRIP_NONE;
             if (s < hw0) { ln = G.lane()[eo + s]; tr = G.trip()[eo + s]; }
-            L.aux[s].lane = ln; L.node[s].trip = tr; L.aux[s].cell = 0xFFFF;
-            if (ln == LANE_NONE) continue;
-            const float sp = G.speed()[eo + s];
-            L.node[s].pos = G.pos()[eo + s]; L.node[s].speed = sp;
+            Aux ax; ax.lane = ln; ax.rq = 0; ax.nlink = NLINK_NONE; ax.lct = 0;
+            if (ln == LANE_NONE) { L.aux[s] = ax; L.node[s].trip = TRIP_NONE; continue; }
+            const float sp = G.speed()[eo + s], x = G.pos()[eo + s];
             const int rq = (int)T.routes()[T.trip_route()[tr]].start + (int)G.cursor()[eo + s];
-            L.aux[s].rq = (uint16_t)rq;
-            L.node[s].vt = T.trip_vtype()[tr];
             const LaneRec LR0 = T.lanes()[ln];
-            L.aux[s].nlink = cache_link(T, LR0, ln, rq, tr);
-            const int c = LR0.cell0 + cell_of(L.node[s].pos, lane_cells(LR0));
-            L.aux[s].cell = (uint16_t)c;
-            L.node[s].nxt = grid_push(L.grid, c, s, sp > RM_HALT_SPEED);
+            ax.rq = (uint16_t)rq;
+            ax.nlink = cache_link(T, LR0, ln, rq, tr);
+            L.aux[s] = ax;
+            Node nn; nn.pos = x; nn.speed = sp; nn.trip = tr; nn.vt = T.trip_vtype()[tr];
+            nn.fl = 0; nn.pad[0] = nn.pad[1] = 0;
+            nn.nxt = grid_push(grid0, LR0.cell0 + cell_of(x, lane_cells(LR0)), s, sp > RM_HALT_SPEED);
+            if (n_ticks > 0) nn.fl = (uint8_t)classify(T, L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, rq, tr, G.sf()[eo + s], L.sc[SC_T]);
+            L.node[s] = nn;
             rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
         }
-    });
-    // ---- L2: Signal.prep_phase for every signal (traffic_signal.py:176-184), then the TLS events of tick 0
-    ex.phase(2, [&](int tid) {
         for (int s = B - 1 - tid; s < S; s += B) {
             if (P.do_fsm && !P.fixed_program) {
                 const int a = actions[env * S + s], cur = L.phase[s], Gn = T.cold.tls_ngreen[s];
@@ -837,137 +967,143 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             if (n_ticks > 0) tls_begin_of_tick(T, L, P, s, 0);
         }
     });
-    // ---- L3: approach registration of the first tick (later ticks register at their end, see A2)
-    if (n_ticks > 0) ex.phase(3, [&](int tid) {
+    // ---- L2: approach registration of the first tick (later ticks register while they move, see M)
+    if (n_ticks > 0) ex.phase(2, [&](int tid) {
         const int hw = L.sc[SC_HW];
-        for (int s = tid; s < hw; s += B) register_approach(T, L, s);
+        for (int s = tid; s < hw; s += B) {
+            const Aux ax = L.aux[s];
+            if (ax.lane == LANE_NONE) continue;
+            const Node me = L.node[s];
+            register_approach(T, L, ax.nlink, me.speed, me.pos, T.lanes()[ax.lane].len, me.vt);
+        }
     });
 
+    // A tick = three phases on the state at its beginning (oracle: orc_tick):
+    //   P  every vehicle: next speed (car following, links, foes, cooperation) and lane-change decision
+    //   C  role threads: which departure lanes insert (knowing the next speeds), the TLS events of the NEXT tick; the approach
+    //      registers and the per-tick scalars are reset (nobody reads them between P and M)
+    //   M  every vehicle: sideways, forward, hand-over, arrival; it leaves the grid of this tick's parity (which is empty
+    //      afterwards) and enters the other one together with the inserted vehicles; the next tick's approach registration
+    int cur = 0;
     for (int tick = 0; tick < n_ticks; ++tick) {
-        const int t = L.sc[SC_T], hw = L.sc[SC_HW];
-        // ---- P: plan
+        const int t = L.sc[SC_T], hw = L.sc[cur ? SC_HWNEW : SC_HW];
+        uint16_t *const gold = cur ? grid1 : grid0, *const gnew = cur ? grid0 : grid1;
+        const bool more = tick + 1 < n_ticks;
+        const int lcap = (int)L.lcap;
+        const int nwv = B >> 6;
+        // Who does what inside a phase is decided per WAVE (a wave runs every branch any of its lanes takes, and what it does
+        // one after the other adds up on the critical path of the phase): the first waves take the lists of the vehicles with
+        // the long code paths, the others share the slots on the short path.
         ex.phase(4, [&](int tid) {
-            for (int s = tid; s < hw; s += B) phase_plan(T, L, G, eo, P, genv, t, s);
-        });
-        // ---- C: everybody leaves the grid and drops its approach registration (nobody reads them between plan and move)
-        ex.phase(5, [&](int tid) {
-            for (int s = tid; s < hw; s += B) {
-                const int c = L.aux[s].cell;
-                if (c < 0xFFF0) L.grid[c] = NIL;
-                const int nlk = L.aux[s].nlink;
-                if (L.aux[s].lane != LANE_NONE && (nlk & NLINK_ARR)) L.arr[T.links()[nlk & 0x7FFF].arr_idx] = ARR_NONE;
+            const int wv = tid >> 6, ln = tid & 63;
+            const int nh = L.sc[SC_NH], nlc = L.sc[SC_NLC];
+            int hwv = (nh + 63) >> 6, lwv = (nlc + 63) >> 6;            // waves for the look-ahead list, the lane-change list
+            // a list overflowed, or the lists leave no wave for the slots: every thread handles its slots in full, in two passes
+            const bool all = nh > lcap || nlc > lcap || hwv + lwv >= nwv;
+            for (int pass = 0; pass < (all ? 2 : 1); ++pass) {
+                int kind, w0, stride, lim;                              // kind 0: plan of a slot, 1: plan from the list, 2: lane change
+                if (all) { kind = pass ? 2 : 0; w0 = tid; stride = B; lim = hw; }
+                else if (wv < hwv) { kind = 1; w0 = wv * 64 + ln; stride = hwv * 64; lim = nh; }
+                else if (wv < hwv + lwv) { kind = 2; w0 = (wv - hwv) * 64 + ln; stride = lwv * 64; lim = nlc; }
+                else { kind = 0; w0 = (wv - hwv - lwv) * 64 + ln; stride = (nwv - hwv - lwv) * 64; lim = hw; }
+                for (int w = w0; w < lim; w += stride) {
+                    int s = w;
+                    if (kind == 1) s = L.ls_h[w];
+                    else if (kind == 2 && !all) s = L.ls_lc[w];
+                    else {
+                        const int f = L.node[w].fl;
+                        if (kind == 0 ? (!all && (f & FL_H)) : !(f & FL_LC)) continue;
+                    }
+                    if (kind == 2) {
+                        const Aux ax = L.aux[s];
+                        if (ax.lane == LANE_NONE) continue;
+                        const int code = phase_lc_decide(T, L, gold, G, eo, t, s, ax, L.node[s], T.lanes()[ax.lane]);
+                        if (code) { L.aux[s].lct = (uint16_t)code; flag_mover(L, s, t); }
+                    } else phase_plan(T, L, gold, G, eo, P, genv, t, s);
+                }
             }
-            if (tid == 0) { L.sc[SC_HWNEW] = 0; L.sc[SC_REBUILD] = 0; }
             for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
         });
-        // ---- M: move; build the grid of the moved state
+        ex.phase(5, [&](int tid) {
+            for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
+            for (int i = tid; i < (C + 31) / 32; i += B) L.alive0[i] = L.alive[i];
+            for (int d = B - 1 - tid; d < T.n_dep; d += B)
+                if (phase_insert_decide(T, L, gold, t, d)) rs_atomic_or(&L.insm[d >> 5], 1u << (d & 31));
+            if (more)
+                for (int sg = B - 1 - tid; sg < S; sg += B) tls_begin_of_tick(T, L, P, sg, tick + 1);
+            if (tid == 0) {
+                L.sc[SC_T] = t + 1; L.sc[SC_STATS + ST_TICKS] += 1;
+                L.sc[cur ? SC_HW : SC_HWNEW] = 0;               // the high-water mark the move phase builds
+                L.sc[SC_ROOM] = C - L.sc[SC_NACT];
+                L.sc[SC_NH] = 0; L.sc[SC_NLC] = 0;              // the move phase queues the next tick's lists
+                L.sc[SC_NMH + ((t + 1) & 1)] = 0;               // the next plan phase queues the next tick's movers
+            }
+        });
         ex.phase(6, [&](int tid) {
             int active = 0, halted = 0, top = 0;
-            for (int s = tid; s < hw; s += B) phase_move(T, L, G, P, env, eo, t, tick == n_ticks - 1, s, active, halted, top);
-            if (active) rs_atomic_add(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
-            if (halted) rs_atomic_add(&L.sc[SC_STATS + ST_WAITING], halted);
-            if (top) rs_atomic_max(&L.sc[SC_HWNEW], top);
-        });
-        const int hw2 = L.sc[SC_HWNEW];
-        // ---- D: decisions on the moved state: lane changes (+ cooperation requests), insertions, next tick's TLS events
-#ifdef RS_PHASE_SPLIT       // diagnostic build: the three roles of D as separately timed phases (ids 11, 12 borrow O0 / O1's slots)
-        ex.phase(7, [&](int tid) { for (int s = tid; s < hw2; s += B) L.vnx[s] = rs_int_as_float(phase_lc_decide(T, L, G, eo, t, s)); });
-        ex.phase(11, [&](int tid) {
-            for (int d = B - 1 - tid; d < T.n_dep; d += B)
-                if (phase_insert_decide(T, L, t, d)) rs_atomic_or(&L.insm[d >> 5], 1u << (d & 31));
-        });
-        ex.phase(12, [&](int tid) {
-            if (tick + 1 < n_ticks)
-                for (int sg = B - 1 - tid; sg < S; sg += B) tls_begin_of_tick(T, L, P, sg, tick + 1);
-            if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
-        });
-#else
-        ex.phase(7, [&](int tid) {
-            for (int s = tid; s < hw2; s += B) L.vnx[s] = rs_int_as_float(phase_lc_decide(T, L, G, eo, t, s));
-            for (int d = B - 1 - tid; d < T.n_dep; d += B)
-                if (phase_insert_decide(T, L, t, d)) rs_atomic_or(&L.insm[d >> 5], 1u << (d & 31));
-            if (tick + 1 < n_ticks)
-                for (int sg = B - 1 - tid; sg < S; sg += B) tls_begin_of_tick(T, L, P, sg, tick + 1);
-            if (tid == 0) { L.sc[SC_T] = t + 1; L.sc[SC_HW] = hw2; L.sc[SC_STATS + ST_TICKS] += 1; }
-        });
-#endif
-        // ---- A1: lane changers leave their cell; the winners of the departure lanes fill free slots
-        ex.phase(8, [&](int tid) {
-            for (int s = tid; s < hw2; s += B) {
-                if (L.aux[s].lane == LANE_NONE) continue;
-                const int target = rs_float_as_int(L.vnx[s]);
-                if (target < 0) continue;
-                const int c = L.aux[s].cell;
-#ifdef RS_EMU_DEBUG
-                if (s == 104 && t >= 470) printf("A1 t %d slot %d lane %d -> %d cell %d head %d nxt %d\n", t, s, L.aux[s].lane, target, c, L.grid[c], L.node[s].nxt);
-#endif
-                if ((L.grid[c] & 0x7FFF) == s && L.node[s].nxt == NIL) { L.grid[c] = NIL; L.aux[s].cell = 0xFFFD; }   // alone in my cell: leave it, re-register in A2
-                else L.sc[SC_REBUILD] = 1;      // shared cell: everybody leaves and re-enters the grid (my cell index stays valid for the clearing)
-                L.aux[s].lane = (uint16_t)target;
-                L.aux[s].nlink = cache_link(T, T.lanes()[target], target, L.aux[s].rq, L.node[s].trip);
+            // the first waves take the list of the vehicles that leave their lane, the others share the slots
+            const int wv = tid >> 6, ln = tid & 63;
+            const int nmh = L.sc[SC_NMH + (t & 1)];
+            int mwv = (nmh + 63) >> 6;
+            const bool all = nmh > lcap || mwv >= nwv;
+            if (all) mwv = 0;
+            const bool list = wv < mwv;
+            const int w0 = (list ? wv : wv - mwv) * 64 + ln, stride = (list ? mwv : nwv - mwv) * 64, lim = list ? nmh : hw;
+            for (int w = w0; w < lim; w += stride) {
+                int s = w;
+                if (list) s = L.ls_mh[w];
+                else if (!(L.alive0[w >> 5] & (1u << (w & 31))) || (!all && (L.node[w].fl & fl_mh(t)))) continue;
+                phase_move(T, L, gold, gnew, G, P, env, eo, t, !more, more, s, active, halted, top);
             }
+            // the winners of the departure lanes take the slots that were free at the beginning of the tick, lower lane first
             for (int d = B - 1 - tid; d < T.n_dep; d += B) {
                 if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
                 int rank = rs_popc(L.insm[d >> 5] & ((1u << (d & 31)) - 1u));
                 for (int w = 0; w < (d >> 5); ++w) rank += rs_popc(L.insm[w]);
-                if (rank >= C - L.sc[SC_NACT]) continue;            // the network is full (lower lane index first)
+                if (rank >= L.sc[SC_ROOM]) continue;            // the network is full
                 const int s = nth_free_slot(L, C, rank);
                 if (s < 0) continue;
                 const int k = L.dep[d];
                 const int v = T.trip_vtype()[k];
                 const float *vt = L.vtp + v * VT_COLS;
                 const RouteRec RR = T.routes()[T.trip_route()[k]];
-                L.node[s].pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
-                L.node[s].trip = (uint16_t)k; L.node[s].nxt = NIL;
-                L.node[s].speed = 0.0f; G.swait()[eo + s] = 0; L.node[s].vt = (uint8_t)v;
-                L.aux[s].lane = RR.depart_lane; L.aux[s].rq = (uint16_t)RR.start;
-                L.aux[s].nlink = cache_link(T, T.lanes()[RR.depart_lane], RR.depart_lane, (int)RR.start, k);
-                L.aux[s].cell = CELL_NEW;
-                G.sf()[eo + s] = speed_factor(P, genv, k, vt); G.tloss()[eo + s] = 0.0f; G.cooplead()[eo + s] = COOP_NONE; G.coop()[eo + s] = COOP_NONE;
+                const LaneRec LRd = T.lanes()[RR.depart_lane];
+                const float sfn = speed_factor(P, genv, k, vt);
+                Node nn; nn.pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
+                nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.pad[0] = nn.pad[1] = 0;
+                nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(nn.pos, lane_cells(LRd)), s, false);
+                if (more) nn.fl = (uint8_t)classify(T, L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, (int)RR.start, k, sfn, t + 1);
+                L.node[s] = nn;
+                Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.lct = 0;
+                na.nlink = cache_link(T, LRd, RR.depart_lane, (int)RR.start, k);
+                L.aux[s] = na;
+                G.swait()[eo + s] = 0;
+                G.sf()[eo + s] = sfn; G.tloss()[eo + s] = 0.0f; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE; G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE;
                 G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
                 L.dep[d] = T.cold.trip_next[k];
-                rs_atomic_max(&L.sc[SC_HW], s + 1);
+                rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
+                rs_atomic_add(&L.sc[SC_NACT], 1);
+                rs_atomic_add(&L.sc[SC_NINS], 1);
                 rs_atomic_add(&L.sc[SC_STATS + ST_INSERTED], 1);
                 rs_atomic_add(&L.sc[SC_STATS + ST_DEPDELAY], t - T.cold.trip_depart[k]);
+                if (s + 1 > top) top = s + 1;
+                // (a standing vehicle does not register an approach)
             }
+            if (active) rs_atomic_add(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
+            if (halted) rs_atomic_add(&L.sc[SC_STATS + ST_WAITING], halted);
+            if (top) rs_atomic_max(&L.sc[cur ? SC_HW : SC_HWNEW], top);
         });
-        const int hw3 = L.sc[SC_HW];
-        const bool more = tick + 1 < n_ticks;
-        if (L.sc[SC_REBUILD]) {
-            ex.phase(9, [&](int tid) {
-                for (int s = tid; s < hw3; s += B) { const int c = L.aux[s].cell; if (c < 0xFFF0) L.grid[c] = NIL; }
-            });
-        }
-        const bool rebuild = L.sc[SC_REBUILD] != 0;
-        // ---- A2: changers and new vehicles enter the grid; the next tick's approach registrations (P3)
-        ex.phase(10, [&](int tid) {
-            for (int s = tid; s < hw3; s += B) {
-                const int ln = L.aux[s].lane;
-                if (ln == (int)LANE_NONE) continue;
-                const int c0 = L.aux[s].cell;
-                if (c0 == (int)CELL_NEW) {
-                    rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
-                    rs_atomic_add(&L.sc[SC_NACT], 1);
-                    rs_atomic_add(&L.sc[SC_NINS], 1);
-                }
-                if (rebuild || c0 >= 0xFFF0) {
-                    const LaneRec LRn = T.lanes()[ln];
-                    const int c = LRn.cell0 + cell_of(L.node[s].pos, lane_cells(LRn));
-                    L.aux[s].cell = (uint16_t)c;
-                    L.node[s].nxt = grid_push(L.grid, c, s, L.node[s].speed > RM_HALT_SPEED);
-                }
-                if (more) register_approach(T, L, s);
-            }
-        });
+        cur ^= 1;
     }
+    const int hw_end = L.sc[cur ? SC_HWNEW : SC_HW];
 
     // ---- Signal.observe for every signal (traffic_signal.py:189-247)
     ex.phase(11, [&](int tid) {
         for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
     });
     ex.phase(12, [&](int tid) {
-        const int hwf = L.sc[SC_HW], hw0 = G.env[env * 4 + 2];
-        const int top = hwf > hw0 ? hwf : hw0;
+        const int hw0 = G.env[env * 4 + 2];
+        const int top = hw_end > hw0 ? hw_end : hw0;
         int hi = 0;
         for (int s = tid; s < top; s += B) {
             const int lane = L.aux[s].lane;
@@ -1006,7 +1142,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             else rs_atomic_add(&L.agg_a[oi], 1);
             rs_atomic_add((int32_t *)&L.agg_s[oi], (int32_t)(uint32_t)(L.node[s].speed * 65536.0f + 0.5f));
         }
-        if (hi) rs_atomic_max(&L.sc[SC_HWNEW], hi);
+        if (hi) rs_atomic_max(&L.sc[SC_HWOUT], hi);
     });
     // per observed lane rows, written as flat coalesced streams; states / rewards; state write-back
     ex.phase(13, [&](int tid) {
@@ -1081,7 +1217,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
     ex.phase(14, [&](int tid) {
         if (tid == 0) {
             G.env[env * 4 + 0] = L.sc[SC_T]; G.env[env * 4 + 1] = L.sc[SC_NINS]; G.env[env * 4 + 3] = L.sc[SC_NACT];
-            G.env[env * 4 + 2] = L.sc[SC_HWNEW];
+            G.env[env * 4 + 2] = L.sc[SC_HWOUT];
         }
         if (tid < ST_N) {
             long long *st = G.stats + (size_t)env * ST_N;

@@ -25,7 +25,7 @@ enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, 
 // a cell holds the slot of a vehicle whose front is inside it (more than one: a short chain).  Every neighbour search of
 // the model is a bounded scan over a few consecutive cells.
 #ifndef CELL_LEN
-#define CELL_LEN 16.0f
+#define CELL_LEN 32.0f
 #endif
 #define CELL_INV (1.0f / CELL_LEN)
 

@@ -25,7 +25,9 @@ static inline void rs_atomic_min(int32_t *p, int32_t v) { if (v < *p) *p = v; }
 static inline void rs_atomic_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
 static inline void rs_atomic_max(int32_t *p, int32_t v) { if (v > *p) *p = v; }
 static inline void rs_atomic_add(int32_t *p, int32_t v) { *p += v; }
+static inline int32_t rs_atomic_fetch_add(int32_t *p, int32_t v) { const int32_t o = *p; *p += v; return o; }
 static inline void rs_atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
+static inline uint32_t rs_atomic_fetch_or(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
 static inline void rs_atomic_and(uint32_t *p, uint32_t v) { *p &= v; }
 static inline uint32_t rs_atomic_cas(uint32_t *p, uint32_t cmp, uint32_t v) { uint32_t o = *p; if (o == cmp) *p = v; return o; }
 static inline int rs_ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
@@ -57,13 +59,23 @@ static inline uint16_t rs_f2h(float f) {
     return (uint16_t)(sign | r);
 }
 
+#ifdef RS_EMU_DEBUG
+#include <stdio.h>
+static int rs_dbg_slot = getenv("RS_DBG_SLOT") ? atoi(getenv("RS_DBG_SLOT")) : -1;
+static int rs_dbg_t = getenv("RS_DBG_T") ? atoi(getenv("RS_DBG_T")) : -1;
+static long rs_dbg_chain = 0;         // chain-walk steps of the current phase (reset by HostExec::phase)
+#endif
 #include "resco_step.h"
 
 struct HostExec {
     int B;
     int order;          // 0 ascending, 1 descending, 2 shuffled (a different permutation in every phase)
     uint32_t rng = 12345u;
-    template <class F> void phase(int, F f) {
+    template <class F> void phase(int id, F f) {
+#ifdef RS_EMU_DEBUG
+        if (getenv("RS_DBG_PHASES")) { printf("phase %d\n", id); fflush(stdout); }
+        rs_dbg_chain = 0;
+#endif
         if (order == 0) for (int t = 0; t < B; ++t) f(t);
         else if (order == 1) for (int t = B - 1; t >= 0; --t) f(t);
         else {
@@ -193,7 +205,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     set_buf(h, RS_BUF_VEH_WTOT, G.wtot(), RS_U16, 2, n, cc);
     set_buf(h, RS_BUF_TRIP_LOG, G.trip_log, RS_I32, 3, n, p->trip_log ? sc->n_trips : 0, 4);
     set_buf(h, RS_BUF_DEP_NEXT, G.dep_next, RS_U16, 2, n, K.n_dep);
-    set_buf(h, RS_BUF_VEH_COOP, G.coop(), RS_U32, 2, n, cc); set_buf(h, RS_BUF_VEH_COOPLEAD, G.cooplead(), RS_U32, 2, n, cc);
+    set_buf(h, RS_BUF_VEH_COOP, G.coop(0), RS_U32, 2, n, cc); set_buf(h, RS_BUF_VEH_COOPLEAD, G.cooplead(0), RS_U32, 2, n, cc);
     set_buf(h, RS_BUF_ARRIVALS, O.arrivals(), RS_I32, 2, n, s); set_buf(h, RS_BUF_DEPARTURES, O.departures(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_MPLIGHT_FULL, O.mplight_full(), RS_F32, 3, n, s, 49);
     *out = h;
@@ -210,7 +222,7 @@ int rs_reset(rs_handle h, void *) {
             G.lane()[eo + s] = LANE_NONE; G.trip()[eo + s] = TRIP_NONE; G.owner()[eo + s] = OWNER_NONE;
             G.rwait()[eo + s] = 0; G.swait()[eo + s] = 0; G.cursor()[eo + s] = 0; G.depart()[eo + s] = 0; G.wtot()[eo + s] = 0;
             G.pos()[eo + s] = 0.0f; G.speed()[eo + s] = 0.0f; G.accel()[eo + s] = 0.0f; G.tloss()[eo + s] = 0.0f; G.sf()[eo + s] = 1.0f;
-            G.coop()[eo + s] = COOP_NONE; G.cooplead()[eo + s] = COOP_NONE;
+            G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE;
         }
         for (int s = 0; s < S; ++s) {
             int ph, left;

@@ -63,5 +63,6 @@ def test_algorithmic_bytes_formula():
     import bench
     sc = load_scenario('ingolstadt21')
     b = bench.algorithmic_bytes_per_env_step(sc, 300.0)
-    # 60 B per active vehicle + 152 B per signal + 40 B per observed lane + fp16 padded obs + scalars
-    assert b == 300 * 60 + 21 * 152 + 163 * 40 + 21 * 17 * 10 + 104
+    # 60 B per active vehicle + 12 B per signal (action, FSM in / out) + 20 B per observed lane + 8 B of rewards per signal
+    assert b == 300 * 60 + 21 * 12 + 163 * 20 + 21 * 8
+    assert bench.designed_bytes_per_env_step(sc, 300.0) > b

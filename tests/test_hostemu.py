@@ -73,6 +73,24 @@ def test_kernel_source_equals_oracle(name, steps, order, sigma, speed_dev, fixed
     sim.close()
 
 
+@pytest.mark.parametrize('name,steps,order', [('cologne8', 60, 2), ('ingolstadt7', 80, 1)])
+def test_work_lists_overflow(name, steps, order):
+    """the work lists of the phases (look-ahead, lane change, lane leavers) are scheduling only: with lists of 8 entries they
+    overflow in most ticks and every thread handles its own slots in full -- same results"""
+    sc = load_scenario(name)
+    sim = EmuSim(sc, 1, order=order, short_lists=True, seed=9, env_base=3)
+    o = OracleEnv(sc, env_index=3, seed=9, sigma=-1.0, speed_dev=1)
+    o.observe()
+    rng = np.random.default_rng(2)
+    for step in range(steps):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        sim.step(a[None, :])
+        o.step(a)
+        if step % 10 == 9:
+            assert_equal(sim, [o], step)
+    sim.close()
+
+
 def test_half_the_threads_two_slots_each():
     """block_threads < capacity: a thread owns slots tid, tid + B (the 512-thread launch of a 1024-slot scenario)"""
     sc = load_scenario('cologne8')

@@ -17,7 +17,7 @@ sim.phase_profile(True)
 for k in range(100, 160):
     sim.act_random(k); sim.step(None)
 acc = sim.phase_profile(False)
-names = ['L0', 'L1', 'L2', 'L3', 'P plan', 'C leave', 'M move', 'D decide', 'A1 apply', 'RB rebuild', 'A2 enter', 'O0', 'O1 observe', 'O2 outputs', 'O3']
+names = ['L0 init', 'L1 load+prep', 'L2 register', '-', 'P plan+lc', 'C insert?+tls', 'M move+insert', '-', '-', '-', '-', 'O0', 'O1 observe', 'O2 outputs', 'O3']
 tot = float(sum(acc)) or 1.0
 for nm, a in zip(names, acc):
     print('%-12s %6.2f %%' % (nm, 100.0 * a / tot))
