@@ -93,6 +93,7 @@ def run(name, policy, envs=8, seed=0, steps=360, pool=None):
     rows = pool.map(episode, jobs) if pool is not None else [episode(j) for j in jobs]
     d = np.array([r['delay'] for r in rows])
     return dict(map=name, policy=policy, envs=envs, avg_delay=float(d.mean()), median_delay=float(np.median(d)),
+                delays_sorted=[round(float(x), 1) for x in np.sort(d)],
                 arrived=float(np.mean([r['arrived'] for r in rows])), inserted=float(np.mean([r['inserted'] for r in rows])),
                 pending=float(np.mean([r['pending'] for r in rows])), mean_active=float(np.mean([r['mean_active'] for r in rows])),
                 avg_duration=float(np.mean([r['duration'] for r in rows])), reference_delay=REF.get((name, policy)))

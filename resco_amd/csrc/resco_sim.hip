@@ -41,6 +41,24 @@ __device__ __forceinline__ void rs_atomic_min(uint32_t *p, uint32_t v) { atomicM
 __device__ __forceinline__ void rs_atomic_max(int32_t *p, int32_t v) { atomicMax(p, v); }
 __device__ __forceinline__ void rs_atomic_add(int32_t *p, int32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ int32_t rs_atomic_fetch_add(int32_t *p, int32_t v) { return atomicAdd(p, v); }
+// the lanes of a wave that are here together take consecutive tickets from ONE atomic (the counter is the same for all of them)
+__device__ __forceinline__ int32_t rs_wave_ticket(int32_t *p) {
+    const unsigned long long m = __ballot(1);
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    int32_t base = 0;
+    if (below == 0) base = atomicAdd(p, (int32_t)__popcll(m));
+    return __builtin_amdgcn_readlane(base, __ffsll((long long)m) - 1) + below;
+}
+// one atomic per wave instead of one per lane (64 lanes adding to ONE LDS address are served one after the other): called
+// where the whole wave is converged
+__device__ __forceinline__ void rs_wave_add(int32_t *p, int32_t v) {
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
+}
+__device__ __forceinline__ void rs_wave_max(int32_t *p, int32_t v) {
+    for (int m = 32; m > 0; m >>= 1) { const int32_t o = __shfl_xor(v, m); v = o > v ? o : v; }
+    if ((threadIdx.x & 63) == 0) atomicMax(p, v);
+}
 __device__ __forceinline__ void rs_atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 __device__ __forceinline__ uint32_t rs_atomic_fetch_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 __device__ __forceinline__ int rs_atomic_inc(int32_t *p) { return atomicAdd(p, 1); }
@@ -70,6 +88,11 @@ struct DevExec {
         f((int)threadIdx.x);
         __syncthreads();
         if (prof && threadIdx.x == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(&prof[id], t1 - t0); t0 = t1; }
+    }
+    // time a wave spends in one role of a phase: sum of the 100 MHz ticks in the low 40 bits, number of waves above
+    __device__ __forceinline__ unsigned long long role_begin() const { return prof ? wall_clock64() : 0ull; }
+    __device__ __forceinline__ void role_end(int id, unsigned long long start) const {
+        if (prof && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicAdd(&prof[id], (wall_clock64() - start) + (1ull << 40));   // (every 16th environment: the sum stays below 2^40)
     }
 };
 // Two register budgets: 64 VGPRs (two 1024-thread workgroups = 32 waves share a CU) and 128 VGPRs (blocks of <= 512);

@@ -443,16 +443,26 @@ RS_DEV void tls_begin_of_tick(const KTab &T, const Lds &L, const KParams &P, int
 // strategic lane-change need at route step rq on lane index kk of an edge with n lanes, at position x with speed v:
 // 0 when the lane is as good as any, or the need is still far away; else the direction of the nearest best lane.
 // extra = RM_SG_EXTRA_LANES when asking whether a lane is good enough to move INTO for speed gain.  (oracle: strategic_dir_at)
-RS_DEV int strategic_dir(const KTab &T, int rq, int kk, int n, float x, float v, int extra, float &rem) {
-    const float *cn = T.route_cont() + (size_t)rq * T.kmax;
+// the continuation lengths of the lanes of route step rq (route_cont row), loaded once: the first four in registers
+struct ContRow { float c[4]; const float *cn; };
+RS_DEV ContRow cont_row(const KTab &T, int rq) {
+    ContRow R;
+    R.cn = T.route_cont() + (size_t)rq * T.kmax;
+    for (int j = 0; j < 4; ++j) R.c[j] = j < T.kmax ? R.cn[j] : 0.0f;
+    return R;
+}
+RS_DEV float cont_of(const ContRow &R, int j) {
+    return j == 0 ? R.c[0] : (j == 1 ? R.c[1] : (j == 2 ? R.c[2] : (j == 3 ? R.c[3] : R.cn[j])));
+}
+RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int extra, float &rem) {
     float best = 0.0f;
-    for (int j = 0; j < n; ++j) { const float c = cn[j]; if (c > best) best = c; }
-    const float mine = cn[kk];
+    for (int j = 0; j < n; ++j) { const float c = cont_of(R, j); if (c > best) best = c; }
+    const float mine = cont_of(R, kk);
     rem = mine - x;
     if (mine >= best - RM_CONT_EPS) return 0;
     int dl = 1000, dr = 1000;
-    for (int j = kk + 1; j < n; ++j) if (cn[j] >= best - RM_CONT_EPS) { dl = j - kk; break; }
-    for (int j = kk - 1; j >= 0; --j) if (cn[j] >= best - RM_CONT_EPS) { dr = kk - j; break; }
+    for (int j = kk + 1; j < n; ++j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dl = j - kk; break; }
+    for (int j = kk - 1; j >= 0; --j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dr = kk - j; break; }
     const int off = (dr <= dl ? dr : dl) + extra;
     const float la = (v > RM_LOOK_MIN_SPEED ? v : RM_LOOK_MIN_SPEED) * RM_LOOK_TIME + RM_LOOK_BASE;
     if (rem >= la * (float)off) return 0;
@@ -460,17 +470,21 @@ RS_DEV int strategic_dir(const KTab &T, int rq, int kk, int n, float x, float v,
 }
 // approach registration for the coming tick (P3): a moving vehicle whose next link somebody may have to yield to registers
 // its arrival time there (v, pos, vType, lane length and next link of the vehicle AFTER this tick's move)
-RS_DEV void register_approach(const KTab &T, const Lds &L, int nlk, float v, float pos, float lane_len, int vt) {
-    if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
-    if (v <= RM_HALT_SPEED) return;
-    const LinkRec K = T.links()[nlk & 0x7FFF];
-    const int st = tls_state(T, L, K.tls, K.tls_pos);
+// (the three fields of the link the registration needs are one dword of its record: arr_idx | tls << 16 | tls_pos << 24)
+RS_DEV uint32_t link_reg_word(const KTab &T, int nlk) { return ((const uint32_t *)&T.links()[nlk & 0x7FFF])[2]; }
+RS_DEV void register_approach_w(const KTab &T, const Lds &L, uint32_t kw, float v, float pos, float lane_len, int vt) {
+    const int st = tls_state(T, L, (int)((kw >> 16) & 0xFFu), (int)(kw >> 24));
     if (st == TLS_R) return;
     const float dist = lane_len - pos;
     if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[vt * VT_COLS + VT_DECEL])) return;
     const float ta = dist / (v > 1.0f ? v : 1.0f);
     const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
-    rs_atomic_min(&L.arr[K.arr_idx], q);
+    rs_atomic_min(&L.arr[(int16_t)(kw & 0xFFFFu)], q);
+}
+RS_DEV void register_approach(const KTab &T, const Lds &L, int nlk, float v, float pos, float lane_len, int vt) {
+    if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
+    if (v <= RM_HALT_SPEED) return;
+    register_approach_w(T, L, link_reg_word(T, nlk), v, pos, lane_len, vt);
 }
 // follow `X` (a vehicle on a neighbouring lane of my edge) as if it were my leader, braking no harder than comfortably:
 // the cooperative part of the lane changing (oracle: plan(), coop / coop_lead).  key = trip << 16 | slot.
@@ -504,7 +518,7 @@ RS_DEV void flag_mover(const Lds &L, int s, int t) {
 }
 // queue slot s in a work list (best effort: the flag in Node.fl is what counts, see the phases)
 RS_DEV void list_push(const Lds &L, const LPtr<uint16_t> &list, int counter, int s) {
-    const int i = rs_atomic_fetch_add(&L.sc[counter], 1);
+    const int i = rs_wave_ticket(&L.sc[counter]);
     if (i < (int)L.lcap) list[i] = (uint16_t)s;
 }
 // how far the plan of a vehicle looks ahead (speed v on a lane with limit vmax, speed factor sf): its free speed and the
@@ -523,21 +537,21 @@ RS_DEV bool looks_beyond(const float *vt, float v, float x, float lane_len, floa
 }
 // can the lane-change decision of tick t have an effect for a vehicle in this state?  (a superset: a strategic need, or its
 // turn to look for speed gain on a neighbour lane that is good enough)
-RS_DEV bool may_change_lanes(const KTab &T, const LaneRec &LR, int lane, int rq, int k, float x, float v, int t) {
+RS_DEV bool may_change_lanes(const ContRow &R, const LaneRec &LR, int lane, int k, float x, float v, int t) {
     const int n = LR.flags >> 2;
     if ((LR.flags & LF_INTERNAL) || n < 2) return false;
     const int kk = lane - (int)LR.edge_lane0;
     float rem;
-    if (strategic_dir(T, rq, kk, n, x, v, 0, rem) != 0) return true;
+    if (strategic_dir(R, kk, n, x, v, 0, rem) != 0) return true;
     if ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) return false;
     const int tk = kk + ((t & 1) ? -1 : +1);
-    return tk >= 0 && tk < n && strategic_dir(T, rq, tk, n, x, v, RM_SG_EXTRA_LANES, rem) == 0;
+    return tk >= 0 && tk < n && strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem) == 0;
 }
 // The work of tick t for the vehicle in slot s (state as of the beginning of that tick): its flags, and it is queued
-RS_DEV int classify(const KTab &T, const Lds &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, int rq, int k, float sf, int t) {
+RS_DEV int classify(const Lds &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, const ContRow &R, int k, float sf, int t) {
     int fl = 0;
     if (looks_beyond(vt, v, x, LR.len, LR.vmax, sf)) { fl |= FL_H; list_push(L, L.ls_h, SC_NH, s); }
-    if (may_change_lanes(T, LR, lane, rq, k, x, v, t)) { fl |= FL_LC; list_push(L, L.ls_lc, SC_NLC, s); }
+    if (may_change_lanes(R, LR, lane, k, x, v, t)) { fl |= FL_LC; list_push(L, L.ls_lc, SC_NLC, s); }
     return fl;
 }
 
@@ -675,6 +689,10 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     }
 #endif
     LaneRec LR = T.lanes()[lane];
+    // what the end of the move needs from the tables is requested now (the common case: the vehicle stays on its lane)
+    ContRow R = cont_row(T, ax.rq);
+    uint32_t kw = 0;
+    if (more && (ax.nlink & NLINK_ARR)) kw = link_reg_word(T, ax.nlink);
     const float sfv = G.sf()[eo + s];
     float tl = G.tloss()[eo + s];
     const int sw = G.swait()[eo + s];
@@ -752,9 +770,10 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     nn.pos = x; nn.speed = vn; nn.fl = (uint8_t)(me.fl & fl_mh(t));
     nn.nxt = grid_push(gnew, LR.cell0 + cell_of(x, lane_cells(LR)), s, vn > RM_HALT_SPEED);
     if (more) {
-        nn.fl |= classify(T, L, s, L.vtp + me.vt * VT_COLS, vn, x, LR, lane, rq, k, sfv, t + 1);
+        if (relink) { R = cont_row(T, rq); if (na.nlink & NLINK_ARR) kw = link_reg_word(T, na.nlink); }
+        nn.fl |= classify(L, s, L.vtp + me.vt * VT_COLS, vn, x, LR, lane, R, k, sfv, t + 1);
         L.node[s] = nn;
-        register_approach(T, L, na.nlink, vn, x, LR.len, me.vt);
+        if ((na.nlink & NLINK_ARR) && vn > RM_HALT_SPEED) register_approach_w(T, L, kw, vn, x, LR.len, me.vt);
     } else L.node[s] = nn;
     (void)P;
 }
@@ -771,9 +790,12 @@ RS_DEV int overlapping(const Lds &L, const uint16_t *grid, int cell0, int ncell,
 
 // The lane-change decision of slot s on the state at the beginning of the tick: returns LCT_* (0: stay).  A blocked strategic
 // changer asks for cooperation; a mutual block is swapped out (oracle: lane_change())
-RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, int t, int s, const Aux &ax, const Node &me,
-                           const LaneRec &LR) {
+RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, int t, int s, const Aux &ax, const Node &me) {
     const int lane = ax.lane;
+    // (everything the decision may need from global memory is requested at once)
+    const LaneRec LR = T.lanes()[lane];
+    const ContRow R = cont_row(T, ax.rq);
+    const int my_wait = (int)G.swait()[eo + s];
     const int n = LR.flags >> 2;
     if ((LR.flags & LF_INTERNAL) || n < 2) return 0;
     const int dir_allowed = (t & 1) ? -1 : +1;
@@ -784,7 +806,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
     const int nc = lane_cells(LR);
     int want = 0, dir = dir_allowed;
     float rem;
-    const int sdir = strategic_dir(T, rq, kk, n, x, v, 0, rem);
+    const int sdir = strategic_dir(R, kk, n, x, v, 0, rem);
     if (sdir != 0) { dir = sdir; want = 2; }
     int code = 0;
     const int tk = kk + dir;
@@ -796,7 +818,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
             // speed gain between lanes that are both good: more room ahead on the neighbour.  A vehicle reconsiders only on
             // one pair of ticks (one left, one right chance) out of four
             float rem_t;
-            if (strategic_dir(T, rq, tk, n, x, v, RM_SG_EXTRA_LANES, rem_t) == 0) {
+            if (strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem_t) == 0) {
                 const int lead_c = leader_within(L, grid, LR.cell0, nc, x, k, s, RM_NB_WINDOW);
                 if (lead_c != NIL) {
                     lead_t = leader_within(L, grid, tcell0, nc, x, k, s, RM_NB_WINDOW);
@@ -848,13 +870,13 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
     // the lane the other one needs, can never find a gap: they trade places.  The test is symmetric, so both threads reach
     // the same verdict (whichever way this tick's changes go).
     if (sdir != 0 && (t % RM_SWAP_EVERY) == 0 && v <= RM_HALT_SPEED && rem <= RM_URGENT_DIST &&
-        (int)G.swait()[eo + s] >= RM_SWAP_WAIT) {
+        my_wait >= RM_SWAP_WAIT) {
         const int b = overlapping(L, grid, (int)LR.cell0 + sdir * nc, nc, x, k, s, vt[VT_LENGTH]);
         if (b != NIL) {
             const Node nb = L.node[b];
             float rem_b;
             if (nb.speed <= RM_HALT_SPEED && (int)G.swait()[eo + b] >= RM_SWAP_WAIT &&
-                strategic_dir(T, L.aux[b].rq, kk + sdir, n, nb.pos, nb.speed, 0, rem_b) == -sdir && rem_b <= RM_URGENT_DIST &&
+                strategic_dir(cont_row(T, L.aux[b].rq), kk + sdir, n, nb.pos, nb.speed, 0, rem_b) == -sdir && rem_b <= RM_URGENT_DIST &&
                 overlapping(L, grid, LR.cell0, nc, nb.pos, nb.trip, b, L.vtp[nb.vt * VT_COLS + VT_LENGTH]) == s)
                 code |= sdir > 0 ? LCT_SWAP_LEFT : LCT_SWAP_RIGHT;
         }
@@ -948,7 +970,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             Node nn; nn.pos = x; nn.speed = sp; nn.trip = tr; nn.vt = T.trip_vtype()[tr];
             nn.fl = 0; nn.pad[0] = nn.pad[1] = 0;
             nn.nxt = grid_push(grid0, LR0.cell0 + cell_of(x, lane_cells(LR0)), s, sp > RM_HALT_SPEED);
-            if (n_ticks > 0) nn.fl = (uint8_t)classify(T, L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, rq, tr, G.sf()[eo + s], L.sc[SC_T]);
+            if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, G.sf()[eo + s], L.sc[SC_T]);
             L.node[s] = nn;
             rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
         }
@@ -1000,12 +1022,15 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             int hwv = (nh + 63) >> 6, lwv = (nlc + 63) >> 6;            // waves for the look-ahead list, the lane-change list
             // a list overflowed, or the lists leave no wave for the slots: every thread handles its slots in full, in two passes
             const bool all = nh > lcap || nlc > lcap || hwv + lwv >= nwv;
+            const unsigned long long r0 = ex.role_begin();
+            int role = 0;
             for (int pass = 0; pass < (all ? 2 : 1); ++pass) {
                 int kind, w0, stride, lim;                              // kind 0: plan of a slot, 1: plan from the list, 2: lane change
                 if (all) { kind = pass ? 2 : 0; w0 = tid; stride = B; lim = hw; }
                 else if (wv < hwv) { kind = 1; w0 = wv * 64 + ln; stride = hwv * 64; lim = nh; }
                 else if (wv < hwv + lwv) { kind = 2; w0 = (wv - hwv) * 64 + ln; stride = lwv * 64; lim = nlc; }
                 else { kind = 0; w0 = (wv - hwv - lwv) * 64 + ln; stride = (nwv - hwv - lwv) * 64; lim = hw; }
+                role = kind;
                 for (int w = w0; w < lim; w += stride) {
                     int s = w;
                     if (kind == 1) s = L.ls_h[w];
@@ -1017,11 +1042,12 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                     if (kind == 2) {
                         const Aux ax = L.aux[s];
                         if (ax.lane == LANE_NONE) continue;
-                        const int code = phase_lc_decide(T, L, gold, G, eo, t, s, ax, L.node[s], T.lanes()[ax.lane]);
+                        const int code = phase_lc_decide(T, L, gold, G, eo, t, s, ax, L.node[s]);
                         if (code) { L.aux[s].lct = (uint16_t)code; flag_mover(L, s, t); }
                     } else phase_plan(T, L, gold, G, eo, P, genv, t, s);
                 }
             }
+            ex.role_end(role == 1 ? 7 : (role == 2 ? 8 : 9), r0);
             for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
         });
         ex.phase(5, [&](int tid) {
@@ -1041,22 +1067,27 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         });
         ex.phase(6, [&](int tid) {
             int active = 0, halted = 0, top = 0;
-            // the first waves take the list of the vehicles that leave their lane, the others share the slots
+            // the first waves take the list of the vehicles that leave their lane, the last one the insertions (when there are
+            // any), the others share the slots
             const int wv = tid >> 6, ln = tid & 63;
             const int nmh = L.sc[SC_NMH + (t & 1)];
-            int mwv = (nmh + 63) >> 6;
-            const bool all = nmh > lcap || mwv >= nwv;
-            if (all) mwv = 0;
-            const bool list = wv < mwv;
-            const int w0 = (list ? wv : wv - mwv) * 64 + ln, stride = (list ? mwv : nwv - mwv) * 64, lim = list ? nmh : hw;
+            int mwv = (nmh + 63) >> 6, iwv = 0;
+            for (int i = 0; i < (T.n_dep + 31) / 32; ++i) if (L.insm[i]) iwv = 1;
+            const bool all = nmh > lcap || mwv + iwv >= nwv;
+            if (all) { mwv = 0; iwv = 0; }
+            const bool list = wv < mwv, ins = all || wv >= nwv - iwv;
+            const int nsw = nwv - mwv - iwv;                // waves that share the slots
+            const int w0 = (list ? wv : wv - mwv) * 64 + ln, stride = (list ? mwv : nsw) * 64, lim = list ? nmh : ((ins && !all) ? 0 : hw);
+            const unsigned long long r0 = ex.role_begin();
             for (int w = w0; w < lim; w += stride) {
                 int s = w;
                 if (list) s = L.ls_mh[w];
                 else if (!(L.alive0[w >> 5] & (1u << (w & 31))) || (!all && (L.node[w].fl & fl_mh(t)))) continue;
                 phase_move(T, L, gold, gnew, G, P, env, eo, t, !more, more, s, active, halted, top);
             }
+            ex.role_end(list ? 10 : 3, r0);
             // the winners of the departure lanes take the slots that were free at the beginning of the tick, lower lane first
-            for (int d = B - 1 - tid; d < T.n_dep; d += B) {
+            for (int d = all ? B - 1 - tid : 63 - ln; ins && d < T.n_dep; d += all ? B : 64) {
                 if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
                 int rank = rs_popc(L.insm[d >> 5] & ((1u << (d & 31)) - 1u));
                 for (int w = 0; w < (d >> 5); ++w) rank += rs_popc(L.insm[w]);
@@ -1072,7 +1103,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 Node nn; nn.pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
                 nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.pad[0] = nn.pad[1] = 0;
                 nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(nn.pos, lane_cells(LRd)), s, false);
-                if (more) nn.fl = (uint8_t)classify(T, L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, (int)RR.start, k, sfn, t + 1);
+                if (more) nn.fl = (uint8_t)classify(L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, cont_row(T, (int)RR.start), k, sfn, t + 1);
                 L.node[s] = nn;
                 Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.lct = 0;
                 na.nlink = cache_link(T, LRd, RR.depart_lane, (int)RR.start, k);
@@ -1089,9 +1120,10 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 if (s + 1 > top) top = s + 1;
                 // (a standing vehicle does not register an approach)
             }
-            if (active) rs_atomic_add(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
-            if (halted) rs_atomic_add(&L.sc[SC_STATS + ST_WAITING], halted);
-            if (top) rs_atomic_max(&L.sc[cur ? SC_HW : SC_HWNEW], top);
+            rs_wave_add(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
+            rs_wave_add(&L.sc[SC_STATS + ST_WAITING], halted);
+            rs_wave_max(&L.sc[cur ? SC_HW : SC_HWNEW], top);
+            ex.role_end(15, r0);
         });
         cur ^= 1;
     }

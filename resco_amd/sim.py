@@ -73,6 +73,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('HIP extension %s is missing: build it with `python -m resco_amd.build` '
                            '(there is no CPU fallback)' % LIB_PATH)
+    # PyTorch ships its own copy of the HIP runtime: when it is going to be used in this process (device tensors over the
+    # library's buffers, torch.distributed), it has to be the one that is loaded first -- a process that initialises
+    # /opt/rocm's runtime through this library and torch's afterwards ends up with "No HIP GPUs are available" in torch.
+    if os.environ.get('RESCO_NO_TORCH') != '1':
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     _lib = bind(C.CDLL(LIB_PATH))
     return _lib
 

@@ -26,6 +26,9 @@ static inline void rs_atomic_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; 
 static inline void rs_atomic_max(int32_t *p, int32_t v) { if (v > *p) *p = v; }
 static inline void rs_atomic_add(int32_t *p, int32_t v) { *p += v; }
 static inline int32_t rs_atomic_fetch_add(int32_t *p, int32_t v) { const int32_t o = *p; *p += v; return o; }
+static inline int32_t rs_wave_ticket(int32_t *p) { return (*p)++; }
+static inline void rs_wave_add(int32_t *p, int32_t v) { *p += v; }
+static inline void rs_wave_max(int32_t *p, int32_t v) { if (v > *p) *p = v; }
 static inline void rs_atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
 static inline uint32_t rs_atomic_fetch_or(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
 static inline void rs_atomic_and(uint32_t *p, uint32_t v) { *p &= v; }
@@ -68,6 +71,8 @@ static long rs_dbg_chain = 0;         // chain-walk steps of the current phase (
 #include "resco_step.h"
 
 struct HostExec {
+    unsigned long long role_begin() const { return 0ull; }
+    void role_end(int, unsigned long long) const {}
     int B;
     int order;          // 0 ascending, 1 descending, 2 shuffled (a different permutation in every phase)
     uint32_t rng = 12345u;

@@ -8,6 +8,7 @@ from resco_amd.scenario import Scenario
 from resco_amd.sim import BatchedSim
 name = sys.argv[1] if len(sys.argv) > 1 else 'ingolstadt21'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+n_envs = n
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
 sim = BatchedSim(sc, n, seed=0, sigma=-1.0, speed_dev=1, block_threads=block)
@@ -17,8 +18,14 @@ sim.phase_profile(True)
 for k in range(100, 160):
     sim.act_random(k); sim.step(None)
 acc = sim.phase_profile(False)
-names = ['L0 init', 'L1 load+prep', 'L2 register', '-', 'P plan+lc', 'C insert?+tls', 'M move+insert', '-', '-', '-', '-', 'O0', 'O1 observe', 'O2 outputs', 'O3']
-tot = float(sum(acc)) or 1.0
-for nm, a in zip(names, acc):
-    print('%-12s %6.2f %%' % (nm, 100.0 * a / tot))
+names = ['L0 init', 'L1 load+prep', 'L2 register', '-', 'P plan+lc', 'C insert?+tls', 'M move+insert', '-', '-', '-', '-', 'O0', 'O1 observe', 'O2 outputs', 'O3', '-']
+roles = {7: 'P look-ahead list', 8: 'P lane-change list', 9: 'P slots', 10: 'M leavers list', 3: 'M slots', 15: 'M whole body'}
+tot = float(sum(a for i, a in enumerate(acc) if i not in roles)) or 1.0
+for i, (nm, a) in enumerate(zip(names, acc)):
+    if i not in roles and nm != '-':
+        print('%-14s %6.2f %%' % (nm, 100.0 * a / tot))
+for i, nm in roles.items():
+    cnt, ticks = acc[i] >> 40, acc[i] & ((1 << 40) - 1)
+    if cnt:
+        print('wave role %-20s %6.2f us per wave per tick (%.2f waves per tick)' % (nm, ticks / cnt / 100.0, cnt / (60.0 * ((n_envs + 15) // 16) * 10)))
 print('total ticks (100 MHz) per env-step per workgroup: %.0f' % (tot / 60 / n))
