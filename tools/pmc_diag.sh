@@ -4,7 +4,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmcdiag}
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 100 --no-cpu-baseline"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps ${2:-300} --warmup ${3:-60} --no-cpu-baseline"
 mkdir -p $OUT
 i=0
 for set in "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_CYCLES" \
