@@ -52,9 +52,39 @@ def designed_bytes_per_env_step(sc, mean_active):
     HBM-resident private fields it touches every tick (sf, coop, cooplead, tloss, swait), every output buffer"""
     S, O = sc.n_signals, sc.n_obs
     lmax = int((sc.sig_obs_start[1:] - sc.sig_obs_start[:-1]).max())
-    per_vehicle = (4 + 4 + 2 + 2 + 2) * 2 + 10 * (4 + 4 + 4 + 4 + 2)
+    # slab fields in and out once (pos, speed, lane, trip, cursor) + speed factor at the load; every tick: speed factor,
+    # both cooperation mailboxes (read), time loss and waiting time (read + write)
+    per_vehicle = (4 + 4 + 2 + 2 + 2) * 2 + 4 + 10 * (4 + 4 + 4 + (4 + 2) * 2)
     per_signal = 4 + 12 + 12 + 4 * (1 + 13 + 12 + 1 + 1 + 1 + 1 + 1 + 2 + 49)
     return mean_active * per_vehicle + S * per_signal + O * 40 + S * lmax * 10 + 24 + 80
+
+
+def pmc_traffic(args, n_local, world):
+    """HBM bytes per launch from the PMC counters: they are collected in SEPARATE rocprofv3 --pmc passes of this very
+    command (tools/pmc_passes.sh -> profiles/r02_pmc_summary.json), so the figure is reported only when this run's
+    workload and window are the ones those passes measured; otherwise None."""
+    import re
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
+    note = ('HBM bytes per launch come from separate rocprofv3 --pmc passes of `bench.py --steps 300 --warmup 60` '
+            '(tools/pmc_passes.sh, profiles/r02_pmc_summary.json); this run has another workload or window')
+    try:
+        with open(path) as f:
+            pm = json.load(f)
+        m = re.search(r'--steps (\d+) --warmup (\d+)', pm['command'])
+        same = (m is not None and int(m.group(1)) == args.steps and int(m.group(2)) == args.warmup and world == 1 and
+                args.map == 'ingolstadt21' and n_local == 4096 and ' --map' not in pm['command'] and ' --envs' not in pm['command'])
+        if not same:
+            return None, note
+        c = pm['counters']
+        fetch_kib, write_kib = c['FETCH_SIZE']['per_launch_avg'], c['WRITE_SIZE']['per_launch_avg']
+        # MI355X_MICROARCH.md (HBM / rocprofv3): both counters are in KiB; gfx950's FETCH_SIZE counts half of the bytes
+        return (2.0 * fetch_kib + write_kib) * 1024.0, (
+            '(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, averaged over the %d launches of the PMC passes of this same '
+            'command (profiles/r02_pmc_summary.json): %.0f + %.0f MB; the state of 4096 environments (%.0f MB) is written '
+            'through to HBM every tick by the per-vehicle waiting / time-loss counters and the register spills'
+            % (c['FETCH_SIZE']['launches'], 2.0 * fetch_kib * 1024 / 1e6, write_kib * 1024 / 1e6, 51.0 * 1024 * n_local / 1e6))
+    except Exception:
+        return None, note
 
 
 EPISODE_MID = 180
@@ -217,6 +247,7 @@ def main():
     k_avg_s = (kernel_ms / max(1, launches)) * 1e-3
     achieved = b_alg * n_local / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
     w0 = window_start(args.steps, args.warmup)
+    traffic, traffic_note = pmc_traffic(args, n_local, world)
     out = {
         'metric': 'env-steps/sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
@@ -230,9 +261,7 @@ def main():
                    'parallelism': 'env-batch split x%d, no collective on the data path' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': None,
-                     'traffic_note': 'HBM bytes per launch are measured in separate rocprofv3 --pmc passes (tools/pmc_passes.sh; '
-                                     'profiles/r02_* hold the summary for the default window) and are not a property of this run',
+                     'traffic': traffic, 'traffic_note': traffic_note,
                      'kernel': 'rs_step_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
                      'algorithmic_bytes_per_env_step': b_alg, 'env_steps_per_launch': n_local,
                      'formula': 'SURVEY 8(d): 60*V + 12*S + 20*SL + 8*S', 'designed_bytes_per_env_step': b_wide,

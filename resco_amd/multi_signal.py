@@ -329,14 +329,28 @@ class VecMultiSignal:
         self.n_actions = [int(g) for g in self.scenario.tls_ngreen]
         self._tensors = {}
 
+    # registry names that are not a device buffer of their own but a cheap arrangement of buffers (torch ops on the stream)
+    DERIVED = ('drq',)
+
     def tensor(self, name):
         t = self._tensors.get(name)
         if t is None:
             t = self._tensors[name] = self.sim.tensor(name)
         return t
 
+    def derived(self, name):
+        """states.drq (reference states.py:9-28) for all environments: [N, n_obs, 5] rows (lane position == phase, approach,
+        total_wait, queue, speed sum) from the lane aggregates (queue, approach, total_wait, max_wait, speed_sum) and the
+        one-hot column the kernel writes into drq_norm"""
+        import torch
+        if name == 'drq':
+            agg, onehot = self.tensor('lane_agg'), self.tensor('drq_norm')[..., 0]
+            return torch.stack((onehot, agg[..., 1], agg[..., 2], agg[..., 0], agg[..., 4]), dim=-1)
+        raise KeyError(name)
+
     def _pack(self):
-        return ({n: self.tensor(n) for n in self.state_names}, {n: self.tensor(n) for n in self.reward_names})
+        return ({n: (self.derived(n) if n in self.DERIVED else self.tensor(n)) for n in self.state_names},
+                {n: self.tensor(n) for n in self.reward_names})
 
     def _stream(self, stream):
         # the tensors handed out are consumed by torch kernels: launch on torch's current stream unless told otherwise

@@ -956,3 +956,34 @@ def test_arrival_departure_counters_and_mplight_full_batched():
                 np.testing.assert_array_equal(mf[e], ref['mplight_full'])
     assert sim.read('arrivals').sum() > 0 and sim.read('departures').sum() > 0
     sim.close()
+
+
+def test_batched_drq_state_equals_the_signal_views():
+    """VecMultiSignal's derived `drq` state (all environments, torch ops over the device buffers) equals states.drq computed
+    through the Signal views of a single-environment MultiSignal run with the same seed and actions (reference
+    states.py:9-28)"""
+    import torch
+    from resco_amd import rewards, states
+    from resco_amd.multi_signal import MultiSignal, VecMultiSignal
+    # (MultiSignal's first episode runs with seed + 0x9E3779B1, the reference restarts SUMO with --random per episode)
+    vec = VecMultiSignal('cologne3', 4, states=('drq', 'drq_norm'), rewards=('wait',), seed=(6 + 0x9E3779B1) & 0xFFFFFFFF)
+    env = MultiSignal('t', 'cologne3', None, states.drq, rewards.wait, yellow_length=3, end_time=28800,
+                      log_dir=tempfile.mkdtemp() + os.sep, seed=6)
+    vec.reset()
+    env.reset()
+    sc = vec.scenario
+    rng = np.random.default_rng(4)
+    for k in range(25):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        obs, _, _, _ = vec.step(torch.as_tensor(np.repeat(a[None, :], 4, axis=0), device='cuda'))
+        ref, _, _, _ = env.step({sid: int(a[i]) for i, sid in enumerate(env.all_ts_ids)})
+    vec.sync()
+    got = obs['drq'][0].cpu().numpy()
+    o = 0
+    for sid in env.all_ts_ids:
+        rows = np.asarray(ref[sid])[0]
+        np.testing.assert_allclose(got[o:o + len(rows)], rows, rtol=0, atol=1e-4)       # (speed sums: 16.16 fixed point on the device)
+        o += len(rows)
+    assert o == got.shape[0] and got[:, 1:].sum() > 0
+    vec.close()
+    env.close()
