@@ -1,14 +1,23 @@
 /*
  * resco_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).  See resco_oracle.h.
  *
- * Phase-synchronous restatement: every phase reads the state left by the previous phase and
- * writes new state, with no dependence on iteration order, so that a data-parallel
- * implementation (one GPU lane per vehicle) must reproduce it bit-for-bit.  All kinematics
- * are IEEE fp32 with no fused contraction (compile with -ffp-contract=off).
+ * What it restates and what pins it:
+ *   - everything ABOVE the simulator (phase lists, create_yellows, prep / set FSM, Signal.observe, the RESCO waiting rule,
+ *     states, rewards, arrivals / departures) follows resco_benchmark/traffic_signal.py and multi_signal.py line by line
+ *     (citations at the functions) and is PINNED: the reference's unmodified Python runs over this oracle in the build
+ *     container (oracle/ref_harness.py) and its outputs are the golden fixtures (tests/golden/, tests/test_oracle_golden.py);
+ *   - simulationStep() itself is SUMO, a third-party binary that is neither vendored nor installable here: the
+ *     microsimulation below is this build's OWN model after SUMO's published algorithms ([SUMO-K] in SURVEY.md).
+ *     PARITY UNPINNED against SUMO; tools/sumo_runner.py holds the comparison for a box that has SUMO.
  *
- * Per tick (SUMO MSNet::simulationStep order [SUMO-K]):
- *   P0 TLS switch events   P1 lane lists   P2 insertion   P3 link approach registration
- *   P4 plan (Krauss)       P5 move         P6 lane lists  P7 lane change
+ * Synchronous tick: every decision of a tick is taken on the state at its beginning and no phase reads what the same
+ * phase writes, so a data-parallel implementation (one GPU lane per vehicle) must reproduce it bit-for-bit in any order.
+ * All kinematics are IEEE fp32 with no fused contraction (compile with -ffp-contract=off).
+ *
+ * Per tick (orc_tick):
+ *   TLS switch events -> lane lists -> link approach registration -> plan (Krauss, links, foes, cooperation) ->
+ *   lane-change decision -> insertion check (with the planned speeds) -> move (sideways, forward, hand-over, arrival) ->
+ *   insertion
  */
 #include "resco_oracle.h"
 #include "../include/resco_model.h"

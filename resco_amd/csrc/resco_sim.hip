@@ -406,9 +406,11 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     // threads (<= 512), -(10000 + threads) the 80-VGPR build -- tuning knobs, see DESIGN.md
     if (block_threads < 0) { h->use_v128 = 1; block_threads = -block_threads; if (block_threads >= 10000) { h->use_v128 = 2; block_threads -= 10000; } }
     else if (block_threads == 0) {
-        // default: one thread per slot up to 512 threads (a 1024-slot scenario: two slots per thread), 80 VGPRs -- three
-        // workgroups of 512 threads share a CU when the working memory stays below 53 KB
-        block_threads = C > 512 ? 512 : C;
+        // default: one thread per TWO slots (the capacity is the episode's peak, about twice the typical occupancy), at most
+        // 512 threads, 80 VGPRs -- three workgroups of 512 threads share a CU when the working memory stays below 53 KB
+        // (DESIGN.md section 4).  Measured: cologne1 (128 slots) 64 threads 12.3 M vs 128 threads 10.1 M env-steps/s,
+        // cologne8 (256 slots) 128 threads 6.5 M vs 256 threads 6.3 M
+        block_threads = C >= 1024 ? 512 : (((C / 2) + 63) / 64) * 64;
         h->use_v128 = 2;
     }
     if (block_threads % 64 || block_threads > (h->use_v128 == 1 ? 512 : (h->use_v128 == 2 ? 768 : 1024)) || block_threads < 64) {
