@@ -196,6 +196,8 @@ class BatchedDQNLearner:
         the target network every ``target_update`` steps."""
         self.t += 1
         out = None
+        if self.t % self.target_update == 0:        # PFRL's DQN.batch_observe_train syncs the target BEFORE the replay update
+            self.sync_target()
         if len(replay) >= self.batch_size:
             for _ in range(updates):
                 if getattr(self, '_graph', None) is not None and replay is self._graph_replay:
@@ -204,6 +206,4 @@ class BatchedDQNLearner:
                     out = self._graph_loss
                 else:
                     out = self.update(replay.sample(self.batch_size, generator))
-        if self.t % self.target_update == 0:
-            self.sync_target()
         return out

@@ -20,7 +20,7 @@ from . import states as _states
 from .config.map_config import map_configs
 from .config.signal_config import signal_configs
 from .scenario import Scenario, compile_from_sumocfg
-from .sim import BatchedSim, torch_stream
+from .sim import BatchedSim, speed_factor, torch_stream
 from .traffic_signal import Phase, Signal
 
 try:  # gym is optional: only observation_space / action_space use it
@@ -79,6 +79,8 @@ class MultiSignal(_EnvBase):
 
         self.scenario = scenario if scenario is not None else load_scenario(map_name, net, lights, yellow_length)
         sc = self.scenario
+        if sc.yellow_length != yellow_length:       # the yellow phases are compiled into the scenario's programmes
+            raise EnvironmentError('scenario %s was compiled with yellow_length=%d (asked %d)' % (map_name, sc.yellow_length, yellow_length))
         self._base_seed = int.from_bytes(os.urandom(4), 'little') if seed is None else int(seed)
         self.sim = BatchedSim(sc, 1, device=device, seed=self._base_seed, max_distance=max_distance, sigma=sigma,
                               speed_dev=speed_dev, fixed_program=1 if fixed_program else 0,
@@ -130,11 +132,22 @@ class MultiSignal(_EnvBase):
             self._cache[name] = hit
         return hit[1]
 
-    def _evaluate(self, fn):
-        """fn(signals) through the kernel-produced buffer when the registry knows one, else on the host."""
+    def _is_fast(self, fn):
         fast = getattr(fn, 'fast_buffer', None) if self.use_fast_path else None
         registry = _states.REGISTRY.get(fn.__name__) is fn or _rewards.REGISTRY.get(fn.__name__) is fn
-        if not fast or not registry:
+        return bool(fast) and registry
+
+    def _observe_all(self):
+        """Signal.observe() runs for every signal in every step of the reference (multi_signal.py:183-186): when a plugin
+        function reads the Signal views, every view is decoded once per step, so that `arrivals` / `departures` are relative
+        to the previous STEP also for a signal the function did not look at last time."""
+        if not (self._is_fast(self.state_fn) and self._is_fast(self.reward_fn)):
+            for sg in self.signals.values():
+                sg.full_observation
+
+    def _evaluate(self, fn):
+        """fn(signals) through the kernel-produced buffer when the registry knows one, else on the host."""
+        if not self._is_fast(fn):
             return fn(self.signals)
         sc, e = self.scenario, self.view_env
         out = {}
@@ -197,6 +210,7 @@ class MultiSignal(_EnvBase):
         for ts in self.signal_ids:
             self.signals[ts].last_step_vehicles = None
             self.wait_metric[ts] = 0.0
+        self._observe_all()
         states = self._evaluate(self.state_fn)
         if self.gymma:
             return [states[ts] for ts in self.ts_order]
@@ -208,6 +222,7 @@ class MultiSignal(_EnvBase):
         a = np.asarray([[int(act[ts]) for ts in self.all_ts_ids]], dtype=np.int32)
         self.sim.step(a)
         self._version += 1
+        self._observe_all()
         observations = self._evaluate(self.state_fn)
         rewards = self._evaluate(self.reward_fn)
         self.calc_metrics(rewards)
@@ -262,7 +277,9 @@ class MultiSignal(_EnvBase):
 
         done = np.nonzero(log[:, 1] > 0)[0]
         for k in done[np.argsort(log[done, 1], kind='stable')]:
-            recs.append(rec(int(k), int(log[k, 0]), int(log[k, 1]), log[k, 2] / 1024.0, int(log[k, 3]), 1.0))
+            # (the trip log does not keep the speed factor: it is a function of seed, env and trip)
+            sf = speed_factor(self.sim.seed, self.sim.env_base + e, int(k), sc.vtype_params[int(sc.trip_vtype[k])], self.sim.speed_dev)
+            recs.append(rec(int(k), int(log[k, 0]), int(log[k, 1]), log[k, 2] / 1024.0, int(log[k, 3]), sf))
         lane, trip = self.sim.read('veh_lane')[e], self.sim.read('veh_trip')[e]
         dep, tl = self.sim.read('veh_depart')[e], self.sim.read('veh_tloss')[e]
         wt, sf = self.sim.read('veh_wtot')[e], self.sim.read('veh_sf')[e]

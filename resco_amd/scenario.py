@@ -777,14 +777,26 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
     # ---- observation tables
     obs_lane_ids, obs_lane, sig_obs_start = [], [], [0]
     obs_index = {}
+    missing_obs_lanes = []
     for sid in tl_ids:
         meta = derive_signal_lanes(sig_cfg_map, sid)
         signal_meta[sid].update(meta)
         for lane in meta['lanes']:
+            if lane in obs_index:
+                # one detector row per lane: the reference gives every signal its own view of a shared lane
+                # (traffic_signal.py:189-247); no packaged map has one, a recompiled one must not get it silently wrong
+                raise ValueError('lane %s is observed by more than one signal (%s): not supported' % (lane, sid))
             obs_index[lane] = len(obs_lane_ids)
             obs_lane_ids.append(lane)
+            if lane not in lane_index:
+                missing_obs_lanes.append(lane)
             obs_lane.append(lane_index.get(lane, -1))
         sig_obs_start.append(len(obs_lane_ids))
+    if missing_obs_lanes:
+        # signal_configs names lanes the net does not have (cologne8: '-24487264_0', '-22959475#4_0'): the reference's
+        # getLastStepVehicleIDs would raise on them only when called; their rows stay zero here
+        import warnings
+        warnings.warn('%s: observed lanes missing from the net (their state rows stay zero): %s' % (name, missing_obs_lanes))
     lane_obs = np.full(nl, -1, np.int32)
     for gi, li in enumerate(obs_lane):
         if li >= 0:

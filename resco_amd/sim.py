@@ -85,6 +85,41 @@ def load_library():
     return _lib
 
 
+def _murmur(seed, words):
+    """the counter-based hash of the model (resco_amd/csrc/resco_step.h: d_hash) on the host"""
+    M = 0xFFFFFFFF
+    rotl = lambda x, r: ((x << r) | (x >> (32 - r))) & M
+    h = seed & M
+    for k in words:
+        k = (k * 0xcc9e2d51) & M
+        k = rotl(k, 15)
+        k = (k * 0x1b873593) & M
+        h ^= k
+        h = rotl(h, 13)
+        h = (h * 5 + 0xe6546b64) & M
+    h ^= 16
+    h ^= h >> 16
+    h = (h * 0x85ebca6b) & M
+    h ^= h >> 13
+    h = (h * 0xc2b2ae35) & M
+    h ^= h >> 16
+    return h
+
+
+def speed_factor(seed, env, trip, vt_row, speed_dev=1):
+    """speedFactor of a trip (resco_step.h: speed_factor): a function of (seed, global env index, trip) only, so it can be
+    recomputed for trips that have left the network (tripinfo output)"""
+    mean, dev = np.float32(vt_row[7]), np.float32(vt_row[8])
+    if not speed_dev:
+        return float(mean)
+    s = np.float32(0.0)
+    for i in range(4):
+        s = np.float32(s + np.float32(_murmur(seed, (env, trip, 0xFFFFFFFF, i)) >> 8) * np.float32(1.0 / 16777216.0))
+    z = np.float32((s - np.float32(2.0)) * np.float32(1.7320508))
+    f = np.float32(mean + np.float32(dev * z))
+    return float(min(max(f, np.float32(0.2)), np.float32(2.0)))
+
+
 def torch_stream(device=None):
     """The stream argument that orders a launch with PyTorch's current stream.  PyTorch's default stream has the
     handle 0, which the C ABI reads as "the handle's own stream": it is mapped to hipStreamLegacy (1)."""
@@ -122,6 +157,7 @@ class BatchedSim:
             self._h = None
             raise RuntimeError('rs_create failed (%d): %s' % (rc, msg.decode() if msg else '?'))
         self.S, self.O, self.C = scenario.n_signals, scenario.n_obs, scenario.capacity
+        self.seed, self.env_base, self.speed_dev = int(seed) & 0xFFFFFFFF, int(env_base), int(speed_dev)
         self._maxwave_ready = False
         self._meta = {}
         for name, bid in BUF_ID.items():
@@ -182,7 +218,8 @@ class BatchedSim:
         self._check(self._lib.rs_reinit_signals(self._h, stream))
 
     def set_seed(self, seed):
-        self._check(self._lib.rs_set_seed(self._h, int(seed) & 0xFFFFFFFF))
+        self.seed = int(seed) & 0xFFFFFFFF
+        self._check(self._lib.rs_set_seed(self._h, self.seed))
 
     def sync(self):
         self._check(self._lib.rs_sync(self._h))

@@ -5,7 +5,7 @@ import types
 import numpy as np
 import pytest
 
-from conftest import HOT_CASES, load_golden
+from conftest import HOT_CASES, load_golden, load_scenario
 from resco_amd import rewards, states
 from resco_amd.agents.static_agents import MAXPRESSURE, MAXWAVE, STOCHASTIC
 from resco_amd.config.map_config import map_configs
@@ -102,3 +102,17 @@ def test_config_surface():
     assert 'phase_pairs' in c1 and c1['valid_acts'] is None
     assert signal_configs['ingolstadt21']['89173763']['downstream']['S'] == '89173763'   # quirk kept verbatim
     assert signal_configs['cologne8']['valid_acts']['247379907'] == {4: 0, 5: 1, 0: 2}
+
+
+def test_host_speed_factor_is_the_models():
+    """tripinfo's speedFactor of a finished trip is recomputed on the host (resco_amd.sim.speed_factor): same counter
+    hash, same fp32 arithmetic as the model (oracle: orc_hash; a vehicle's factor in the oracle's vehicle table)"""
+    from oracle.pyoracle import OracleEnv, lib
+    from resco_amd.sim import _murmur, speed_factor
+    L = lib()
+    for k in range(64):
+        assert _murmur(1234, (7, k, 0xFFFFFFFF, k % 4)) == L.orc_hash(1234, 7, k, 0xFFFFFFFF, k % 4)
+    sc = load_scenario('cologne1')
+    f = [speed_factor(9, 2, k, sc.vtype_params[int(sc.trip_vtype[k])]) for k in range(200)]
+    assert 0.2 <= min(f) and max(f) <= 2.0 and 0.05 < float(np.std(f)) < 0.2
+    assert speed_factor(9, 2, 5, sc.vtype_params[int(sc.trip_vtype[5])], speed_dev=0) == float(sc.vtype_params[int(sc.trip_vtype[5])][7])

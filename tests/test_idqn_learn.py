@@ -113,9 +113,12 @@ def test_observe_step_schedule():
     before = copy.deepcopy(learner.target.state_dict())
     for step in range(1, 6):
         rp.push(_obs(4, rng), torch.zeros(4, 3), torch.ones(4, 3), done=False)
+        online_before = copy.deepcopy(net.state_dict())
         out = learner.observe_step(rp, g)
         assert (out is None) == (len(rp) < 8)                              # replay_start_size = minibatch size
         if step < 5:
             assert all(torch.equal(before[k], v) for k, v in learner.target.state_dict().items())
     assert learner.t == 5 and learner.n_updates == 3
-    assert all(torch.equal(v, learner.target.state_dict()[k]) for k, v in net.state_dict().items())   # hard copy at t=5
+    # hard copy at t = 5, BEFORE that step's update (PFRL's DQN.batch_observe_train order)
+    assert all(torch.equal(v, learner.target.state_dict()[k]) for k, v in online_before.items())
+    assert any(not torch.equal(v, learner.target.state_dict()[k]) for k, v in net.state_dict().items())
