@@ -162,6 +162,10 @@ enum rs_buffer {
     RS_BUF_ARRIVALS,       /* i32 [N][S]  |Signal.arrivals| of the last observe (traffic_signal.py:222-229) */
     RS_BUF_DEPARTURES,     /* i32 [N][S]  |Signal.departures| of the last observe */
     RS_BUF_MPLIGHT_FULL,   /* f32 [N][S][49] states.mplight_full (states.py:83-113) */
+    RS_BUF_LANE_ARRIVALS,  /* i32 [N][n_obs] vehicles of the lane that are in their signal's `arrivals` set of the last observe
+                            * (the fringe arrivals of rewards.fma2c, rewards.py:94-97) */
+    RS_BUF_VEH_COOP_ODD,   /* u32 [N][C]  the mailboxes are double-buffered by tick parity: requests written in odd ticks ... */
+    RS_BUF_VEH_COOPLEAD_ODD, /* u32 [N][C] ... (RS_BUF_VEH_COOP / _COOPLEAD hold those of even ticks) */
     RS_BUF_COUNT
 };
 enum rs_dtype { RS_F32 = 0, RS_I32 = 1, RS_U16 = 2, RS_U8 = 3, RS_F16 = 4, RS_I64 = 5, RS_U32 = 6 };

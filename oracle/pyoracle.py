@@ -53,7 +53,7 @@ def lib():
         L.orc_mplight_full.restype = C.POINTER(C.c_float)
         L.orc_reinit_signals.argtypes = [C.c_void_p]
         L.orc_reinit_signals.restype = None
-        for f in ('orc_phase', 'orc_mplight', 'orc_wave', 'orc_pressure', 'orc_queue_sum', 'orc_queue_max', 'orc_arrivals', 'orc_departures'):
+        for f in ('orc_phase', 'orc_mplight', 'orc_wave', 'orc_pressure', 'orc_queue_sum', 'orc_queue_max', 'orc_arrivals', 'orc_departures', 'orc_lane_arrivals'):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.POINTER(C.c_int32)
         L.orc_get_vehicles.argtypes = [C.c_void_p, C.c_void_p]
@@ -135,6 +135,7 @@ class OracleEnv:
                     wait_norm=self._f('orc_wait_norm', (S,)), pressure=self._f('orc_pressure', (S,)),
                     queue_sum=self._f('orc_queue_sum', (S,)), queue_max=self._f('orc_queue_max', (S,)),
                     arrivals=self._f('orc_arrivals', (S,)), departures=self._f('orc_departures', (S,)),
+                    lane_arrivals=self._f('orc_lane_arrivals', (O,)),
                     mplight_full=self._f('orc_mplight_full', (S, 49)))
 
     def vehicles(self):

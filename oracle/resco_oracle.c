@@ -76,6 +76,7 @@ struct orc_env {
     uint32_t *agg_s;
     int32_t *out_phase, *mplight, *wave, *pressure, *queue_sum, *queue_max;
     int32_t *sig_arr, *sig_dep, *out_arr, *out_dep;     /* |Signal.arrivals| / |Signal.departures| of the running / last observe */
+    int32_t *lane_arr;      /* [n_obs] vehicles of the lane that are in their signal's `arrivals` set (rewards.fma2c fringe arrivals) */
     float *mplight_full;
     int64_t stats[10];
 };
@@ -281,7 +282,7 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     ALLOC(e->agg_q, O); ALLOC(e->agg_a, O); ALLOC(e->agg_w, O); ALLOC(e->agg_m, O); ALLOC(e->agg_s, O);
     ALLOC(e->out_phase, S); ALLOC(e->mplight, S * 13); ALLOC(e->wave, S * 12); ALLOC(e->pressure, S);
     ALLOC(e->queue_sum, S); ALLOC(e->queue_max, S);
-    ALLOC(e->sig_arr, S); ALLOC(e->sig_dep, S); ALLOC(e->out_arr, S); ALLOC(e->out_dep, S); ALLOC(e->mplight_full, S * 49);
+    ALLOC(e->sig_arr, S); ALLOC(e->sig_dep, S); ALLOC(e->out_arr, S); ALLOC(e->out_dep, S); ALLOC(e->mplight_full, S * 49); ALLOC(e->lane_arr, sc->n_obs);
     e->maxlen = 0.0f;
     for (int32_t v = 0; v < sc->n_vtypes; ++v) if (sc->vtype_params[v * VT_COLS + VT_LENGTH] > e->maxlen) e->maxlen = sc->vtype_params[v * VT_COLS + VT_LENGTH];
     orc_reset(e);
@@ -296,7 +297,7 @@ void orc_destroy(orc_env *e) {
     free(e->phase); free(e->left); free(e->next_phase);
     free(e->lane_agg); free(e->drq_norm); free(e->wait); free(e->wait_norm);
     free(e->agg_q); free(e->agg_a); free(e->agg_w); free(e->agg_m); free(e->agg_s);
-    free(e->sig_arr); free(e->sig_dep); free(e->out_arr); free(e->out_dep); free(e->mplight_full);
+    free(e->sig_arr); free(e->sig_dep); free(e->out_arr); free(e->out_dep); free(e->mplight_full); free(e->lane_arr);
     free(e->out_phase); free(e->mplight); free(e->wave); free(e->pressure); free(e->queue_sum); free(e->queue_max);
     free(e);
 }
@@ -773,7 +774,7 @@ void orc_tick(orc_env *e) {
 void orc_observe(orc_env *e) {
     const orc_scenario *sc = e->sc;
     int32_t O = sc->n_obs, S = sc->n_signals;
-    for (int32_t i = 0; i < O; ++i) { e->agg_q[i] = e->agg_a[i] = e->agg_w[i] = e->agg_m[i] = 0; e->agg_s[i] = 0; }
+    for (int32_t i = 0; i < O; ++i) { e->agg_q[i] = e->agg_a[i] = e->agg_w[i] = e->agg_m[i] = 0; e->agg_s[i] = 0; e->lane_arr[i] = 0; }
     /* obs-lane -> signal */
     for (int32_t s = 0; s < e->hw; ++s) {
         int32_t k = e->trip[s];
@@ -796,6 +797,7 @@ void orc_observe(orc_env *e) {
         if (e->owner[s] != (uint8_t)sig) {
             e->resco_wait[s] = 0;
             e->sig_arr[sig] += 1;
+            e->lane_arr[oi] += 1;
             if (e->owner[s] != OWNER_NONE) e->sig_dep[e->owner[s]] += 1;
         }
         if (e->resco_wait[s] > 0) {
@@ -890,6 +892,7 @@ const int32_t *orc_pressure(const orc_env *e) { return e->pressure; }
 const int32_t *orc_queue_sum(const orc_env *e) { return e->queue_sum; }
 const int32_t *orc_queue_max(const orc_env *e) { return e->queue_max; }
 const int32_t *orc_arrivals(const orc_env *e) { return e->out_arr; }
+const int32_t *orc_lane_arrivals(const orc_env *e) { return e->lane_arr; }
 const int32_t *orc_departures(const orc_env *e) { return e->out_dep; }
 const float *orc_mplight_full(const orc_env *e) { return e->mplight_full; }
 /* fresh Signal objects on the running simulation (what MultiSignal.reset does, multi_signal.py:141-147): the RESCO

@@ -399,6 +399,8 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_ARRIVALS, O.arrivals(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_DEPARTURES, O.departures(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_MPLIGHT_FULL, O.mplight_full(), RS_F32, 3, n, s, 49);
+    set_buf(h, RS_BUF_LANE_ARRIVALS, O.lane_arr(), RS_I32, 2, n, sc->n_obs);
+    set_buf(h, RS_BUF_VEH_COOP_ODD, G.coop(1), RS_U32, 2, n, c); set_buf(h, RS_BUF_VEH_COOPLEAD_ODD, G.cooplead(1), RS_U32, 2, n, c);
 
     h->lds = lds_carve(nullptr, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
@@ -603,7 +605,8 @@ static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, 
                                 RS_BUF_ENV, RS_BUF_TLS, RS_BUF_VEH_POS, RS_BUF_VEH_SPEED, RS_BUF_VEH_ACCEL, RS_BUF_VEH_TLOSS,
                                 RS_BUF_VEH_LANE, RS_BUF_VEH_TRIP, RS_BUF_VEH_CURSOR, RS_BUF_VEH_SWAIT, RS_BUF_VEH_RWAIT,
                                 RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_VEH_SF, RS_BUF_VEH_WTOT, RS_BUF_TRIP_LOG, RS_BUF_STATS,
-                                RS_BUF_DEP_NEXT, RS_BUF_VEH_COOP, RS_BUF_VEH_COOPLEAD, RS_BUF_ARRIVALS, RS_BUF_DEPARTURES, RS_BUF_MPLIGHT_FULL};
+                                RS_BUF_DEP_NEXT, RS_BUF_VEH_COOP, RS_BUF_VEH_COOPLEAD, RS_BUF_ARRIVALS, RS_BUF_DEPARTURES, RS_BUF_MPLIGHT_FULL,
+                                RS_BUF_LANE_ARRIVALS, RS_BUF_VEH_COOP_ODD, RS_BUF_VEH_COOPLEAD_ODD};
 extern "C" int rs_snapshot(rs_handle h, void **snap) {
     if (!h || !snap) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));

@@ -63,8 +63,9 @@ struct Out {        // one allocation; n = N, o = n_obs, s = n_signals, lm = lan
     RS_HD int32_t *arrivals() const { return RS_G((int32_t *)(base + 2 * a5() + 31 * ns())); }      // [N][S] |Signal.arrivals| of the last observe
     RS_HD int32_t *departures() const { return RS_G((int32_t *)(base + 2 * a5() + 32 * ns())); }    // [N][S] |Signal.departures|
     RS_HD float *mplight_full() const { return RS_G((float *)(base + 2 * a5() + 33 * ns())); }      // [N][S][49]
-    RS_HD uint16_t *drq_f16() const { return RS_G((uint16_t *)(base + 2 * a5() + 82 * ns())); }
-    RS_HD size_t bytes() const { return 2 * a5() + 82 * ns() + (size_t)n * s * lm * 5 * 2 + 64; }
+    RS_HD int32_t *lane_arr() const { return RS_G((int32_t *)(base + 2 * a5() + 82 * ns())); }     // [N][n_obs] vehicles of the lane that are in their signal's `arrivals` set
+    RS_HD uint16_t *drq_f16() const { return RS_G((uint16_t *)(base + 2 * a5() + 82 * ns() + a5() / 5)); }
+    RS_HD size_t bytes() const { return 2 * a5() + 82 * ns() + a5() / 5 + (size_t)n * s * lm * 5 * 2 + 64; }
 };
 
 // ------------------------------------------------------------------------------------------------ device math
@@ -174,7 +175,7 @@ struct Lds {
     LPtr<int32_t> arr;          // link approach registers
     LPtr<uint16_t> dep;         // head trip of every departure lane's backlog
     LPtr<uint32_t> alive, alive0, insm;     // bit per slot: occupied (now / at the beginning of the tick); bit per departure lane: inserts this tick
-    LPtr<int32_t> agg_q, agg_a, agg_w, agg_m;
+    LPtr<int32_t> agg_q, agg_a, agg_w, agg_m, agg_n;
     LPtr<uint32_t> agg_s;
     LPtr<int32_t> sig_arr, sig_dep;
     LPtr<int32_t> phase, left, nextp;
@@ -204,12 +205,12 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
 #define CARVE(field, bytes) { if (L) L->field.off = (uint32_t)o; o += align16(bytes); }
     CARVE(node, (size_t)C * 16) CARVE(aux, (size_t)C * 8)
     {
-        const size_t ab = align16((size_t)n_obs * 4), a = (size_t)C * 4, b = 5 * ab;
+        const size_t ab = align16((size_t)n_obs * 4), a = (size_t)C * 4, b = 6 * ab;
         if (L) {
             const uint32_t p = (uint32_t)o;
             L->vnx.off = p;
             L->agg_q.off = p; L->agg_a.off = p + (uint32_t)ab; L->agg_w.off = p + (uint32_t)(2 * ab);
-            L->agg_m.off = p + (uint32_t)(3 * ab); L->agg_s.off = p + (uint32_t)(4 * ab);
+            L->agg_m.off = p + (uint32_t)(3 * ab); L->agg_s.off = p + (uint32_t)(4 * ab); L->agg_n.off = p + (uint32_t)(5 * ab);
         }
         o += align16(a > b ? a : b);
     }
@@ -1131,7 +1132,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
 
     // ---- Signal.observe for every signal (traffic_signal.py:189-247)
     ex.phase(11, [&](int tid) {
-        for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; }
+        for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; L.agg_n[i] = 0; }
     });
     ex.phase(12, [&](int tid) {
         const int hw0 = G.env[env * 4 + 2];
@@ -1164,6 +1165,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             if (prev_owner != sig) {
                 rw = 0;
                 rs_atomic_add(&L.sig_arr[sig], 1);
+                rs_atomic_add(&L.agg_n[oi], 1);
                 if (prev_owner != (int)OWNER_NONE) rs_atomic_add(&L.sig_dep[prev_owner], 1);
             }
             if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
@@ -1191,6 +1193,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             O.lane_agg()[(size_t)env * NO * 5 + i] = raw;         // queue, approach, total_wait, max_wait, speed_sum
             O.drq_norm()[(size_t)env * NO * 5 + i] = nrm;         // one-hot(lane position == phase), approach, wait, queue, speed
         }
+        for (int i = tid; i < NO; i += B) O.lane_arr()[(size_t)env * NO + i] = L.agg_n[i];
         for (int i = tid; i < S * T.lmax * 5; i += B) {
             const int sg = i / (T.lmax * 5), r = i - sg * T.lmax * 5;
             const int l = r / 5, c = r - l * 5;

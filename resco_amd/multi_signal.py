@@ -347,7 +347,7 @@ class VecMultiSignal:
         self._tensors = {}
 
     # registry names that are not a device buffer of their own but a cheap arrangement of buffers (torch ops on the stream)
-    DERIVED = ('drq',)
+    DERIVED = ('drq', 'fma2c')
 
     def tensor(self, name):
         t = self._tensors.get(name)
@@ -365,9 +365,103 @@ class VecMultiSignal:
             return torch.stack((onehot, agg[..., 1], agg[..., 2], agg[..., 0], agg[..., 4]), dim=-1)
         raise KeyError(name)
 
+    # ---- FMA2C (states.py:162-229, rewards.py:72-136) for all environments: every worker / manager observation is a gather
+    # of normalised per-lane waves and waits, every reward a linear form of per-lane queues, waits, arrivals and the
+    # per-signal arrival / departure counters -- index tables built once from mdp_configs['FMA2C'] (activate() it first)
+    def _fma2c_tables(self):
+        import torch
+        if getattr(self, '_fma2c', None) is not None:
+            return self._fma2c
+        from .config.mdp_config import mdp_configs
+        cfg, sc = mdp_configs['FMA2C'], self.scenario
+        sup, alpha = cfg['supervisors'], float(cfg['alpha'])
+        ids = self.all_ts_ids
+        O, S = sc.n_obs, self.n_signals
+        lane_pos = {l: i for i, l in enumerate(sc.obs_lane_ids)}
+        lanes = {sid: list(sc.obs_lane_ids[int(sc.sig_obs_start[i]):int(sc.sig_obs_start[i + 1])]) for i, sid in enumerate(ids)}
+        meta = sc.signal_meta
+        fringes = {mgr: [] for mgr in cfg['management']}           # states._fma2c_regions
+        for sid in ids:
+            for direction, nb in meta[sid]['downstream'].items():
+                if nb is None or sup[nb] != sup[sid]:
+                    inbound = meta[sid]['inbounds_fr_direction'].get(direction)
+                    if inbound is not None:
+                        fringes[sup[sid]] += inbound
+        same_region = {sid: [nb for nb in meta[sid]['downstream'].values() if nb is not None and sup[nb] == sup[sid]] for sid in ids}
+        keys = list(ids) + list(cfg['management'].keys())
+        # states: feature vector F = [clip(wave / norm_wave), clip(max_wait / norm_wait)] per observed lane
+        s_idx, s_scale = {}, {}
+        mgr_terms = {mgr: ([lane_pos[l] for l in fl], [1.0] * len(fl)) for mgr, fl in fringes.items()}
+        for sid in ids:
+            idx = [lane_pos[l] for l in lanes[sid]]
+            sc_ = [1.0] * len(idx)
+            for nb in same_region[sid]:
+                idx += [lane_pos[l] for l in lanes[nb]]
+                sc_ += [alpha] * len(lanes[nb])
+            idx += [O + lane_pos[l] for l in lanes[sid]]
+            sc_ += [1.0] * len(lanes[sid])
+            s_idx[sid], s_scale[sid] = idx, sc_
+        for mgr in cfg['management']:
+            idx, sc_ = list(mgr_terms[mgr][0]), list(mgr_terms[mgr][1])
+            for n in cfg['management_neighbors'][mgr]:
+                idx += mgr_terms[n][0]
+                sc_ += [alpha] * len(mgr_terms[n][0])
+            s_idx[mgr], s_scale[mgr] = idx, sc_
+        dev = self.tensor('lane_agg').device
+        st = {k: (torch.as_tensor(s_idx[k], dtype=torch.long, device=dev), torch.as_tensor(s_scale[k], dtype=torch.float32, device=dev))
+              for k in keys}
+        # rewards: G = [queue (O), max_wait (O), lane arrivals (O), signal arrivals (S), signal departures (S)] @ W
+        W = np.zeros((3 * O + 2 * S, len(keys)), np.float32)
+        own = np.zeros((3 * O + 2 * S, S), np.float32)
+        for i, sid in enumerate(ids):
+            for l in lanes[sid]:
+                own[lane_pos[l], i] -= 1.0
+                own[O + lane_pos[l], i] -= float(cfg['coef'])
+        pos = {sid: i for i, sid in enumerate(ids)}
+        for i, sid in enumerate(ids):
+            W[:, i] = own[:, i]
+            for nb in same_region[sid]:
+                W[:, i] += alpha * own[:, pos[nb]]
+        mg = {mgr: np.zeros(3 * O + 2 * S, np.float32) for mgr in cfg['management']}
+        for i, sid in enumerate(ids):
+            m = mg[sup[sid]]
+            m[3 * O + S + i] += 1.0         # departures
+            m[3 * O + i] -= 1.0             # arrivals
+            for l in lanes[sid]:
+                if l in fringes[sup[sid]]:
+                    m[2 * O + lane_pos[l]] += 1.0
+        for j, mgr in enumerate(cfg['management']):
+            W[:, S + j] = mg[mgr]
+            for n in cfg['management_neighbors'][mgr]:
+                W[:, S + j] += alpha * mg[n]
+        self._fma2c = dict(cfg=cfg, keys=keys, states=st, W=torch.as_tensor(W, device=dev))
+        return self._fma2c
+
+    def fma2c_states(self):
+        """dict key -> f32 [N, dim] for every signal and manager (states.fma2c)"""
+        import torch
+        t = self._fma2c_tables()
+        cfg, agg = t['cfg'], self.tensor('lane_agg')
+        F = torch.cat((torch.clamp((agg[..., 0] + agg[..., 1]) / cfg['norm_wave'], 0, cfg['clip_wave']),
+                       torch.clamp(agg[..., 3] / cfg['norm_wait'], 0, cfg['clip_wait'])), dim=1)
+        return {k: F[:, idx] * scale for k, (idx, scale) in t['states'].items()}
+
+    def fma2c_rewards(self):
+        """dict key -> f32 [N] for every signal and manager (rewards.fma2c)"""
+        import torch
+        t = self._fma2c_tables()
+        agg = self.tensor('lane_agg')
+        G = torch.cat((agg[..., 0], agg[..., 3], self.tensor('lane_arrivals').float(), self.tensor('arrivals').float(),
+                       self.tensor('departures').float()), dim=1)
+        R = G @ t['W']
+        return {k: R[:, j] for j, k in enumerate(t['keys'])}
+
     def _pack(self):
-        return ({n: (self.derived(n) if n in self.DERIVED else self.tensor(n)) for n in self.state_names},
-                {n: self.tensor(n) for n in self.reward_names})
+        obs = {}
+        for n in self.state_names:
+            obs[n] = self.fma2c_states() if n == 'fma2c' else (self.derived(n) if n in self.DERIVED else self.tensor(n))
+        rew = {n: (self.fma2c_rewards() if n == 'fma2c' else self.tensor(n)) for n in self.reward_names}
+        return obs, rew
 
     def _stream(self, stream):
         # the tensors handed out are consumed by torch kernels: launch on torch's current stream unless told otherwise

@@ -213,6 +213,8 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     set_buf(h, RS_BUF_VEH_COOP, G.coop(0), RS_U32, 2, n, cc); set_buf(h, RS_BUF_VEH_COOPLEAD, G.cooplead(0), RS_U32, 2, n, cc);
     set_buf(h, RS_BUF_ARRIVALS, O.arrivals(), RS_I32, 2, n, s); set_buf(h, RS_BUF_DEPARTURES, O.departures(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_MPLIGHT_FULL, O.mplight_full(), RS_F32, 3, n, s, 49);
+    set_buf(h, RS_BUF_LANE_ARRIVALS, O.lane_arr(), RS_I32, 2, n, sc->n_obs);
+    set_buf(h, RS_BUF_VEH_COOP_ODD, G.coop(1), RS_U32, 2, n, cc); set_buf(h, RS_BUF_VEH_COOPLEAD_ODD, G.cooplead(1), RS_U32, 2, n, cc);
     *out = h;
     return rs_reset(h, nullptr);
 }

@@ -949,8 +949,10 @@ def test_arrival_departure_counters_and_mplight_full_batched():
             o.step(a[e])
         if k % 15 == 14:
             arr, dep, mf = sim.read('arrivals'), sim.read('departures'), sim.read('mplight_full')
+            la = sim.read('lane_arrivals')
             for e, o in orcs.items():
                 ref = o.outputs()
+                np.testing.assert_array_equal(la[e], ref['lane_arrivals'])
                 np.testing.assert_array_equal(arr[e], ref['arrivals'])
                 np.testing.assert_array_equal(dep[e], ref['departures'])
                 np.testing.assert_array_equal(mf[e], ref['mplight_full'])
@@ -985,5 +987,41 @@ def test_batched_drq_state_equals_the_signal_views():
         np.testing.assert_allclose(got[o:o + len(rows)], rows, rtol=0, atol=1e-4)       # (speed sums: 16.16 fixed point on the device)
         o += len(rows)
     assert o == got.shape[0] and got[:, 1:].sum() > 0
+    vec.close()
+    env.close()
+
+
+@pytest.mark.parametrize('map_name', ['cologne3', 'ingolstadt7'])
+def test_batched_fma2c_equals_the_signal_views(map_name):
+    """VecMultiSignal's FMA2C observations and rewards for all environments (gathers / one matrix product over the device
+    buffers, incl. RS_BUF_LANE_ARRIVALS) equal states.fma2c / rewards.fma2c evaluated through the Signal views of a
+    single-environment MultiSignal with the same seed and actions (reference states.py:162-229, rewards.py:72-136)"""
+    import torch
+    from resco_amd import rewards, states
+    from resco_amd.config.map_config import map_configs
+    from resco_amd.config.mdp_config import activate
+    from resco_amd.multi_signal import MultiSignal, VecMultiSignal
+    activate('FMA2C', map_name)
+    mc = map_configs[map_name]
+    vec = VecMultiSignal(map_name, 3, states=('fma2c',), rewards=('fma2c',), seed=(8 + 0x9E3779B1) & 0xFFFFFFFF)
+    env = MultiSignal('t', map_name, None, states.fma2c, rewards.fma2c, yellow_length=3, end_time=mc['end_time'],
+                      lights=mc['lights'], log_dir=tempfile.mkdtemp() + os.sep, seed=8)
+    vec.reset()
+    env.reset()
+    sc = vec.scenario
+    rng = np.random.default_rng(3)
+    seen_arrivals = 0.0
+    for k in range(40):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        obs, rew, _, _ = vec.step(torch.as_tensor(np.repeat(a[None, :], 3, axis=0), device='cuda'))
+        ro, rr, _, _ = env.step({sid: int(a[i]) for i, sid in enumerate(env.all_ts_ids)})
+        if k % 5 == 4:
+            vec.sync()
+            assert list(obs['fma2c'].keys()) == list(ro.keys()) and list(rew['fma2c'].keys()) == list(rr.keys())
+            for key in ro:
+                np.testing.assert_allclose(obs['fma2c'][key][0].cpu().numpy(), np.asarray(ro[key], np.float64), rtol=0, atol=1e-5, err_msg=key)
+                np.testing.assert_allclose(float(rew['fma2c'][key][0]), float(rr[key]), rtol=0, atol=1e-3, err_msg=key)
+            seen_arrivals += float(vec.tensor('lane_arrivals').sum())
+    assert seen_arrivals > 0
     vec.close()
     env.close()

@@ -11,7 +11,7 @@ from oracle.pyoracle import OracleEnv
 from hostemu.emu import EmuSim
 
 OUT = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_norm', 'pressure', 'queue_sum', 'queue_max',
-       'arrivals', 'departures', 'mplight_full']
+       'arrivals', 'departures', 'mplight_full', 'lane_arrivals']
 VEH = [('veh_lane', 'lane'), ('veh_pos', 'pos'), ('veh_speed', 'speed'), ('veh_cursor', 'cursor'), ('veh_swait', 'sumo_wait'),
        ('veh_tloss', 'time_loss'), ('veh_rwait', 'resco_wait'), ('veh_owner', 'owner'), ('veh_depart', 'depart'), ('veh_accel', 'accel')]
 
