@@ -2,15 +2,19 @@
 // microsimulation + Signal.observe + states / rewards, as a sequence of PHASES over the vehicle slots of the environment.
 //
 // The body is written against a small execution interface (`Exec`):
-//   ex.phase(id, f)   runs f(tid) for every thread of the workgroup and ends with a workgroup barrier (id: 0..15,
-//                     names the phase for the optional per-phase timers: L0 L1 L2 L3 P C M D A1 RB A2 O0 O1 O2 O3)
-// On the GPU (resco_sim.hip) one workgroup = one environment, a thread owns the slots tid, tid + B, ...; the state lives
-// in LDS for the whole env-step and phase() is `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same
-// source for the host (tests/hostemu), where phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never
-// reads what another thread writes in the same phase, except through the order-independent atomics below).
+//   ex.phase(id, f)         runs f(tid) for every thread of the workgroup and ends with a workgroup barrier (id: 0..15 names
+//                           the phase for the optional per-phase timers: 0-2 load, 4 plan, 5 check, 6 move, 11-14 observe)
+//   ex.role_begin/role_end  optional timers of what one WAVE does inside a phase (ids 3, 7-10, 15)
+//   ex.B                    threads per workgroup (a multiple of 64)
+// On the GPU (resco_sim.hip) one workgroup = one environment; the state lives in LDS for the whole env-step and phase() is
+// `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same source for the host (tests/hostemu), where
+// phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never reads what another thread writes in the same
+// phase, except through the order-independent atomics below).
 //
-// Including file provides: RS_DEV / RS_HD / RS_CARVE (function qualifiers; RS_CARVE must force inlining on the device), the atomics rs_atomic_min/max/add/or/and/cas on 32-bit words of
-// the working memory, RS_SMEM (its base, see LPtr), rs_f2h (float -> half bits), and <math.h> sqrtf/floorf.
+// Including file provides: RS_DEV / RS_HD / RS_MEM / RS_CARVE (function qualifiers), RS_G (marks a pointer as global
+// memory), RS_SMEM (base of the working memory, see LPtr), the atomics rs_atomic_min / max / add / or / and / cas /
+// fetch_add / fetch_or on 32-bit words, the wave-level helpers rs_wave_add / rs_wave_max / rs_wave_ticket, the bit helpers
+// rs_popc / rs_ffs / rs_ffsll / rs_clzll, rs_f2h (float -> half bits), rs_int_as_float / rs_float_as_int and <math.h>.
 #pragma once
 #include "resco_tables.h"
 
@@ -426,7 +430,7 @@ RS_DEV void set_phase(const KTab &T, const Lds &L, const KParams &P, int s, int 
     L.left[s] = T.cold.tls_dur[T.cold.tls_dur_off[s] + ph];
     tls_refresh(T, L, P, s, ph);
 }
-// TLS switch events at the beginning of tick `tick` of this launch (P0), preceded by Signal.set_phase when the yellow
+// TLS switch events at the beginning of tick `tick` of this launch, preceded by Signal.set_phase when the yellow
 // ticks are over
 RS_DEV void tls_begin_of_tick(const KTab &T, const Lds &L, const KParams &P, int s, int tick) {
     if (P.do_fsm && !P.fixed_program && tick == T.yellow_length) set_phase(T, L, P, s, L.nextp[s]);
@@ -441,9 +445,6 @@ RS_DEV void tls_begin_of_tick(const KTab &T, const Lds &L, const KParams &P, int
     }
     L.left[s] = left - 1;
 }
-// strategic lane-change need at route step rq on lane index kk of an edge with n lanes, at position x with speed v:
-// 0 when the lane is as good as any, or the need is still far away; else the direction of the nearest best lane.
-// extra = RM_SG_EXTRA_LANES when asking whether a lane is good enough to move INTO for speed gain.  (oracle: strategic_dir_at)
 // the continuation lengths of the lanes of route step rq (route_cont row), loaded once: the first four in registers
 struct ContRow { float c[4]; const float *cn; };
 RS_DEV ContRow cont_row(const KTab &T, int rq) {
@@ -455,6 +456,9 @@ RS_DEV ContRow cont_row(const KTab &T, int rq) {
 RS_DEV float cont_of(const ContRow &R, int j) {
     return j == 0 ? R.c[0] : (j == 1 ? R.c[1] : (j == 2 ? R.c[2] : (j == 3 ? R.c[3] : R.cn[j])));
 }
+// strategic lane-change need on lane index kk of an edge with n lanes (continuation lengths R), at position x with speed v:
+// 0 when the lane is as good as any, or the need is still far away; else the direction of the nearest best lane.
+// extra = RM_SG_EXTRA_LANES when asking whether a lane is good enough to move INTO for speed gain.  (oracle: strategic_dir_at)
 RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int extra, float &rem) {
     float best = 0.0f;
     for (int j = 0; j < n; ++j) { const float c = cont_of(R, j); if (c > best) best = c; }
@@ -469,7 +473,7 @@ RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int 
     if (rem >= la * (float)off) return 0;
     return (dr <= dl) ? -1 : +1;
 }
-// approach registration for the coming tick (P3): a moving vehicle whose next link somebody may have to yield to registers
+// approach registration for the coming tick: a moving vehicle whose next link somebody may have to yield to registers
 // its arrival time there (v, pos, vType, lane length and next link of the vehicle AFTER this tick's move)
 // (the three fields of the link the registration needs are one dword of its record: arr_idx | tls << 16 | tls_pos << 24)
 RS_DEV uint32_t link_reg_word(const KTab &T, int nlk) { return ((const uint32_t *)&T.links()[nlk & 0x7FFF])[2]; }
