@@ -150,15 +150,15 @@ struct __attribute__((aligned(16))) Node {      // everything a NEIGHBOUR wants 
 #define FL_MH1 8        // FL_MH of odd ticks.  Two bits by tick parity: the move phase must not clear the bit it tests (a thread may
                         // look at its own slot after the list's thread has moved the vehicle); the next plan drops the old one
 RS_DEV int fl_mh(int t) { return (t & 1) ? FL_MH1 : FL_MH; }
-// Aux.lct, the lane-change decision of the tick: a change that holds unless the vehicle leaves its lane forward in the same
-// tick (LCT_LEFT / LCT_RIGHT), and / or a swap with the vehicle alongside, which holds in any case
-#define LCT_LEFT 1
-#define LCT_RIGHT 2
-#define LCT_SWAP_LEFT 4
-#define LCT_SWAP_RIGHT 8
+// The upper four bits of Node.fl: the lane-change decision of the tick -- a change that holds unless the vehicle leaves its
+// lane forward in the same tick (LCT_LEFT / LCT_RIGHT), and / or a swap with the vehicle alongside, which holds in any case
+#define LCT_LEFT 16
+#define LCT_RIGHT 32
+#define LCT_SWAP_LEFT 64
+#define LCT_SWAP_RIGHT 128
 struct __attribute__((aligned(8))) Aux {        // what only the owner reads, every tick: one 8-byte read
     uint16_t lane, rq, nlink;
-    uint16_t lct;       // lane-change decision of this tick (LCT_*, 0: stay)
+    uint16_t swait;     // seconds the vehicle has been standing (SUMO's waiting time); HBM holds it between env-steps
 };
 // The layout (a table of offsets, computed once by the host: lds_carve) is read from the constant argument block.
 // An array of the working memory is addressed as (RS_SMEM + offset): the including file defines RS_SMEM as THE shared
@@ -516,10 +516,10 @@ RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool cla
 // mark slot s as one whose move of tick t is a long one and queue it (the plan's thread and the lane-change thread of a
 // vehicle may both do it, at the same time: an atomic OR on the dword that holds Node.fl decides who queues it)
 RS_DEV void list_push(const Lds &L, const LPtr<uint16_t> &list, int counter, int s);
-RS_DEV void flag_mover(const Lds &L, int s, int t) {
+RS_DEV void flag_mover(const Lds &L, int s, int t, int lct = 0) {
     uint32_t *w = (uint32_t *)((Node *)L.node + s) + 3;
     const uint32_t bit = (uint32_t)fl_mh(t) << 8;
-    if (!(rs_atomic_fetch_or(w, bit) & bit)) list_push(L, L.ls_mh, SC_NMH + (t & 1), s);
+    if (!(rs_atomic_fetch_or(w, bit | ((uint32_t)lct << 8)) & bit)) list_push(L, L.ls_mh, SC_NMH + (t & 1), s);
 }
 // queue slot s in a work list (best effort: the flag in Node.fl is what counts, see the phases)
 RS_DEV void list_push(const Lds &L, const LPtr<uint16_t> &list, int counter, int s) {
@@ -700,16 +700,17 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     if (more && (ax.nlink & NLINK_ARR)) kw = link_reg_word(T, ax.nlink);
     const float sfv = G.sf()[eo + s];
     float tl = G.tloss()[eo + s];
-    const int sw = G.swait()[eo + s];
+    const int sw = ax.swait;
+    int swn = sw;
     const float vn = L.vnx[s];
     gold[LR.cell0 + cell_of(me.pos, lane_cells(LR))] = NIL;         // every vehicle of a cell stores the same: the old grid empties
     int rq = ax.rq;
     int link = (int)(ax.nlink & 0x7FFF);
     bool relink = false;
     int side = 0;
-    if (ax.lct) {
-        if ((ax.lct & (LCT_LEFT | LCT_RIGHT)) && !(me.pos + vn > LR.len)) side = (ax.lct & LCT_LEFT) ? +1 : -1;
-        else if (ax.lct & (LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) side = (ax.lct & LCT_SWAP_LEFT) ? +1 : -1;
+    if (me.fl & (LCT_LEFT | LCT_RIGHT | LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) {
+        if ((me.fl & (LCT_LEFT | LCT_RIGHT)) && !(me.pos + vn > LR.len)) side = (me.fl & LCT_LEFT) ? +1 : -1;
+        else if (me.fl & (LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) side = (me.fl & LCT_SWAP_LEFT) ? +1 : -1;
     }
     if (side) {
         lane += side;
@@ -720,10 +721,10 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     const float vref = LR.vmax * sfv;
     if (last_tick) G.accel()[eo + s] = vn - me.speed;
     if (vn <= RM_HALT_SPEED) {
-        if (sw < 65535) G.swait()[eo + s] = (uint16_t)(sw + 1);
+        if (sw < 65535) swn = sw + 1;
         halted += 1;
         if (G.trip_log) { const int wt = G.wtot()[eo + s]; if (wt < 65535) G.wtot()[eo + s] = (uint16_t)(wt + 1); }
-    } else if (sw != 0) G.swait()[eo + s] = 0;
+    } else swn = 0;
     if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss()[eo + s] = tl; }
     float x = me.pos + vn;
     bool arrived = false;
@@ -745,7 +746,7 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
         relink = true;
     }
     if (arrived) {
-        Aux na = ax; na.lane = LANE_NONE; na.lct = 0;
+        Aux na = ax; na.lane = LANE_NONE; na.swait = 0;
         L.aux[s] = na;
         L.node[s].trip = TRIP_NONE; L.node[s].fl = (uint8_t)(me.fl & fl_mh(t));
         G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE;
@@ -768,7 +769,7 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     active += 1;
     if (s + 1 > top) top = s + 1;
     Aux na = ax;
-    na.lane = (uint16_t)lane; na.rq = (uint16_t)rq; na.lct = 0;
+    na.lane = (uint16_t)lane; na.rq = (uint16_t)rq; na.swait = (uint16_t)swn;
     if (relink) na.nlink = cache_link(T, LR, lane, rq, k);
     L.aux[s] = na;
     Node nn = me;
@@ -800,7 +801,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
     // (everything the decision may need from global memory is requested at once)
     const LaneRec LR = T.lanes()[lane];
     const ContRow R = cont_row(T, ax.rq);
-    const int my_wait = (int)G.swait()[eo + s];
+    const int my_wait = (int)ax.swait;
     const int n = LR.flags >> 2;
     if ((LR.flags & LF_INTERNAL) || n < 2) return 0;
     const int dir_allowed = (t & 1) ? -1 : +1;
@@ -880,7 +881,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
         if (b != NIL) {
             const Node nb = L.node[b];
             float rem_b;
-            if (nb.speed <= RM_HALT_SPEED && (int)G.swait()[eo + b] >= RM_SWAP_WAIT &&
+            if (nb.speed <= RM_HALT_SPEED && (int)L.aux[b].swait >= RM_SWAP_WAIT &&
                 strategic_dir(cont_row(T, L.aux[b].rq), kk + sdir, n, nb.pos, nb.speed, 0, rem_b) == -sdir && rem_b <= RM_URGENT_DIST &&
                 overlapping(L, grid, LR.cell0, nc, nb.pos, nb.trip, b, L.vtp[nb.vt * VT_COLS + VT_LENGTH]) == s)
                 code |= sdir > 0 ? LCT_SWAP_LEFT : LCT_SWAP_RIGHT;
@@ -964,13 +965,14 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         for (int s = tid; s < C; s += B) {
             uint16_t ln = LANE_NONE, tr = TRIP_NONE;
             if (s < hw0) { ln = G.lane()[eo + s]; tr = G.trip()[eo + s]; }
-            Aux ax; ax.lane = ln; ax.rq = 0; ax.nlink = NLINK_NONE; ax.lct = 0;
+            Aux ax; ax.lane = ln; ax.rq = 0; ax.nlink = NLINK_NONE; ax.swait = 0;
             if (ln == LANE_NONE) { L.aux[s] = ax; L.node[s].trip = TRIP_NONE; continue; }
             const float sp = G.speed()[eo + s], x = G.pos()[eo + s];
             const int rq = (int)T.routes()[T.trip_route()[tr]].start + (int)G.cursor()[eo + s];
             const LaneRec LR0 = T.lanes()[ln];
             ax.rq = (uint16_t)rq;
             ax.nlink = cache_link(T, LR0, ln, rq, tr);
+            ax.swait = G.swait()[eo + s];
             L.aux[s] = ax;
             Node nn; nn.pos = x; nn.speed = sp; nn.trip = tr; nn.vt = T.trip_vtype()[tr];
             nn.fl = 0; nn.pad[0] = nn.pad[1] = 0;
@@ -1048,7 +1050,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                         const Aux ax = L.aux[s];
                         if (ax.lane == LANE_NONE) continue;
                         const int code = phase_lc_decide(T, L, gold, G, eo, t, s, ax, L.node[s]);
-                        if (code) { L.aux[s].lct = (uint16_t)code; flag_mover(L, s, t); }
+                        if (code) flag_mover(L, s, t, code);
                     } else phase_plan(T, L, gold, G, eo, P, genv, t, s);
                 }
             }
@@ -1110,10 +1112,9 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(nn.pos, lane_cells(LRd)), s, false);
                 if (more) nn.fl = (uint8_t)classify(L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, cont_row(T, (int)RR.start), k, sfn, t + 1);
                 L.node[s] = nn;
-                Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.lct = 0;
+                Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.swait = 0;
                 na.nlink = cache_link(T, LRd, RR.depart_lane, (int)RR.start, k);
                 L.aux[s] = na;
-                G.swait()[eo + s] = 0;
                 G.sf()[eo + s] = sfn; G.tloss()[eo + s] = 0.0f; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE; G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE;
                 G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
                 L.dep[d] = T.cold.trip_next[k];
@@ -1150,7 +1151,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             hi = s + 1;
             // store the slab back (once per env-step)
             const int rq = L.aux[s].rq;
-            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.node[s].speed;
+            G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.node[s].speed; G.swait()[eo + s] = L.aux[s].swait;
             G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes()[T.trip_route()[L.node[s].trip]].start);
             const LaneRec LR = T.lanes()[lane];
             const int oi = T.cold.lane_obs[lane];
@@ -1173,7 +1174,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 if (prev_owner != (int)OWNER_NONE) rs_atomic_add(&L.sig_dep[prev_owner], 1);
             }
             if (rw > 0) { rw += T.step_length; if (rw > 65535) rw = 65535; }
-            else { const int sw = G.swait()[eo + s]; if (sw > 0) rw = sw; }
+            else { const int sw = L.aux[s].swait; if (sw > 0) rw = sw; }
             G.rwait()[eo + s] = (uint16_t)rw;
             G.owner()[eo + s] = (uint8_t)sig;
             if (rw > 0) { rs_atomic_add(&L.agg_q[oi], 1); rs_atomic_add(&L.agg_w[oi], rw); rs_atomic_max(&L.agg_m[oi], rw); }
