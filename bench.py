@@ -49,12 +49,12 @@ def algorithmic_bytes_per_env_step(sc, mean_active):
 
 def designed_bytes_per_env_step(sc, mean_active):
     """what the kernel moves per env-step BY DESIGN: the slab fields it loads / stores once, the
-    HBM-resident private fields it touches every tick (sf, coop, cooplead, tloss, swait), every output buffer"""
+    HBM-resident private fields it touches every tick (the two mailboxes, tloss), every output buffer"""
     S, O = sc.n_signals, sc.n_obs
     lmax = int((sc.sig_obs_start[1:] - sc.sig_obs_start[:-1]).max())
     # slab fields in and out once (pos, speed, lane, trip, cursor, waiting time) + speed factor at the load; every tick:
-    # speed factor (plan and move), both cooperation mailboxes (read), time loss (read + write)
-    per_vehicle = (4 + 4 + 2 + 2 + 2 + 2) * 2 + 4 + 10 * (4 + 4 + 4 + 4 + 4 * 2)
+    # both cooperation mailboxes (read), time loss (read + write)
+    per_vehicle = (4 + 4 + 2 + 2 + 2 + 2) * 2 + 4 + 10 * (4 + 4 + 4 * 2)
     per_signal = 4 + 12 + 12 + 4 * (1 + 13 + 12 + 1 + 1 + 1 + 1 + 1 + 2 + 49)
     return mean_active * per_vehicle + S * per_signal + O * 40 + S * lmax * 10 + 24 + 80
 

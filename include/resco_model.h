@@ -30,5 +30,6 @@
                                      broken up by trading places once both have stood this many seconds ... */
 #define RM_SWAP_EVERY 4           /* ... looked for on every 4th tick only */
 #define RM_BIGF 1.0e30f
+#define RM_SF_QUANT 4096.0f      /* speed factors are multiples of 1 / 4096 (they fit 16 bits next to the vehicle's position) */
 
 #endif

@@ -138,15 +138,17 @@ static inline const float *vt_of(const orc_env *e, int32_t trip) {
 static inline int32_t trip_of_slot(const orc_env *e, int32_t slot) { return e->trip[slot]; }
 static float speed_factor(const orc_env *e, int32_t trip) {
     const float *vt = vt_of(e, trip);
-    if (!e->p.speed_dev) return vt[VT_SF_MEAN];
-    /* Irwin-Hall(4) normal surrogate: basic arithmetic only, identical on CPU and GPU */
-    float s = 0.0f;
-    for (uint32_t i = 0; i < 4; ++i) s += u01(orc_hash(e->p.seed, (uint32_t)e->env_index, (uint32_t)trip, 0xFFFFFFFFu, i));
-    float z = (s - 2.0f) * 1.7320508f;
-    float f = vt[VT_SF_MEAN] + vt[VT_SF_DEV] * z;
+    float f = vt[VT_SF_MEAN];
+    if (e->p.speed_dev) {
+        /* Irwin-Hall(4) normal surrogate: basic arithmetic only, identical on CPU and GPU */
+        float s = 0.0f;
+        for (uint32_t i = 0; i < 4; ++i) s += u01(orc_hash(e->p.seed, (uint32_t)e->env_index, (uint32_t)trip, 0xFFFFFFFFu, i));
+        float z = (s - 2.0f) * 1.7320508f;
+        f = vt[VT_SF_MEAN] + vt[VT_SF_DEV] * z;
+    }
     if (f < 0.2f) f = 0.2f;
     if (f > 2.0f) f = 2.0f;
-    return f;
+    return (float)(int32_t)(f * RM_SF_QUANT + 0.5f) * (1.0f / RM_SF_QUANT);       /* a multiple of 1 / 4096 */
 }
 static inline int ahead_of(float pj, int32_t kj, float pi, int32_t ki) { /* j strictly ahead of i */
     return pj > pi || (pj == pi && kj < ki);

@@ -119,17 +119,21 @@ RS_DEV float d_follow_speed(float gap, float vl, float b, float bl, float tau) {
     const float bm = b > bl ? b : bl;
     return d_stop_speed(gap + d_brake_gap(vl, bm), b, tau);
 }
-RS_DEV float speed_factor(const KParams &P, int env, int trip, const float *vt) {
-    if (!P.speed_dev) return vt[VT_SF_MEAN];
-    float s = 0.0f;
+// speedFactor of a trip in units of 1 / RM_SF_QUANT (oracle: speed_factor): carried in 16 bits of the vehicle's Node
+RS_DEV int speed_factor_q(const KParams &P, int env, int trip, const float *vt) {
+    float f = vt[VT_SF_MEAN];
+    if (P.speed_dev) {
+        float s = 0.0f;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) s += d_u01(d_hash(P.seed, (uint32_t)env, (uint32_t)trip, 0xFFFFFFFFu, i));
-    const float z = (s - 2.0f) * 1.7320508f;
-    float f = vt[VT_SF_MEAN] + vt[VT_SF_DEV] * z;
+        for (uint32_t i = 0; i < 4; ++i) s += d_u01(d_hash(P.seed, (uint32_t)env, (uint32_t)trip, 0xFFFFFFFFu, i));
+        const float z = (s - 2.0f) * 1.7320508f;
+        f = vt[VT_SF_MEAN] + vt[VT_SF_DEV] * z;
+    }
     if (f < 0.2f) f = 0.2f;
     if (f > 2.0f) f = 2.0f;
-    return f;
+    return (int)(f * RM_SF_QUANT + 0.5f);
 }
+RS_DEV float sf_of(int q) { return (float)q * (1.0f / RM_SF_QUANT); }
 
 // ------------------------------------------------------------------------------------------------ working memory (LDS)
 struct __attribute__((aligned(16))) Node {      // everything a NEIGHBOUR wants to know about a vehicle: one 16-byte read
@@ -138,8 +142,8 @@ struct __attribute__((aligned(16))) Node {      // everything a NEIGHBOUR wants 
     uint16_t trip;      // TRIP_NONE: free slot
     uint16_t nxt;       // next vehicle of the same grid cell (unordered), NIL terminated
     uint8_t vt;         // vType
-    uint8_t fl;         // scheduling hints, see FL_* (they decide WHICH thread handles the vehicle, never what is computed)
-    uint8_t pad[2];
+    uint8_t fl;         // scheduling hints and the tick's lane-change decision, see FL_* / LCT_*
+    uint16_t sfq;       // speedFactor in units of 1 / RM_SF_QUANT
 };
 // A wave executes every branch that ANY of its 64 lanes takes, so the rare, long code paths (junction look-ahead, lane-change
 // searches, hand-over / arrival) are not left scattered over all waves: the vehicles that need them are queued in short
@@ -571,7 +575,7 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const 
     const float *vt = L.vtp + me.vt * VT_COLS;
     const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
     const float v = me.speed, x = me.pos;
-    const float sf = G.sf()[eo + s];
+    const float sf = sf_of(me.sfq);
     const uint32_t c2 = G.cooplead((t + 1) & 1)[eo + s];
     const LaneRec LR0 = T.lanes()[lane];
     LaneRec LR = LR0;
@@ -698,7 +702,7 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     ContRow R = cont_row(T, ax.rq);
     uint32_t kw = 0;
     if (more && (ax.nlink & NLINK_ARR)) kw = link_reg_word(T, ax.nlink);
-    const float sfv = G.sf()[eo + s];
+    const float sfv = sf_of(me.sfq);
     float tl = G.tloss()[eo + s];
     const int sw = ax.swait;
     int swn = sw;
@@ -975,9 +979,9 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             ax.swait = G.swait()[eo + s];
             L.aux[s] = ax;
             Node nn; nn.pos = x; nn.speed = sp; nn.trip = tr; nn.vt = T.trip_vtype()[tr];
-            nn.fl = 0; nn.pad[0] = nn.pad[1] = 0;
+            nn.fl = 0; nn.sfq = (uint16_t)(int)(G.sf()[eo + s] * RM_SF_QUANT + 0.5f);
             nn.nxt = grid_push(grid0, LR0.cell0 + cell_of(x, lane_cells(LR0)), s, sp > RM_HALT_SPEED);
-            if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, G.sf()[eo + s], L.sc[SC_T]);
+            if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, sf_of(nn.sfq), L.sc[SC_T]);
             L.node[s] = nn;
             rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
         }
@@ -1106,9 +1110,10 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 const float *vt = L.vtp + v * VT_COLS;
                 const RouteRec RR = T.routes()[T.trip_route()[k]];
                 const LaneRec LRd = T.lanes()[RR.depart_lane];
-                const float sfn = speed_factor(P, genv, k, vt);
+                const int sfq = speed_factor_q(P, genv, k, vt);
+                const float sfn = sf_of(sfq);
                 Node nn; nn.pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
-                nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.pad[0] = nn.pad[1] = 0;
+                nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.sfq = (uint16_t)sfq;
                 nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(nn.pos, lane_cells(LRd)), s, false);
                 if (more) nn.fl = (uint8_t)classify(L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, cont_row(T, (int)RR.start), k, sfn, t + 1);
                 L.node[s] = nn;

@@ -110,14 +110,15 @@ def speed_factor(seed, env, trip, vt_row, speed_dev=1):
     """speedFactor of a trip (resco_step.h: speed_factor): a function of (seed, global env index, trip) only, so it can be
     recomputed for trips that have left the network (tripinfo output)"""
     mean, dev = np.float32(vt_row[7]), np.float32(vt_row[8])
-    if not speed_dev:
-        return float(mean)
-    s = np.float32(0.0)
-    for i in range(4):
-        s = np.float32(s + np.float32(_murmur(seed, (env, trip, 0xFFFFFFFF, i)) >> 8) * np.float32(1.0 / 16777216.0))
-    z = np.float32((s - np.float32(2.0)) * np.float32(1.7320508))
-    f = np.float32(mean + np.float32(dev * z))
-    return float(min(max(f, np.float32(0.2)), np.float32(2.0)))
+    f = mean
+    if speed_dev:
+        s = np.float32(0.0)
+        for i in range(4):
+            s = np.float32(s + np.float32(_murmur(seed, (env, trip, 0xFFFFFFFF, i)) >> 8) * np.float32(1.0 / 16777216.0))
+        z = np.float32((s - np.float32(2.0)) * np.float32(1.7320508))
+        f = np.float32(mean + np.float32(dev * z))
+    f = min(max(np.float32(f), np.float32(0.2)), np.float32(2.0))
+    return float(np.float32(int(np.float32(f * np.float32(4096.0)) + np.float32(0.5))) * np.float32(1.0 / 4096.0))     # RM_SF_QUANT
 
 
 def torch_stream(device=None):
