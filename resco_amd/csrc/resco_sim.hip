@@ -85,9 +85,18 @@ struct DevExec {
     unsigned long long *prof;       // optional per-phase timers (rs_phase_profile)
     unsigned long long t0;
     template <class F> __device__ __forceinline__ void phase(int id, F f) {
-        f((int)threadIdx.x);
+        // the thread index is made opaque per phase: otherwise every address derived from it (the small strided loops of the
+        // tick's phases) is computed once before the tick loop and kept alive across it -- 18 VGPRs spilled to scratch, written
+        // once per thread and launch: two thirds of the kernel's HBM write traffic
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        f(tid);
         __syncthreads();
-        if (prof && threadIdx.x == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(&prof[id], t1 - t0); t0 = t1; }
+        if (prof) {         // (t0 stays wave-uniform: every thread takes the time, thread 0 adds it up)
+            const unsigned long long t1 = wall_clock64();
+            if (threadIdx.x == 0) atomicAdd(&prof[id], t1 - t0);
+            t0 = t1;
+        }
     }
     // time a wave spends in one role of a phase: sum of the 100 MHz ticks in the low 40 bits, number of waves above
     __device__ __forceinline__ unsigned long long role_begin() const { return prof ? wall_clock64() : 0ull; }
