@@ -84,6 +84,36 @@ def test_gpu_equals_oracle_bit_exact(name, n_envs, steps, sigma, speed_dev, fixe
     sim.close()
 
 
+@pytest.mark.parametrize('name,block,steps', [
+    ('ingolstadt7', 64, 120),           # one wave for 256 slots: no wave roles, every thread handles its slots in full
+    ('ingolstadt7', 256, 120),          # one thread per slot
+    ('ingolstadt7', -128, 120),         # 128-VGPR build
+    ('ingolstadt21', 1024, 150),        # 64-VGPR build, 16 waves
+    ('ingolstadt21', -10768, 150),      # 80-VGPR build, 12 waves
+    ('ingolstadt21', -10256, 150),      # 4 waves for ~300 vehicles: the lists take most of them
+])
+def test_block_sizes_and_register_budgets_bit_exact(name, block, steps):
+    """the wave-role scheduling of the step kernel (lists on their own waves, slots shared by the rest) gives the oracle's
+    results for every workgroup shape and register budget, not only the default one"""
+    from oracle.pyoracle import OracleEnv
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario(name)
+    n = 2
+    sim = BatchedSim(sc, n, seed=21, block_threads=block, env_base=5)
+    orcs = [OracleEnv(sc, env_index=5 + e, seed=21, sigma=-1.0, speed_dev=1) for e in range(n)]
+    for o in orcs:
+        o.observe()
+    rng = np.random.default_rng(6)
+    for step in range(steps):
+        acts = np.stack([rng.integers(0, sc.tls_ngreen) for _ in range(n)]).astype(np.int32)
+        sim.step(acts)
+        for e, o in enumerate(orcs):
+            o.step(acts[e])
+        if step % 30 == 29:
+            assert_env_equal(sim, orcs, step)
+    sim.close()
+
+
 def test_full_episode_bit_exact_ingolstadt21():
     """a whole 360-step episode (3600 ticks, ~4000 trips, congestion, slot reuse) stays bit-identical to the oracle"""
     from oracle.pyoracle import OracleEnv
