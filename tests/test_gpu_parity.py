@@ -800,9 +800,11 @@ REF_DELAY = {
 }
 BAND = 0.35
 # Known exceptions, with the evidence (DESIGN.md section 2 has the traces):
-#  * ingolstadt21 FIXED: two approaches of TLS 243641585 are over-saturated under the net's own programme (486 veh/h on one
-#    lane with 20 s of green per 86 s, 515 + part of 310 veh/h with 26 s); the queues spill back through the neighbouring
-#    junctions further than SUMO's do.  Measured ~2.0-2.5 x the published median; the test keeps it below 3 x.
+#  * ingolstadt21 FIXED: 486 of the 539 trips per hour on -201201945#0.78 turn left at TLS 243641585 on ONE lane and meet
+#    the next signal (gneJ257: red for 40 s of 90 s) 12 m later; the two programmes have different cycle lengths (86 / 90
+#    s), so much of the 20 s of green is lost to a full 12 m edge: 208 vehicles per hour get through, the queue spills
+#    back along the -201201945 corridor (exception 1).  Measured ~2.0-2.5 x the published median;
+#    the test keeps it below 3 x.
 #  * ingolstadt21 MAXWAVE / MAXPRESSURE: the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2} maps the pressure of
 #    the S approach (movements S-S + S-E, 841 veh/h) to green phase 0 = 'rGgG', in which that approach is red (phase
 #    order = the tlLogic's file order, exactly as multi_signal.py:52-59 extracts it): the greedy policies starve it for
