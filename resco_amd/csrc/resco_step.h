@@ -181,7 +181,7 @@ struct Lds {
                                 // parity and builds the other one while it moves the vehicles
     uint32_t gstride;           // cells per grid (padded)
     LPtr<int32_t> arr;          // link approach registers
-    LPtr<uint16_t> dep;         // head trip of every departure lane's backlog
+    LPtr<uint16_t> dep, dep_t;  // head trip of every departure lane's backlog, and its departure second (0xFFFF: none)
     LPtr<uint32_t> alive, alive0, insm;     // bit per slot: occupied (now / at the beginning of the tick); bit per departure lane: inserts this tick
     LPtr<int32_t> agg_q, agg_a, agg_w, agg_m, agg_n;
     LPtr<uint32_t> agg_s;
@@ -231,7 +231,7 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
     CARVE(tstate, (size_t)S * tls_maxl)
     if (L) L->gstride = (uint32_t)((n_cells + 8 + 7) & ~7);
     CARVE(grid, (size_t)((n_cells + 8 + 7) & ~7) * 2 * 2)
-    CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2)
+    CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2) CARVE(dep_t, (size_t)n_dep * 2)
     {
 #ifdef RS_LIST_CAP                  // (tests: lists so short that they overflow all the time)
         const int cap = RS_LIST_CAP;
@@ -897,8 +897,8 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
 // C: does the oldest waiting trip of departure lane d get onto the network in tick t?  The space on its lane is judged
 // AFTER this tick's move of the vehicles that are on it now -- their next speeds are known (oracle: insertion_check)
 RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, const uint16_t *grid, int t, int d) {
+    if ((int)L.dep_t[d] > t) return false;           // nothing due on this lane (the common case: no global access)
     const int k = L.dep[d];
-    if (k == (int)TRIP_NONE || T.cold.trip_depart[k] > t) return false;
     const int dl = T.cold.dep_lane[d];
     const LaneRec LR = T.lanes()[dl];
     const float *vt = L.vtp + T.trip_vtype()[k] * VT_COLS;
@@ -952,7 +952,11 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
         for (int i = tid; i < (C + 31) / 32; i += B) L.alive[i] = 0u;
         for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
-        for (int i = tid; i < T.n_dep; i += B) L.dep[i] = G.dep_next[(size_t)env * T.n_dep + i];
+        for (int i = tid; i < T.n_dep; i += B) {
+            const int k = G.dep_next[(size_t)env * T.n_dep + i];
+            L.dep[i] = (uint16_t)k;
+            L.dep_t[i] = k == (int)TRIP_NONE ? (uint16_t)0xFFFF : (uint16_t)T.cold.trip_depart[k];
+        }
         for (int i = tid; i < S; i += B) { L.sig_arr[i] = 0; L.sig_dep[i] = 0; }
         for (int i = tid; i < S; i += B) {
             const int ph = G.tls[(env * S + i) * 3 + 0];
@@ -1122,7 +1126,11 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 L.aux[s] = na;
                 G.sf()[eo + s] = sfn; G.tloss()[eo + s] = 0.0f; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE; G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE;
                 G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
-                L.dep[d] = T.cold.trip_next[k];
+                {
+                    const int k2 = T.cold.trip_next[k];
+                    L.dep[d] = (uint16_t)k2;
+                    L.dep_t[d] = k2 == (int)TRIP_NONE ? (uint16_t)0xFFFF : (uint16_t)T.cold.trip_depart[k2];
+                }
                 rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
                 rs_atomic_add(&L.sc[SC_NACT], 1);
                 rs_atomic_add(&L.sc[SC_NINS], 1);
