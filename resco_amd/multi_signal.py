@@ -347,7 +347,7 @@ class VecMultiSignal:
         self._tensors = {}
 
     # registry names that are not a device buffer of their own but a cheap arrangement of buffers (torch ops on the stream)
-    DERIVED = ('drq', 'fma2c')
+    DERIVED = ('drq', 'fma2c', 'fma2c_full')
 
     def tensor(self, name):
         t = self._tensors.get(name)
@@ -368,12 +368,15 @@ class VecMultiSignal:
     # ---- FMA2C (states.py:162-229, rewards.py:72-136) for all environments: every worker / manager observation is a gather
     # of normalised per-lane waves and waits, every reward a linear form of per-lane queues, waits, arrivals and the
     # per-signal arrival / departure counters -- index tables built once from mdp_configs['FMA2C'] (activate() it first)
-    def _fma2c_tables(self):
+    def _fma2c_tables(self, full=False):
         import torch
-        if getattr(self, '_fma2c', None) is not None:
-            return self._fma2c
+        cache = getattr(self, '_fma2c', None)
+        if cache is None:
+            cache = self._fma2c = {}
+        if full in cache:
+            return cache[full]
         from .config.mdp_config import mdp_configs
-        cfg, sc = mdp_configs['FMA2C'], self.scenario
+        cfg, sc = mdp_configs['FMA2CFull' if full else 'FMA2C'], self.scenario
         sup, alpha = cfg['supervisors'], float(cfg['alpha'])
         ids = self.all_ts_ids
         O, S = sc.n_obs, self.n_signals
@@ -392,13 +395,22 @@ class VecMultiSignal:
         # states: feature vector F = [clip(wave / norm_wave), clip(max_wait / norm_wait)] per observed lane
         s_idx, s_scale = {}, {}
         mgr_terms = {mgr: ([lane_pos[l] for l in fl], [1.0] * len(fl)) for mgr, fl in fringes.items()}
+        # feature blocks of F: wave (0), [full: total_wait / 28 (1), speed term (2)], max_wait (last)
+        nb_blocks = 3 if full else 1
+
+        def own_idx(sid_):      # fma2c_full interleaves wave, total_wait / 28 and the drq_norm speed term per lane (states.py:232-305)
+            out_ = []
+            for l in lanes[sid_]:
+                out_ += [b * O + lane_pos[l] for b in range(nb_blocks)]
+            return out_
         for sid in ids:
-            idx = [lane_pos[l] for l in lanes[sid]]
+            idx = own_idx(sid)
             sc_ = [1.0] * len(idx)
             for nb in same_region[sid]:
-                idx += [lane_pos[l] for l in lanes[nb]]
-                sc_ += [alpha] * len(lanes[nb])
-            idx += [O + lane_pos[l] for l in lanes[sid]]
+                ni = own_idx(nb)
+                idx += ni
+                sc_ += [alpha] * len(ni)
+            idx += [nb_blocks * O + lane_pos[l] for l in lanes[sid]]
             sc_ += [1.0] * len(lanes[sid])
             s_idx[sid], s_scale[sid] = idx, sc_
         for mgr in cfg['management']:
@@ -434,22 +446,27 @@ class VecMultiSignal:
             W[:, S + j] = mg[mgr]
             for n in cfg['management_neighbors'][mgr]:
                 W[:, S + j] += alpha * mg[n]
-        self._fma2c = dict(cfg=cfg, keys=keys, states=st, W=torch.as_tensor(W, device=dev))
-        return self._fma2c
+        cache[full] = dict(cfg=cfg, keys=keys, states=st, W=torch.as_tensor(W, device=dev), full=full)
+        return cache[full]
 
-    def fma2c_states(self):
-        """dict key -> f32 [N, dim] for every signal and manager (states.fma2c)"""
+    def fma2c_states(self, full=False):
+        """dict key -> f32 [N, dim] for every signal and manager (states.fma2c / states.fma2c_full)"""
         import torch
-        t = self._fma2c_tables()
+        t = self._fma2c_tables(full)
         cfg, agg = t['cfg'], self.tensor('lane_agg')
-        F = torch.cat((torch.clamp((agg[..., 0] + agg[..., 1]) / cfg['norm_wave'], 0, cfg['clip_wave']),
-                       torch.clamp(agg[..., 3] / cfg['norm_wait'], 0, cfg['clip_wait'])), dim=1)
+        nw, cw = cfg['norm_wave'], cfg['clip_wave']
+        blocks = [torch.clamp((agg[..., 0] + agg[..., 1]) / nw, 0, cw)]
+        if full:
+            blocks += [torch.clamp(agg[..., 2] / 28 / nw, 0, cw), torch.clamp(agg[..., 4] / 20 / 28 / nw, 0, cw)]
+        blocks.append(torch.clamp(agg[..., 3] / cfg['norm_wait'], 0, cfg['clip_wait']))
+        F = torch.cat(blocks, dim=1)
+        # (the managers' observations use the wave block only, in both variants)
         return {k: F[:, idx] * scale for k, (idx, scale) in t['states'].items()}
 
-    def fma2c_rewards(self):
-        """dict key -> f32 [N] for every signal and manager (rewards.fma2c)"""
+    def fma2c_rewards(self, full=False):
+        """dict key -> f32 [N] for every signal and manager (rewards.fma2c / rewards.fma2c_full)"""
         import torch
-        t = self._fma2c_tables()
+        t = self._fma2c_tables(full)
         agg = self.tensor('lane_agg')
         G = torch.cat((agg[..., 0], agg[..., 3], self.tensor('lane_arrivals').float(), self.tensor('arrivals').float(),
                        self.tensor('departures').float()), dim=1)
@@ -459,8 +476,10 @@ class VecMultiSignal:
     def _pack(self):
         obs = {}
         for n in self.state_names:
-            obs[n] = self.fma2c_states() if n == 'fma2c' else (self.derived(n) if n in self.DERIVED else self.tensor(n))
-        rew = {n: (self.fma2c_rewards() if n == 'fma2c' else self.tensor(n)) for n in self.reward_names}
+            obs[n] = self.fma2c_states(n == 'fma2c_full') if n in ('fma2c', 'fma2c_full') else (
+                self.derived(n) if n in self.DERIVED else self.tensor(n))
+        rew = {n: (self.fma2c_rewards(n == 'fma2c_full') if n in ('fma2c', 'fma2c_full') else self.tensor(n))
+               for n in self.reward_names}
         return obs, rew
 
     def _stream(self, stream):

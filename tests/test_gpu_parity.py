@@ -1023,8 +1023,8 @@ def test_batched_drq_state_equals_the_signal_views():
     env.close()
 
 
-@pytest.mark.parametrize('map_name', ['cologne3', 'ingolstadt7'])
-def test_batched_fma2c_equals_the_signal_views(map_name):
+@pytest.mark.parametrize('map_name,full', [('cologne3', False), ('ingolstadt7', False), ('cologne8', True), ('ingolstadt21', True)])
+def test_batched_fma2c_equals_the_signal_views(map_name, full):
     """VecMultiSignal's FMA2C observations and rewards for all environments (gathers / one matrix product over the device
     buffers, incl. RS_BUF_LANE_ARRIVALS) equal states.fma2c / rewards.fma2c evaluated through the Signal views of a
     single-environment MultiSignal with the same seed and actions (reference states.py:162-229, rewards.py:72-136)"""
@@ -1033,10 +1033,11 @@ def test_batched_fma2c_equals_the_signal_views(map_name):
     from resco_amd.config.map_config import map_configs
     from resco_amd.config.mdp_config import activate
     from resco_amd.multi_signal import MultiSignal, VecMultiSignal
-    activate('FMA2C', map_name)
+    name = 'fma2c_full' if full else 'fma2c'
+    activate('FMA2CFull' if full else 'FMA2C', map_name)
     mc = map_configs[map_name]
-    vec = VecMultiSignal(map_name, 3, states=('fma2c',), rewards=('fma2c',), seed=(8 + 0x9E3779B1) & 0xFFFFFFFF)
-    env = MultiSignal('t', map_name, None, states.fma2c, rewards.fma2c, yellow_length=3, end_time=mc['end_time'],
+    vec = VecMultiSignal(map_name, 3, states=(name,), rewards=(name,), seed=(8 + 0x9E3779B1) & 0xFFFFFFFF)
+    env = MultiSignal('t', map_name, None, getattr(states, name), getattr(rewards, name), yellow_length=3, end_time=mc['end_time'],
                       lights=mc['lights'], log_dir=tempfile.mkdtemp() + os.sep, seed=8)
     vec.reset()
     env.reset()
@@ -1049,10 +1050,10 @@ def test_batched_fma2c_equals_the_signal_views(map_name):
         ro, rr, _, _ = env.step({sid: int(a[i]) for i, sid in enumerate(env.all_ts_ids)})
         if k % 5 == 4:
             vec.sync()
-            assert list(obs['fma2c'].keys()) == list(ro.keys()) and list(rew['fma2c'].keys()) == list(rr.keys())
+            assert list(obs[name].keys()) == list(ro.keys()) and list(rew[name].keys()) == list(rr.keys())
             for key in ro:
-                np.testing.assert_allclose(obs['fma2c'][key][0].cpu().numpy(), np.asarray(ro[key], np.float64), rtol=0, atol=1e-5, err_msg=key)
-                np.testing.assert_allclose(float(rew['fma2c'][key][0]), float(rr[key]), rtol=0, atol=1e-3, err_msg=key)
+                np.testing.assert_allclose(obs[name][key][0].cpu().numpy(), np.asarray(ro[key], np.float64), rtol=0, atol=1e-5, err_msg=key)
+                np.testing.assert_allclose(float(rew[name][key][0]), float(rr[key]), rtol=0, atol=1e-3, err_msg=key)
             seen_arrivals += float(vec.tensor('lane_arrivals').sum())
     assert seen_arrivals > 0
     vec.close()
