@@ -44,6 +44,8 @@ struct orc_env {
     int32_t env_index;
     int32_t t;              /* ticks since begin */
     float maxlen;           /* longest vehicle of the scenario */
+    float occ_unit;         /* length + minGap of the scenario's most common vehicle type: what one queued vehicle occupies */
+    int32_t *lane_cnt;      /* per lane: vehicles on it at the beginning of the tick (build_lists) */
     int32_t room_ins;       /* free capacity when this tick's insertions were decided */
     uint8_t *free_before;   /* per slot: free when this tick's insertions were decided */
     int32_t n_inserted;     /* trips inserted so far */
@@ -196,6 +198,9 @@ static int32_t choose_link(const orc_env *e, int32_t lane, int32_t route, int32_
  * speed gain: LC2013 leaves the best lanes only if it can stay away for (lanes + 2) look-aheads] */
 static int32_t strategic_dir_at(const orc_env *e, int32_t route, int32_t cursor, int32_t kk, int32_t n, float x, float v, int extra, float *rem) {
     const orc_scenario *sc = e->sc;
+    /* [SUMO-K LC2013 _wantsChange: usableDist = currentDist - posOnLane - best.occupation * JAM_FACTOR] the vehicles standing
+     * or driving on the lane I have to get to shorten the distance I can still use: a vehicle that needs the neighbouring lane
+     * joins the queue there at its tail instead of driving past it.  Occupation = vehicles on that lane now * occ_unit */
     const float *cn = sc->route_cont + (size_t)(sc->route_start[route] + cursor) * sc->kmax;
     float best = 0.0f;
     for (int32_t j = 0; j < n; ++j) if (cn[j] > best) best = cn[j];
@@ -206,7 +211,8 @@ static int32_t strategic_dir_at(const orc_env *e, int32_t route, int32_t cursor,
     for (int32_t j = kk - 1; j >= 0; --j) if (cn[j] >= best - RM_CONT_EPS) { dr = kk - j; break; }
     int32_t off = (dr <= dl ? dr : dl) + extra;
     float la = (v > RM_LOOK_MIN_SPEED ? v : RM_LOOK_MIN_SPEED) * RM_LOOK_TIME + RM_LOOK_BASE;
-    if (*rem >= la * (float)off) return 0;
+    int32_t bl = sc->edge_lane0[sc->route_edge[sc->route_start[route] + cursor]] + ((dr <= dl) ? kk - dr : kk + dl);
+    if (*rem - (float)e->lane_cnt[bl] * e->occ_unit >= la * (float)off) return 0;
     return (dr <= dl) ? -1 : +1;
 }
 static inline int32_t tls_state(const orc_env *e, int32_t link) {
@@ -223,11 +229,12 @@ static inline int32_t depart_lane(const orc_scenario *sc, int32_t route) {
 }
 static void build_lists(orc_env *e) {
     const orc_scenario *sc = e->sc;
-    for (int32_t l = 0; l < sc->n_lanes; ++l) e->lane_head[l] = NIL;
+    for (int32_t l = 0; l < sc->n_lanes; ++l) { e->lane_head[l] = NIL; e->lane_cnt[l] = 0; }
     for (int32_t s = 0; s < e->hw; ++s) {
         if (e->lane[s] >= LANE_PENDING) continue;
         e->next_in_lane[s] = e->lane_head[e->lane[s]];
         e->lane_head[e->lane[s]] = s;
+        e->lane_cnt[e->lane[s]] += 1;
     }
 }
 /* rear-most vehicle of a lane (min pos, ties -> larger trip index) if its front is within `win` metres of the lane start.
@@ -269,7 +276,7 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     ALLOC(e->vnext, C); ALLOC(e->lc_target, C); ALLOC(e->trip, C); ALLOC(e->dbg_reason, C); ALLOC(e->dbg_block, C); ALLOC(e->wtot, C);
     if (p->trip_log) ALLOC(e->trip_log, (size_t)sc->n_trips * 4);
     ALLOC(e->lane_head, sc->n_lanes); ALLOC(e->next_in_lane, C); ALLOC(e->link_arr, sc->n_links);
-    ALLOC(e->lane_ins, sc->n_lanes);
+    ALLOC(e->lane_ins, sc->n_lanes); ALLOC(e->lane_cnt, sc->n_lanes);
     ALLOC(e->dep_next, sc->n_lanes); ALLOC(e->dep_first, sc->n_lanes); ALLOC(e->trip_next, sc->n_trips); ALLOC(e->coop, C); ALLOC(e->coop_lead, C); ALLOC(e->free_before, C); ALLOC(e->coop_lead_trip, C);
     {   /* the trips of one departure lane form a FIFO in trip (= departure time) order */
         for (int32_t l = 0; l < sc->n_lanes; ++l) e->dep_first[l] = -1;
@@ -285,6 +292,15 @@ orc_env *orc_create(const orc_scenario *sc, const orc_params *p, int32_t env_ind
     ALLOC(e->out_phase, S); ALLOC(e->mplight, S * 13); ALLOC(e->wave, S * 12); ALLOC(e->pressure, S);
     ALLOC(e->queue_sum, S); ALLOC(e->queue_max, S);
     ALLOC(e->sig_arr, S); ALLOC(e->sig_dep, S); ALLOC(e->out_arr, S); ALLOC(e->out_dep, S); ALLOC(e->mplight_full, S * 49); ALLOC(e->lane_arr, sc->n_obs);
+    {   /* the most common vehicle type (ties: the lower index) */
+        int32_t best = 0, bestn = -1;
+        for (int32_t v = 0; v < sc->n_vtypes; ++v) {
+            int32_t c = 0;
+            for (int32_t k = 0; k < sc->n_trips; ++k) if (sc->trip_vtype[k] == v) c += 1;
+            if (c > bestn) { bestn = c; best = v; }
+        }
+        e->occ_unit = sc->vtype_params[best * VT_COLS + VT_LENGTH] + sc->vtype_params[best * VT_COLS + VT_MINGAP];
+    }
     e->maxlen = 0.0f;
     for (int32_t v = 0; v < sc->n_vtypes; ++v) if (sc->vtype_params[v * VT_COLS + VT_LENGTH] > e->maxlen) e->maxlen = sc->vtype_params[v * VT_COLS + VT_LENGTH];
     orc_reset(e);
@@ -294,7 +310,7 @@ void orc_destroy(orc_env *e) {
     if (!e) return;
     free(e->lane); free(e->cursor); free(e->sumo_wait); free(e->resco_wait); free(e->depart); free(e->owner);
     free(e->pos); free(e->speed); free(e->accel); free(e->time_loss); free(e->vnext); free(e->lc_target); free(e->trip); free(e->dbg_reason); free(e->dbg_block); free(e->wtot); free(e->trip_log);
-    free(e->lane_head); free(e->next_in_lane); free(e->link_arr); free(e->lane_ins);
+    free(e->lane_head); free(e->next_in_lane); free(e->link_arr); free(e->lane_ins); free(e->lane_cnt);
     free(e->dep_next); free(e->dep_first); free(e->trip_next); free(e->coop); free(e->coop_lead); free(e->free_before); free(e->coop_lead_trip);
     free(e->phase); free(e->left); free(e->next_phase);
     free(e->lane_agg); free(e->drq_norm); free(e->wait); free(e->wait_norm);

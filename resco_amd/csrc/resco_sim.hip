@@ -310,7 +310,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         h->err = "need 0 <= yellow_length < step_length"; return fail(RS_EINVAL);
     }
     const int C = sc->capacity;
-    if (C < 64 || (C % 64) || C > 16384) { h->err = "capacity must be a multiple of 64 in [64, 16384]"; return fail(RS_ELIMIT); }
+    if (C < 64 || (C % 64) || C > 1984) { h->err = "capacity must be a multiple of 64 in [64, 1984]"; return fail(RS_ELIMIT); }
     if (sc->kmax < 1 || sc->kmax > 16) { h->err = "kmax (lanes per edge) must be in [1, 16]"; return fail(RS_ELIMIT); }
     PackedTables PT;
     if (!PT.build(sc)) { h->err = PT.err; return fail(RS_ELIMIT); }
@@ -344,7 +344,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         UP(cold.pr_out_start, int32_t, sc->pr_out_start, sc->n_signals + 1) UP(cold.pr_out_idx, int32_t, sc->pr_out_idx, sc->n_pr_out)
         UP(cold.trips_cum, int32_t, sc->trips_cum, sc->horizon + 2)
 #undef UP
-        K.maxlen = PT.maxlen;
+        K.maxlen = PT.maxlen; K.occ_unit = PT.occ_unit;
         K.n_trips = sc->n_trips; K.tls_maxl = PT.tls_maxl; K.kmax = sc->kmax;
         K.n_lanes = sc->n_lanes; K.n_cells = PT.n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes;
         K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = PT.lmax;

@@ -256,24 +256,40 @@ RS_DEV int lane_cells(const LaneRec &LR) { return (int)(LR.len * CELL_INV) + 1; 
 RS_DEV int cell_of(float pos, int ncell) { const int c = (int)(pos * CELL_INV); return c < ncell ? c : ncell - 1; }
 
 // push slot s into cell c; returns the previous head (the new chain link).  16-bit cells, exchanged with a CAS on the
-// containing dword (LDS has no 16-bit atomics)
+// containing dword (LDS has no 16-bit atomics); the cell's vehicle count goes up by one
 RS_DEV uint16_t grid_push(uint16_t *grid, int c, int s, bool mover) {
     uint32_t *w = (uint32_t *)grid + (c >> 1);
     const int sh = (c & 1) * 16;
-    const uint32_t flag = mover ? 0x8000u : 0u;
+    const uint32_t flag = mover ? CELL_MOVER : 0u;
     uint32_t old = *w, assumed;
     do {
         assumed = old;
-        const uint32_t keep = (assumed >> sh) & 0x8000u;          // sticky mover flag of the cell
-        old = rs_atomic_cas(w, assumed, (assumed & ~(0xFFFFu << sh)) | (((uint32_t)s | keep | flag) << sh));
+        const uint32_t cell = (assumed >> sh) & 0xFFFFu;
+        const uint32_t keep = cell & CELL_MOVER;                  // sticky mover flag of the cell
+        uint32_t cnt = (cell >> CELL_CNT_SHIFT) & CELL_CNT_MAX;
+        if (cnt < CELL_CNT_MAX) cnt += 1u;
+        old = rs_atomic_cas(w, assumed, (assumed & ~(0xFFFFu << sh)) | (((uint32_t)s | (cnt << CELL_CNT_SHIFT) | keep | flag) << sh));
     } while (old != assumed);
-    return (uint16_t)((old >> sh) & 0x7FFFu);
+    return (uint16_t)((old >> sh) & NIL);
 }
-// occupancy mask of the 4 cells of the aligned quad starting at b: bit 16 j + 15 set iff cell b + j is occupied
+// occupancy mask of the 4 cells of the aligned quad starting at b: bit 16 j + 11 set iff cell b + j is occupied
 RS_DEV unsigned long long quad_occ(const uint16_t *grid, int b) {
     const unsigned long long w = *(const unsigned long long *)(grid + b);
-    const unsigned long long x = (w & 0x7FFF7FFF7FFF7FFFull) ^ 0x7FFF7FFF7FFF7FFFull;       // 15-bit field != 0: occupied
-    return (x + 0x7FFF7FFF7FFF7FFFull) & 0x8000800080008000ull;
+    const unsigned long long x = (w & 0x07FF07FF07FF07FFull) ^ 0x07FF07FF07FF07FFull;       // 11-bit field != 0: occupied
+    return (x + 0x07FF07FF07FF07FFull) & 0x0800080008000800ull;
+}
+// number of vehicles in the cells [c0, c0 + nc) (the lane with these cells): the sum of the cells' counters
+RS_DEV int cells_count(const uint16_t *grid, int c0, int nc) {
+    const int c1 = c0 + nc - 1;
+    int n = 0;
+    for (int b = c0 & ~3; b <= c1; b += 4) {
+        unsigned long long m = (*(const unsigned long long *)(grid + b) >> CELL_CNT_SHIFT) & 0x000F000F000F000Full;
+        const int lo = c0 - b, hi = c1 - b;
+        if (lo > 0) m &= ~0ull << (16 * lo);
+        if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
+        n += (int)((m * 0x0001000100010001ull) >> 48);      // the four 4-bit counters added up in the top 16 bits
+    }
+    return n;
 }
 // first occupied cell of [c0, c1] scanning upwards, -1: none
 RS_DEV int scan_up(const uint16_t *grid, int c0, int c1) {
@@ -314,7 +330,7 @@ RS_DEV bool cells_have_mover(const uint16_t *grid, int c0, int nc) {
 RS_DEV int chain_rearmost(const Lds &L, int head) {
     int best = NIL, bk = 0;
     float bp = 0.0f;
-    for (int s = head & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
+    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         if (best == NIL || nd.pos < bp || (nd.pos == bp && (int)nd.trip > bk)) { best = s; bk = nd.trip; bp = nd.pos; }
         s = nd.nxt;
@@ -325,7 +341,7 @@ RS_DEV int chain_rearmost(const Lds &L, int head) {
 RS_DEV int chain_frontmost(const Lds &L, int head) {
     int best = NIL, bk = 0;
     float bp = 0.0f;
-    for (int s = head & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
+    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         if (best == NIL || ahead_of(nd.pos, nd.trip, bp, bk)) { best = s; bk = nd.trip; bp = nd.pos; }
         s = nd.nxt;
@@ -345,7 +361,7 @@ RS_DEV int leader_within(const Lds &L, const uint16_t *grid, int cell0, int ncel
     const int c = cell_of(pos, ncell);
     int Ld = NIL, Lk = 0;
     float Lp = 0.0f;
-    for (int s = grid[cell0 + c] & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD        // my own cell first
+    for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD        // my own cell first
         const Node nd = L.node[s];
         const int cur = s;
         s = nd.nxt;
@@ -364,7 +380,7 @@ RS_DEV int follower_within(const Lds &L, const uint16_t *grid, int cell0, int nc
     const int c = cell_of(pos, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
-    for (int s = grid[cell0 + c] & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
+    for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         const int cur = s;
         s = nd.nxt;
@@ -385,7 +401,7 @@ RS_DEV int at_or_behind_within(const Lds &L, const uint16_t *grid, int cell0, in
     const int c = cell_of(back, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
-    for (int s = grid[cell0 + c] & 0x7FFF; s != NIL;) { RS_CHAIN_GUARD
+    for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         if (!(nd.pos > back) && (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk))) { Fd = s; Fk = nd.trip; Fp = nd.pos; }
         s = nd.nxt;
@@ -463,7 +479,13 @@ RS_DEV float cont_of(const ContRow &R, int j) {
 // strategic lane-change need on lane index kk of an edge with n lanes (continuation lengths R), at position x with speed v:
 // 0 when the lane is as good as any, or the need is still far away; else the direction of the nearest best lane.
 // extra = RM_SG_EXTRA_LANES when asking whether a lane is good enough to move INTO for speed gain.  (oracle: strategic_dir_at)
-RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int extra, float &rem) {
+// The vehicles on the lane to get to shorten the usable distance by occ_unit metres each [SUMO-K LC2013 best.occupation]:
+// `grid` is the tick's grid and cell0 / nc the cell block of lane kk (the blocks of an edge's lanes are consecutive and
+// equally sized).  OCC_NONE / OCC_FULL instead of a grid: assume that lane empty / full -- the bounds the scheduling hints
+// are computed with while the next tick's grid is still being built.
+#define OCC_NONE ((const uint16_t *)0)
+#define OCC_FULL ((const uint16_t *)1)
+RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int extra, float &rem, const uint16_t *grid, int cell0, int nc, float occ_unit) {
     float best = 0.0f;
     for (int j = 0; j < n; ++j) { const float c = cont_of(R, j); if (c > best) best = c; }
     const float mine = cont_of(R, kk);
@@ -472,10 +494,14 @@ RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int 
     int dl = 1000, dr = 1000;
     for (int j = kk + 1; j < n; ++j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dl = j - kk; break; }
     for (int j = kk - 1; j >= 0; --j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dr = kk - j; break; }
+    const int dir = (dr <= dl) ? -1 : +1;
+    if (grid == OCC_FULL) return dir;
     const int off = (dr <= dl ? dr : dl) + extra;
     const float la = (v > RM_LOOK_MIN_SPEED ? v : RM_LOOK_MIN_SPEED) * RM_LOOK_TIME + RM_LOOK_BASE;
-    if (rem >= la * (float)off) return 0;
-    return (dr <= dl) ? -1 : +1;
+    int cnt = 0;
+    if (grid != OCC_NONE) cnt = cells_count(grid, cell0 + ((dr <= dl) ? -dr : dl) * nc, nc);
+    if (rem - (float)cnt * occ_unit >= la * (float)off) return 0;
+    return dir;
 }
 // approach registration for the coming tick: a moving vehicle whose next link somebody may have to yield to registers
 // its arrival time there (v, pos, vType, lane length and next link of the vehicle AFTER this tick's move)
@@ -544,17 +570,18 @@ RS_DEV float plan_look(const float *vt, float vfree) { return d_brake_gap(vfree,
 RS_DEV bool looks_beyond(const float *vt, float v, float x, float lane_len, float lane_vmax, float sf) {
     return lane_len - x < plan_look(vt, plan_vfree(vt, v, lane_vmax, sf));
 }
-// can the lane-change decision of tick t have an effect for a vehicle in this state?  (a superset: a strategic need, or its
-// turn to look for speed gain on a neighbour lane that is good enough)
+// can the lane-change decision of tick t have an effect for a vehicle in this state?  (a superset, computed before the
+// grid of tick t is complete: it is on a lane that is not a best one -- whether the need has arisen depends on the queue
+// beside it --, or it is its turn to look for speed gain on a neighbour lane that may be good enough)
 RS_DEV bool may_change_lanes(const ContRow &R, const LaneRec &LR, int lane, int k, float x, float v, int t) {
     const int n = LR.flags >> 2;
     if ((LR.flags & LF_INTERNAL) || n < 2) return false;
     const int kk = lane - (int)LR.edge_lane0;
     float rem;
-    if (strategic_dir(R, kk, n, x, v, 0, rem) != 0) return true;
+    if (strategic_dir(R, kk, n, x, v, 0, rem, OCC_FULL, 0, 0, 0.0f) != 0) return true;      // any lane that is not a best one
     if ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) return false;
     const int tk = kk + ((t & 1) ? -1 : +1);
-    return tk >= 0 && tk < n && strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem) == 0;
+    return tk >= 0 && tk < n && strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem, OCC_NONE, 0, 0, 0.0f) == 0;
 }
 // The work of tick t for the vehicle in slot s (state as of the beginning of that tick): its flags, and it is queued
 RS_DEV int classify(const Lds &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, const ContRow &R, int k, float sf, int t) {
@@ -816,7 +843,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
     const int nc = lane_cells(LR);
     int want = 0, dir = dir_allowed;
     float rem;
-    const int sdir = strategic_dir(R, kk, n, x, v, 0, rem);
+    const int sdir = strategic_dir(R, kk, n, x, v, 0, rem, grid, LR.cell0, nc, T.occ_unit);
     if (sdir != 0) { dir = sdir; want = 2; }
     int code = 0;
     const int tk = kk + dir;
@@ -828,7 +855,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
             // speed gain between lanes that are both good: more room ahead on the neighbour.  A vehicle reconsiders only on
             // one pair of ticks (one left, one right chance) out of four
             float rem_t;
-            if (strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem_t) == 0) {
+            if (strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem_t, grid, tcell0, nc, T.occ_unit) == 0) {
                 const int lead_c = leader_within(L, grid, LR.cell0, nc, x, k, s, RM_NB_WINDOW);
                 if (lead_c != NIL) {
                     lead_t = leader_within(L, grid, tcell0, nc, x, k, s, RM_NB_WINDOW);
@@ -886,7 +913,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
             const Node nb = L.node[b];
             float rem_b;
             if (nb.speed <= RM_HALT_SPEED && (int)L.aux[b].swait >= RM_SWAP_WAIT &&
-                strategic_dir(cont_row(T, L.aux[b].rq), kk + sdir, n, nb.pos, nb.speed, 0, rem_b) == -sdir && rem_b <= RM_URGENT_DIST &&
+                strategic_dir(cont_row(T, L.aux[b].rq), kk + sdir, n, nb.pos, nb.speed, 0, rem_b, grid, (int)LR.cell0 + sdir * nc, nc, T.occ_unit) == -sdir && rem_b <= RM_URGENT_DIST &&
                 overlapping(L, grid, LR.cell0, nc, nb.pos, nb.trip, b, L.vtp[nb.vt * VT_COLS + VT_LENGTH]) == s)
                 code |= sdir > 0 ? LCT_SWAP_LEFT : LCT_SWAP_RIGHT;
         }
@@ -907,7 +934,7 @@ RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, const uint16_t *gri
     const int nc = lane_cells(LR);
     const int c1 = LR.cell0 + cell_of(mypos + vt[VT_MINGAP] + T.maxlen, nc);
     for (int c = scan_up(grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(grid, c + 1, c1) : -1))
-        for (int o = grid[c] & 0x7FFF; o != NIL;) { RS_CHAIN_GUARD
+        for (int o = grid[c] & NIL; o != NIL;) { RS_CHAIN_GUARD
             const Node od = L.node[o];
             const float back = (od.pos + L.vnx[o]) - L.vtp[od.vt * VT_COLS + VT_LENGTH];
             if (back - mypos - vt[VT_MINGAP] < 0.0f) return false;
@@ -948,7 +975,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
     ex.phase(0, [&](int tid) {
         if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 4 ? G.env[env * 4 + tid] : 0;
         for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold.vtype_params[i];
-        for (int i = tid; i < (int)L.gstride; i += B) ((uint32_t *)grid0)[i] = 0x7FFF7FFFu;      // both grids: 2 * gstride cells
+        for (int i = tid; i < (int)L.gstride; i += B) ((uint32_t *)grid0)[i] = 0x07FF07FFu;      // both grids: 2 * gstride cells
         for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
         for (int i = tid; i < (C + 31) / 32; i += B) L.alive[i] = 0u;
         for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;

@@ -16,7 +16,12 @@ enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, 
 
 #define LANE_NONE 0xFFFFu
 #define OWNER_NONE 0xFFu
-#define NIL 0x7FFF              /* empty grid cell / end of a cell chain (15-bit slot ids; bit 15 of a cell = it holds a moving vehicle) */
+#define NIL 0x7FF               /* empty grid cell / end of a cell chain (11-bit slot ids) */
+// a grid cell (16 bits): bits 0..10 the head slot of its chain (NIL: empty), bits 11..14 the number of vehicles in it
+// (saturating; a CELL_LEN-metre cell cannot hold 15), bit 15 = it holds a moving vehicle
+#define CELL_CNT_SHIFT 11
+#define CELL_CNT_MAX 15u
+#define CELL_MOVER 0x8000u
 #define ARR_NONE 65535
 #define COOP_NONE 0xFFFFFFFFu
 #define TRIP_NONE 0xFFFFu
@@ -106,6 +111,7 @@ struct KTab {
     const uint8_t *trip_vtype_;
     KCold cold;                     // by value: every table pointer is then loaded from the constant argument block
     float maxlen;
+    float occ_unit;                 // length + minGap of the most common vehicle type (oracle: occ_unit)
     int32_t n_trips, tls_maxl, kmax;
     int32_t n_lanes, n_cells, n_signals, n_obs, n_vtypes, horizon, capacity, step_length, yellow_length, lmax, n_arr, n_dep;
     RS_MEM const LaneRec *lanes() const { return RS_G(lanes_); }
@@ -142,7 +148,7 @@ struct PackedTables {
     std::vector<int16_t> lane_obs16;
     std::vector<int32_t> obs_sig;
     int n_cells = 0, n_arr = 1, n_dep = 1, kmax = 1, lmax = 1, tls_maxl = 1;
-    float maxlen = 0.0f;
+    float maxlen = 0.0f, occ_unit = 0.0f;
     std::string err;
 
     // the link a vehicle on normal lane `ln` takes towards route step q + 1 (oracle/resco_oracle.c choose_link restated
@@ -184,6 +190,14 @@ struct PackedTables {
         }
         for (int v = 0; v < sc->n_vtypes; ++v)
             if (sc->vtype_params[v * VT_COLS + VT_LENGTH] > maxlen) maxlen = sc->vtype_params[v * VT_COLS + VT_LENGTH];
+        {   // what one queued vehicle occupies: the most common vehicle type (ties: the lower index)
+            std::vector<int> cnt((size_t)(sc->n_vtypes > 0 ? sc->n_vtypes : 1), 0);
+            for (int k = 0; k < sc->n_trips; ++k) cnt[sc->trip_vtype[k]] += 1;
+            int best = 0;
+            for (int v = 1; v < sc->n_vtypes; ++v) if (cnt[v] > cnt[best]) best = v;
+            occ_unit = sc->vtype_params[best * VT_COLS + VT_LENGTH] + sc->vtype_params[best * VT_COLS + VT_MINGAP];
+        }
+        if (sc->capacity >= NIL) { err = "capacity exceeds the 11-bit slot ids of the grid cells"; return false; }
         std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
         int n_foe_targets = 0;
         for (int l = 0; l < sc->n_links; ++l)

@@ -174,7 +174,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     c.mv_out_start = keep_i32(h, sc->mv_out_start, sc->n_signals * 12 + 1); c.mv_out_idx = keep_i32(h, sc->mv_out_idx, sc->n_mv_out);
     c.pr_out_start = keep_i32(h, sc->pr_out_start, sc->n_signals + 1); c.pr_out_idx = keep_i32(h, sc->pr_out_idx, sc->n_pr_out);
     c.trips_cum = keep_i32(h, sc->trips_cum, sc->horizon + 2);
-    K.maxlen = PT.maxlen; K.n_trips = sc->n_trips; K.tls_maxl = PT.tls_maxl; K.kmax = sc->kmax;
+    K.maxlen = PT.maxlen; K.occ_unit = PT.occ_unit; K.n_trips = sc->n_trips; K.tls_maxl = PT.tls_maxl; K.kmax = sc->kmax;
     K.n_lanes = sc->n_lanes; K.n_cells = PT.n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes;
     K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = PT.lmax;
     K.n_arr = PT.n_arr; K.n_dep = PT.n_dep;
