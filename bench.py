@@ -4,7 +4,8 @@
 Workload (BASELINE.json config 3, the configuration the headline metric is quoted on): ingolstadt21
 (21 signals, 163 observed lanes, 4 283 trips / 3600 s) x 4096 lock-step environments PER GPU, bench mode
 (Krauss sigma 0.5, per-vehicle speedFactor), on-device seeded random policy (STOCHASTIC analogue), every
-step producing lane aggregates + drq_norm + mplight + wave + wait + wait_norm + pressure.
+step producing the per-lane drq_norm rows + mplight + wait + wait_norm + pressure (config 3's state and reward functions;
+the other derived buffers are switched off with rs_set_outputs).
 One "step" = one MultiSignal.step() of every environment = 10 one-second simulation ticks, fused in ONE
 kernel launch.  The timed window is placed in the BULK of the 360-step episode whatever --steps / --warmup are: an
 untimed fast-forward first rolls the batch to step 180 - K/2 - W (the demand ramps up over the hour, so the first steps
@@ -31,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 EPISODE_STEPS = 360
+OUTPUTS = ('drq_norm', 'mplight')
 
 
 def shard(rank, world, envs_per_gpu):
@@ -55,36 +57,49 @@ def designed_bytes_per_env_step(sc, mean_active):
     # slab fields in and out once (pos, speed, lane, trip, cursor, waiting time) + speed factor at the load; every tick:
     # both cooperation mailboxes (read), time loss (read + write)
     per_vehicle = (4 + 4 + 2 + 2 + 2 + 2) * 2 + 4 + 10 * (4 + 4 + 4 * 2)
-    per_signal = 4 + 12 + 12 + 4 * (1 + 13 + 12 + 1 + 1 + 1 + 1 + 1 + 2 + 49)
-    return mean_active * per_vehicle + S * per_signal + O * 40 + S * lmax * 10 + 24 + 80
+    per_signal = 4 + 16 + 16 + 4 * (1 + 13 + 1 + 1 + 1 + 1 + 1 + 2)          # action, FSM in / out, mplight + the per-signal scalars
+    return mean_active * per_vehicle + S * per_signal + O * 20 + 24 + 80     # + the drq_norm rows
+
+
+KERNEL_SOURCES = ('resco_amd/csrc/resco_step.h', 'resco_amd/csrc/resco_sim.hip', 'resco_amd/csrc/resco_tables.h',
+                  'include/resco_model.h', 'include/resco_sim.h')
+
+
+def kernel_source_hash():
+    """identifies the build a PMC summary was measured on (tools/pmc_passes.sh stores the same hash)"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(args, n_local, world):
-    """HBM bytes per launch from the PMC counters: they are collected in SEPARATE rocprofv3 --pmc passes of this very
-    command (tools/pmc_passes.sh -> profiles/r02_pmc_summary.json), so the figure is reported only when this run's
-    workload and window are the ones those passes measured; otherwise None."""
-    import re
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json')
-    note = ('HBM bytes per launch come from separate rocprofv3 --pmc passes of `bench.py --steps 300 --warmup 60` '
-            '(tools/pmc_passes.sh, profiles/r02_pmc_summary.json); this run has another workload or window')
+    """HBM bytes per launch from the PMC counters.  They are collected in SEPARATE rocprofv3 --pmc passes of this very command
+    (tools/pmc_passes.sh <tag> K W -> profiles/r03_pmc_s<K>_w<W>.json), so a figure is reported only when a committed
+    summary exists for this run's --steps / --warmup on the default workload AND was measured on the kernel sources that are
+    running now (source hash); otherwise None, with the reason."""
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_s%d_w%d.json' % (args.steps, args.warmup))
+    default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0
+    if not default_workload or not os.path.exists(path):
+        return None, ('HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_passes.sh); '
+                      'there is no committed summary for this workload / window (%s)' % os.path.basename(path))
     try:
         with open(path) as f:
             pm = json.load(f)
-        m = re.search(r'--steps (\d+) --warmup (\d+)', pm['command'])
-        same = (m is not None and int(m.group(1)) == args.steps and int(m.group(2)) == args.warmup and world == 1 and
-                args.map == 'ingolstadt21' and n_local == 4096 and ' --map' not in pm['command'] and ' --envs' not in pm['command'])
-        if not same:
-            return None, note
+        if pm.get('source_hash') != kernel_source_hash():
+            return None, ('stale: %s was measured on kernel sources %s, this build is %s -- re-run tools/pmc_passes.sh'
+                          % (os.path.basename(path), pm.get('source_hash'), kernel_source_hash()))
         c = pm['counters']
         fetch_kib, write_kib = c['FETCH_SIZE']['per_launch_avg'], c['WRITE_SIZE']['per_launch_avg']
         # MI355X_MICROARCH.md (HBM / rocprofv3): both counters are in KiB; gfx950's FETCH_SIZE counts half of the bytes
         return (2.0 * fetch_kib + write_kib) * 1024.0, (
-            '(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, averaged over the %d launches of the PMC passes of this same '
-            'command (profiles/r02_pmc_summary.json): %.0f + %.0f MB; the state of 4096 environments (%.0f MB) is written '
-            'through to HBM every tick by the per-vehicle waiting / time-loss counters and the register spills'
-            % (c['FETCH_SIZE']['launches'], 2.0 * fetch_kib * 1024 / 1e6, write_kib * 1024 / 1e6, 51.0 * 1024 * n_local / 1e6))
-    except Exception:
-        return None, note
+            '(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, averaged over the %d launches of the PMC passes of this same command '
+            '(profiles/%s, same kernel sources %s): %.0f + %.0f MB' % (c['FETCH_SIZE']['launches'], os.path.basename(path),
+                                                                      pm['source_hash'], 2.0 * fetch_kib * 1024 / 1e6, write_kib * 1024 / 1e6))
+    except Exception as e:
+        return None, 'PMC summary %s unreadable: %r' % (os.path.basename(path), e)
 
 
 EPISODE_MID = 180
@@ -219,6 +234,9 @@ def main():
     env_base, n_local = shard(rank, world, args.envs)
     sim = BatchedSim(sc, n_local, device=local, seed=args.seed, sigma=-1.0, speed_dev=1, env_base=env_base,
                      block_threads=args.block)
+    # BASELINE config 3 / SURVEY 8(d): "state fns computed every step: lane aggregates -> drq_norm + mplight; rewards wait +
+    # pressure" -- only what those consume is written (the per-signal rewards and metrics always are)
+    sim.set_outputs(OUTPUTS)
 
     def barrier():
         if dist is not None:
@@ -258,6 +276,7 @@ def main():
                    'map': args.map, 'envs_per_gpu': n_local, 'ticks_per_env_step': 10,
                    'episode_window': [w0, w0 + args.steps], 'untimed_fast_forward_steps': w0 - args.warmup,
                    'block_threads': info['block_threads'], 'lds_bytes_per_env': info['lds_bytes'],
+                   'outputs_per_step': list(OUTPUTS) + ['wait', 'wait_norm', 'pressure', 'phase', 'queue_sum', 'queue_max', 'arrivals', 'departures'],
                    'parallelism': 'env-batch split x%d, no collective on the data path' % world},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS,

@@ -86,8 +86,14 @@ typedef struct rs_params {
 typedef struct rs_sim *rs_handle;
 
 /* env_base: global index of this handle's first environment (keys the counter-based RNG so that a batch
- * sharded over several GPUs reproduces the single-GPU batch).  block_threads: 0 = one thread per vehicle slot (<= 1024);
- * a negative value selects the 128-VGPR build of the step kernel with |block_threads| (<= 512) threads. */
+ * sharded over several GPUs reproduces the single-GPU batch).
+ * block_threads selects the workgroup shape and the register budget of the step kernel:
+ *    0            default: one thread per TWO vehicle slots (capacity / 2, a multiple of 64, at most 512) with the 80-VGPR
+ *                 build -- three 512-thread workgroups per CU for a 1024-slot scenario;
+ *    n > 0        n threads (a multiple of 64, <= 1024) with the 64-VGPR build;
+ *    -n, n <= 512 n threads with the 128-VGPR build;
+ *    -(10000 + n) n threads (<= 768) with the 80-VGPR build.
+ * Results do not depend on the choice (tests/test_gpu_parity.py::test_block_sizes_and_register_budgets_bit_exact). */
 int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
               int32_t block_threads, rs_handle *out);
 void rs_destroy(rs_handle h);
@@ -107,6 +113,15 @@ int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_device, void
 /* n x step_sim() = n x sumo.simulationStep() (multi_signal.py:102-105) without touching the signal FSM, followed by an
  * observe: MultiSignal's `warmup` ticks (multi_signal.py:139-140) and single simulation steps. */
 int rs_ticks(rs_handle h, int32_t n_ticks, void *stream);
+/* n x MultiSignal.step_sim() (multi_signal.py:102-105) and NOTHING else: the simulation advances, the Signal objects are
+ * not touched -- no observe, so Signal.waiting_times, the arrival / departure sets and every output buffer stay as the last
+ * observe left them (vehicles that leave meanwhile are counted into the next observe's departures). */
+int rs_step_sim(rs_handle h, int32_t n_ticks, void *stream);
+/* Which per-lane / per-movement output buffers the observes of the FOLLOWING launches write: bit b of buffer_mask = buffer id
+ * b (RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_DRQ_NORM_F16, RS_BUF_LANE_ARRIVALS, RS_BUF_MPLIGHT, RS_BUF_WAVE,
+ * RS_BUF_MPLIGHT_FULL); buffers left out keep their contents and cost no HBM traffic.  The per-signal scalars (phase,
+ * wait, wait_norm, pressure, queue_sum / max, arrivals, departures) are always written.  Default: all. */
+int rs_set_outputs(rs_handle h, uint64_t buffer_mask);
 int rs_sync(rs_handle h);
 /* Fresh Signal objects on the RUNNING simulation: what MultiSignal.reset() does after (re)starting SUMO
  * (multi_signal.py:141-147 -> Signal.__init__, traffic_signal.py:28-104): the RESCO waiting-time bookkeeping
@@ -137,7 +152,7 @@ enum rs_buffer {
     RS_BUF_QUEUE_MAX,      /* i32 [N][S]         calc_metrics max_queues */
     RS_BUF_ACTIONS,        /* i32 [N][S]         action staging buffer */
     RS_BUF_ENV,            /* i32 [N][4]         ticks since begin, trips inserted, high-water slot, vehicles on the network */
-    RS_BUF_TLS,            /* i32 [N][S][3]      phase, time left, next_phase */
+    RS_BUF_TLS,            /* i32 [N][S][4]      phase, time left, next_phase, |Signal.departures| collected since the last observe */
     RS_BUF_VEH_POS,        /* f32 [N][C] */
     RS_BUF_VEH_SPEED,      /* f32 [N][C] */
     RS_BUF_VEH_ACCEL,      /* f32 [N][C] */
@@ -193,9 +208,11 @@ int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches);   /* syncs;
 int rs_set_seed(rs_handle h, uint32_t seed);
 
 /* in-kernel phase timers (development aid): enable, run steps, then read 16 accumulators of wall_clock64 ticks
- * (100 MHz) summed over all workgroups, one per phase of the step kernel (barrier wait included): L0 L1 L2 L3 (load, FSM,
- * first registrations) P plan, C leave grid, M move, D decisions, A1 apply, RB grid rebuild, A2 re-enter + registrations,
- * O0..O3 observe / outputs / write-back.  Reading also resets. */
+ * (100 MHz).  Slots 0-2, 4-6, 11-14: one per phase of the step kernel, summed over all workgroups, barrier wait included
+ * (0-2 load / FSM / first registrations, 4 P plan + lane-change decision, 5 C insertion check + TLS events, 6 M move,
+ * 11-14 observe / outputs / write-back).  Slots 3, 7-10, 15: what one WAVE spends in a role inside a phase, every 16th
+ * environment, sum of ticks in the low 40 bits and number of waves above (7 look-ahead list, 8 lane-change list, 9 slots
+ * of P; 10 leavers list, 3 slots, 15 whole wave of M).  Reading also resets. */
 int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16);
 
 /* ---- fused IDQN policy forward (BASELINE config 5) ------------------------------------------

@@ -3,7 +3,8 @@
 for the static controllers, against the reference-held result arrays (tests/golden/ref_bands.json, produced by
 tests/golden/make_ref_bands.py from resco_benchmark/utils/avg_{timeLoss,duration,waitingTime,queue}.py).
 
-  delay     timeLoss + departDelay per trip, never-departed trips charged until the end   (utils/readXML.py:16-77)
+  delay     timeLoss + departDelay per tripinfo entry; never-departed demand charged only for
+            <vehicle> route files, as the reference's script does                          (utils/readXML.py:16-77)
   duration  tripinfo `duration`, arrived and (--tripinfo-output.write-unfinished) running   (utils/readXML.py:41-44)
   waiting   tripinfo `waitingTime`                                                          (the same loop)
   queue     mean over the steps of sum_signals(queue) / (S + 1)                             (utils/readCSV.py:32-46)
@@ -80,11 +81,17 @@ def episode(job):
     now = env.time
     waited, n_wait = env.backlog_delay()
     trips = st['inserted'] + n_wait
-    delay = (st['sum_time_loss_q10'] / 1024.0 + float((v['time_loss'] * act).sum()) + st['sum_depart_delay'] + waited) / max(1, trips)
     n_info = st['arrived'] + int(act.sum())                # tripinfo children: arrived + still running
+    loss = st['sum_time_loss_q10'] / 1024.0 + float((v['time_loss'] * act).sum())
+    # utils/readXML.py:59-68 adds the demand that never departed only for rou.xml files made of <vehicle> elements
+    if sc.demand_tag == 'vehicle':
+        delay = (loss + st['sum_depart_delay'] + waited) / max(1, trips)
+    else:
+        delay = (loss + st['sum_depart_delay']) / max(1, n_info)
     duration = (st['sum_duration'] + float(((now - v['depart'].astype(np.int64)) * act).sum())) / max(1, n_info)
     waiting = st['sum_waiting'] / max(1, n_info)
-    return dict(delay=delay, duration=duration, waiting=waiting, queue=qsum / steps, arrived=st['arrived'],
+    time_loss = (st['sum_time_loss_q10'] / 1024.0 + float((v['time_loss'] * act).sum())) / max(1, n_info)
+    return dict(delay=delay, duration=duration, waiting=waiting, queue=qsum / steps, time_loss=time_loss, arrived=st['arrived'],
                 inserted=st['inserted'], pending=st['pending'], mean_active=st['active_ticks'] / max(1, st['ticks']),
                 depart_delay=(st['sum_depart_delay'] + waited) / max(1, trips))
 
@@ -125,9 +132,9 @@ def main():
                     if key in ref:
                         s += ' /%7.1f (%.2f)' % (ref[key], r[key] / ref[key])
                     cells.append(s)
-                resid = r['duration'] - r['delay']
+                resid = r['duration'] - r['time_loss']
                 extra = ''
-                if pol == 'MAXPRESSURE' and 'free_flow_residual' in RB.get(m, {}):
+                if pol in ('MAXPRESSURE', 'FIXED') and 'free_flow_residual' in RB.get(m, {}):
                     extra = '  resid %.1f / %.1f' % (resid, RB[m]['free_flow_residual'])
                 print('%-13s %-11s %s  | arr %5.0f pend %4.0f V %6.1f dd %5.1f%s' % (m, pol, '  '.join(cells), r['arrived'], r['pending'], r['mean_active'], r['depart_delay'], extra), flush=True)
                 allrows.append(r)

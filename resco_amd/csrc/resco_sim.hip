@@ -154,7 +154,7 @@ __global__ void rs_reset_kernel(KTab T, State G, KParams P) {
         int ph, left;
         if (P.fixed_program) { ph = T.cold.fix_init_phase[s]; left = T.cold.fix_init_left[s]; }
         else { ph = T.cold.tls_init_phase[s]; left = T.cold.tls_dur[T.cold.tls_dur_off[s] + ph]; }
-        G.tls[(env * S + s) * 3 + 0] = ph; G.tls[(env * S + s) * 3 + 1] = left; G.tls[(env * S + s) * 3 + 2] = 0;
+        G.tls[(env * S + s) * TLS_W + 0] = ph; G.tls[(env * S + s) * TLS_W + 1] = left; G.tls[(env * S + s) * TLS_W + 2] = 0; G.tls[(env * S + s) * TLS_W + 3] = 0;
     }
     for (int d = threadIdx.x; d < T.n_dep; d += blockDim.x) G.dep_next[(size_t)env * T.n_dep + d] = T.cold.dep_first[d];
     if (threadIdx.x < 4) G.env[env * 4 + threadIdx.x] = 0;
@@ -170,8 +170,8 @@ __global__ void rs_reinit_kernel(KTab T, State G, KParams P) {
     const size_t eo = (size_t)env * C;
     for (int s = threadIdx.x; s < C; s += blockDim.x) { G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0; }
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        if (!P.fixed_program) G.tls[(env * S + s) * 3 + 1] = T.cold.tls_dur[T.cold.tls_dur_off[s] + G.tls[(env * S + s) * 3 + 0]];
-        G.tls[(env * S + s) * 3 + 2] = 0;
+        if (!P.fixed_program) G.tls[(env * S + s) * TLS_W + 1] = T.cold.tls_dur[T.cold.tls_dur_off[s] + G.tls[(env * S + s) * TLS_W + 0]];
+        G.tls[(env * S + s) * TLS_W + 2] = 0; G.tls[(env * S + s) * TLS_W + 3] = 0;
     }
 }
 
@@ -218,6 +218,7 @@ struct rs_sim {
     State G{};
     Out O{};
     KParams P{};
+    uint32_t out_mask = OUT_ALL;        // rs_set_outputs
     int32_t *actions = nullptr;
     int32_t *pairs = nullptr, *valid = nullptr, *order = nullptr;
     unsigned long long *prof = nullptr;
@@ -363,7 +364,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         G.nc = NC;
         O.n = n_envs; O.o = sc->n_obs; O.s = sc->n_signals; O.lm = lmax;
         if ((rc = dev_alloc(h, &slab, State::bytes(NC))) || (rc = dev_alloc(h, &outb, O.bytes())) ||
-            (rc = dev_alloc(h, &G.env, N * 4)) || (rc = dev_alloc(h, &G.tls, N * S * 3)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
+            (rc = dev_alloc(h, &G.env, N * 4)) || (rc = dev_alloc(h, &G.tls, N * S * TLS_W)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
             (rc = dev_alloc(h, &G.dep_next, N * (size_t)h->K.n_dep)) ||
             (rc = dev_alloc(h, &h->actions, N * S)))
             return fail(rc);
@@ -383,7 +384,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_QUEUE_MAX, O.queue_max(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_ACTIONS, h->actions, RS_I32, 2, n, s);
     set_buf(h, RS_BUF_ENV, G.env, RS_I32, 2, n, 4);
-    set_buf(h, RS_BUF_TLS, G.tls, RS_I32, 3, n, s, 3);
+    set_buf(h, RS_BUF_TLS, G.tls, RS_I32, 3, n, s, TLS_W);
     set_buf(h, RS_BUF_VEH_POS, G.pos(), RS_F32, 2, n, c);
     set_buf(h, RS_BUF_VEH_SPEED, G.speed(), RS_F32, 2, n, c);
     set_buf(h, RS_BUF_VEH_ACCEL, G.accel(), RS_F32, 2, n, c);
@@ -469,9 +470,9 @@ extern "C" void rs_destroy(rs_handle h) {
 
 extern "C" const char *rs_last_error(rs_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm) {
+static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm, int do_observe = 1) {
     KParams P = h->P;
-    P.n_ticks = n_ticks; P.do_fsm = do_fsm; P.prof = h->prof;
+    P.n_ticks = n_ticks; P.do_fsm = do_fsm; P.do_observe = do_observe; P.out_mask = h->out_mask; P.prof = h->prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->timing) {
         if (h->ev_used == h->events.size()) {
@@ -538,6 +539,29 @@ extern "C" int rs_ticks(rs_handle h, int32_t n_ticks, void *stream) {
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     h->last = st;
     return launch_step(h, st, n_ticks, 0);
+}
+
+extern "C" int rs_step_sim(rs_handle h, int32_t n_ticks, void *stream) {
+    if (!h || n_ticks < 0) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->last = st;
+    return launch_step(h, st, n_ticks, 0, 0);
+}
+
+// which output buffers the observe of the following launches writes (bit b = buffer id b); the others keep their contents
+extern "C" int rs_set_outputs(rs_handle h, uint64_t buffer_mask) {
+    if (!h) return RS_EINVAL;
+    uint32_t m = 0;
+    if (buffer_mask & (1ull << RS_BUF_LANE_AGG)) m |= OUT_LANE_AGG;
+    if (buffer_mask & (1ull << RS_BUF_DRQ_NORM)) m |= OUT_DRQ_NORM;
+    if (buffer_mask & (1ull << RS_BUF_DRQ_NORM_F16)) m |= OUT_DRQ_F16;
+    if (buffer_mask & (1ull << RS_BUF_LANE_ARRIVALS)) m |= OUT_LANE_ARR;
+    if (buffer_mask & (1ull << RS_BUF_MPLIGHT)) m |= OUT_MPLIGHT;
+    if (buffer_mask & (1ull << RS_BUF_WAVE)) m |= OUT_WAVE;
+    if (buffer_mask & (1ull << RS_BUF_MPLIGHT_FULL)) m |= OUT_MPLIGHT_FULL;
+    h->out_mask = m;
+    return RS_OK;
 }
 
 extern "C" int rs_sync(rs_handle h) {

@@ -26,7 +26,7 @@ struct State {      // env-major SoA in HBM: field[env][slot]
     size_t nc;          // N * C
     int32_t *trip_log;  // [N][n_trips][4] or NULL
     int32_t *env;       // [N][4] t, n_inserted, hw, n_active
-    int32_t *tls;       // [N][S][3] phase, left, next_phase
+    int32_t *tls;       // [N][S][TLS_W] phase, left, next_phase, departures since the last observe
     long long *stats;   // [N][10]
     uint16_t *dep_next; // [N][n_dep] head of every departure lane's backlog (TRIP_NONE: exhausted)
     RS_HD float *pos() const { return (float *)base; }
@@ -984,12 +984,12 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             L.dep[i] = (uint16_t)k;
             L.dep_t[i] = k == (int)TRIP_NONE ? (uint16_t)0xFFFF : (uint16_t)T.cold.trip_depart[k];
         }
-        for (int i = tid; i < S; i += B) { L.sig_arr[i] = 0; L.sig_dep[i] = 0; }
         for (int i = tid; i < S; i += B) {
-            const int ph = G.tls[(env * S + i) * 3 + 0];
+            const int ph = G.tls[(env * S + i) * TLS_W + 0];
             L.phase[i] = ph;
-            L.left[i] = G.tls[(env * S + i) * 3 + 1];
-            L.nextp[i] = G.tls[(env * S + i) * 3 + 2];
+            L.left[i] = G.tls[(env * S + i) * TLS_W + 1];
+            L.nextp[i] = G.tls[(env * S + i) * TLS_W + 2];
+            L.sig_arr[i] = 0; L.sig_dep[i] = G.tls[(env * S + i) * TLS_W + 3];     // (vehicles that left since the last observe)
             tls_refresh(T, L, P, i, ph);
         }
     });
@@ -1175,8 +1175,10 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
     }
     const int hw_end = L.sc[cur ? SC_HWNEW : SC_HW];
 
-    // ---- Signal.observe for every signal (traffic_signal.py:189-247)
-    ex.phase(11, [&](int tid) {
+    // ---- Signal.observe for every signal (traffic_signal.py:189-247); without it (step_sim, multi_signal.py:102-105) only the
+    //      state goes back: the Signal objects' waiting times, owners and arrival / departure sets are left alone
+    const bool obs = P.do_observe != 0;
+    if (obs) ex.phase(11, [&](int tid) {
         for (int i = tid; i < NO; i += B) { L.agg_q[i] = 0; L.agg_a[i] = 0; L.agg_w[i] = 0; L.agg_m[i] = 0; L.agg_s[i] = 0; L.agg_n[i] = 0; }
     });
     ex.phase(12, [&](int tid) {
@@ -1185,7 +1187,6 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         int hi = 0;
         for (int s = tid; s < top; s += B) {
             const int lane = L.aux[s].lane;
-            const int prev_owner = G.owner()[eo + s];
             G.lane()[eo + s] = (uint16_t)lane; G.trip()[eo + s] = L.node[s].trip;
             if (lane == (int)LANE_NONE) continue;
             hi = s + 1;
@@ -1193,6 +1194,8 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             const int rq = L.aux[s].rq;
             G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.node[s].speed; G.swait()[eo + s] = L.aux[s].swait;
             G.cursor()[eo + s] = (uint16_t)(rq - (int)T.routes()[T.trip_route()[L.node[s].trip]].start);
+            if (!obs) continue;
+            const int prev_owner = G.owner()[eo + s];
             const LaneRec LR = T.lanes()[lane];
             const int oi = T.cold.lane_obs[lane];
             bool detect = false;
@@ -1223,9 +1226,11 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         }
         if (hi) rs_atomic_max(&L.sc[SC_HWOUT], hi);
     });
-    // per observed lane rows, written as flat coalesced streams; states / rewards; state write-back
+    // per observed lane rows, written as flat coalesced streams; states / rewards -- only the buffers the caller asked for
+    // (rs_set_outputs); state write-back
     ex.phase(13, [&](int tid) {
-        for (int i = tid; i < NO * 5; i += B) {
+        const uint32_t om = obs ? P.out_mask : 0u;
+        if (om & (OUT_LANE_AGG | OUT_DRQ_NORM)) for (int i = tid; i < NO * 5; i += B) {
             const int oi = i / 5, c = i - oi * 5;
             const int sg = T.cold.obs_sig[oi];
             const float sp = (float)L.agg_s[oi] * (1.0f / 65536.0f);
@@ -1235,11 +1240,11 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             else if (c == 2) { raw = (float)L.agg_w[oi]; nrm = raw / 28.0f; }
             else if (c == 3) { raw = (float)L.agg_m[oi]; nrm = (float)L.agg_q[oi] / 28.0f; }
             else { raw = sp; nrm = sp / 20.0f / 28.0f; }
-            O.lane_agg()[(size_t)env * NO * 5 + i] = raw;         // queue, approach, total_wait, max_wait, speed_sum
-            O.drq_norm()[(size_t)env * NO * 5 + i] = nrm;         // one-hot(lane position == phase), approach, wait, queue, speed
+            if (om & OUT_LANE_AGG) O.lane_agg()[(size_t)env * NO * 5 + i] = raw;         // queue, approach, total_wait, max_wait, speed_sum
+            if (om & OUT_DRQ_NORM) O.drq_norm()[(size_t)env * NO * 5 + i] = nrm;         // one-hot(lane position == phase), approach, wait, queue, speed
         }
-        for (int i = tid; i < NO; i += B) O.lane_arr()[(size_t)env * NO + i] = L.agg_n[i];
-        for (int i = tid; i < S * T.lmax * 5; i += B) {
+        if (om & OUT_LANE_ARR) for (int i = tid; i < NO; i += B) O.lane_arr()[(size_t)env * NO + i] = L.agg_n[i];
+        if (om & OUT_DRQ_F16) for (int i = tid; i < S * T.lmax * 5; i += B) {
             const int sg = i / (T.lmax * 5), r = i - sg * T.lmax * 5;
             const int l = r / 5, c = r - l * 5;
             const int o0 = T.cold.sig_obs_start[sg];
@@ -1255,7 +1260,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             O.drq_f16()[(size_t)env * S * T.lmax * 5 + i] = rs_f2h(nrm);
         }
         // states.mplight / wave / mplight_full: one thread per (signal, movement)
-        for (int i = tid; i < S * 12; i += B) {
+        if (om & (OUT_MPLIGHT | OUT_WAVE | OUT_MPLIGHT_FULL)) for (int i = tid; i < S * 12; i += B) {
             const int sg = i / 12, m = i - sg * 12;
             int q = 0, wv = 0, tw = 0, ap = 0;
             float last_speed = 0.0f;
@@ -1266,31 +1271,36 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             }
             for (int j = T.cold.mv_out_start[i]; j < T.cold.mv_out_start[i + 1]; ++j) q -= L.agg_q[T.cold.mv_out_idx[j]];
             const size_t so = (size_t)env * S + sg;
-            O.mplight()[so * 13 + 1 + m] = q;
-            O.wave()[so * 12 + m] = wv;
-            float *mf = O.mplight_full() + so * 49 + 1 + m * 4;             // states.mplight_full (states.py:83-113)
-            mf[0] = (float)q; mf[1] = (float)tw / 28.0f; mf[2] = last_speed; mf[3] = (float)ap / 28.0f;
+            if (om & OUT_MPLIGHT) O.mplight()[so * 13 + 1 + m] = q;
+            if (om & OUT_WAVE) O.wave()[so * 12 + m] = wv;
+            if (om & OUT_MPLIGHT_FULL) {
+                float *mf = O.mplight_full() + so * 49 + 1 + m * 4;         // states.mplight_full (states.py:83-113)
+                mf[0] = (float)q; mf[1] = (float)tw / 28.0f; mf[2] = last_speed; mf[3] = (float)ap / 28.0f;
+            }
         }
         // per signal: phase, rewards, metrics
         for (int sg = tid; sg < S; sg += B) {
             const int ph = L.phase[sg];
-            const int o0 = T.cold.sig_obs_start[sg], o1 = T.cold.sig_obs_start[sg + 1];
-            int tw = 0, tq = 0, mq = 0;
-            for (int oi = o0; oi < o1; ++oi) { tw += L.agg_w[oi]; const int qq = L.agg_q[oi]; tq += qq; if (qq > mq) mq = qq; }
-            const size_t so = (size_t)env * S + sg;
-            O.phase()[so] = ph; O.queue_sum()[so] = tq; O.queue_max()[so] = mq;
-            O.wait()[so] = -(float)tw;
-            const float wn = -(float)tw / 224.0f;
-            O.wait_norm()[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
-            int pr = tq;
-            for (int i = T.cold.pr_out_start[sg]; i < T.cold.pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.cold.pr_out_idx[i]];
-            O.pressure()[so] = -pr;
-            O.mplight()[so * 13] = ph;
-            O.mplight_full()[so * 49] = (float)ph;
-            O.arrivals()[so] = L.sig_arr[sg]; O.departures()[so] = L.sig_dep[sg];
-            G.tls[(env * S + sg) * 3 + 0] = ph;
-            G.tls[(env * S + sg) * 3 + 1] = L.left[sg];
-            G.tls[(env * S + sg) * 3 + 2] = L.nextp[sg];
+            if (obs) {
+                const int o0 = T.cold.sig_obs_start[sg], o1 = T.cold.sig_obs_start[sg + 1];
+                int tw = 0, tq = 0, mq = 0;
+                for (int oi = o0; oi < o1; ++oi) { tw += L.agg_w[oi]; const int qq = L.agg_q[oi]; tq += qq; if (qq > mq) mq = qq; }
+                const size_t so = (size_t)env * S + sg;
+                O.phase()[so] = ph; O.queue_sum()[so] = tq; O.queue_max()[so] = mq;
+                O.wait()[so] = -(float)tw;
+                const float wn = -(float)tw / 224.0f;
+                O.wait_norm()[so] = wn < -4.0f ? -4.0f : (wn > 4.0f ? 4.0f : wn);
+                int pr = tq;
+                for (int i = T.cold.pr_out_start[sg]; i < T.cold.pr_out_start[sg + 1]; ++i) pr -= L.agg_q[T.cold.pr_out_idx[i]];
+                O.pressure()[so] = -pr;
+                if (om & OUT_MPLIGHT) O.mplight()[so * 13] = ph;
+                if (om & OUT_MPLIGHT_FULL) O.mplight_full()[so * 49] = (float)ph;
+                O.arrivals()[so] = L.sig_arr[sg]; O.departures()[so] = L.sig_dep[sg];
+            }
+            G.tls[(env * S + sg) * TLS_W + 0] = ph;
+            G.tls[(env * S + sg) * TLS_W + 1] = L.left[sg];
+            G.tls[(env * S + sg) * TLS_W + 2] = L.nextp[sg];
+            G.tls[(env * S + sg) * TLS_W + 3] = obs ? 0 : L.sig_dep[sg];
         }
         for (int i = tid; i < T.n_dep; i += B) G.dep_next[(size_t)env * T.n_dep + i] = L.dep[i];
     });

@@ -132,9 +132,22 @@ struct KParams {
     int32_t speed_dev, fixed_program;
     int32_t n_ticks;        // ticks to simulate in this launch (0: observe only)
     int32_t do_fsm;         // apply prep_phase / set_phase around the ticks
+    int32_t do_observe;     // 1: Signal.observe + states / rewards after the ticks; 0: only the state goes back (step_sim)
+    uint32_t out_mask;      // which of the per-lane / per-movement output buffers an observe writes, see OUT_*
     int32_t n_envs;
     unsigned long long *prof;   // optional [16] per-phase cycle accumulators (rs_phase_profile), NULL = off
 };
+
+// output groups (KParams.out_mask); the per-signal scalars (phase, rewards, queue metrics, arrivals / departures) are always written
+#define OUT_LANE_AGG 1u
+#define OUT_DRQ_NORM 2u
+#define OUT_DRQ_F16 4u
+#define OUT_LANE_ARR 8u
+#define OUT_MPLIGHT 16u
+#define OUT_WAVE 32u
+#define OUT_MPLIGHT_FULL 64u
+#define OUT_ALL 127u
+#define TLS_W 4         // ints per signal in State.tls: phase, time left, next_phase, |Signal.departures| collected since the last observe
 
 // ---------------------------------------------------------------------------------------------- host-side builder
 struct PackedTables {

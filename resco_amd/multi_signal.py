@@ -41,6 +41,42 @@ except Exception:  # pragma: no cover - gym is not installed in the build image
 _SCEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scenarios')
 
 
+def tripinfo_records(sc, log, now, lane, trip, depart, tloss, wtot, seed, env_index, speed_dev):
+    """tripinfo entries from the trip log ([n_trips][4] depart tick, arrival tick, timeLoss / 1024, waiting) and the
+    per-slot arrays of the vehicles still on the network: finished trips in arrival order, then the running ones."""
+    sched = sc.trip_depart
+
+    def rec(k, depart_tick, arrival_tick, tl, waiting):
+        dep = depart_tick - 1               # inserted at the end of the previous simulation second
+        # (the speed factor is a function of seed, environment and trip)
+        sf = speed_factor(seed, env_index, k, sc.vtype_params[int(sc.trip_vtype[k])], speed_dev)
+        return {'id': sc.trip_ids[k], 'depart': float(sc.begin + dep), 'departDelay': float(dep - int(sched[k])),
+                'arrival': float(sc.begin + arrival_tick) if arrival_tick > 0 else -1.0,
+                'duration': float((arrival_tick if arrival_tick > 0 else now) - depart_tick),
+                'waitingTime': float(waiting), 'timeLoss': float(tl),
+                'vType': sc.vtype_ids[int(sc.trip_vtype[k])], 'speedFactor': float(sf)}
+
+    done = np.nonzero(log[:, 1] > 0)[0]
+    recs = [rec(int(k), int(log[k, 0]), int(log[k, 1]), log[k, 2] / 1024.0, int(log[k, 3]))
+            for k in done[np.argsort(log[done, 1], kind='stable')]]
+    for s_ in np.nonzero(np.asarray(lane) < 0xFFFE)[0]:
+        recs.append(rec(int(trip[s_]), int(depart[s_]), 0, float(tloss[s_]), int(wtot[s_])))
+    return recs
+
+
+def write_tripinfo(path, recs):
+    """tripinfo_<run>.xml with the attributes the reference's post-processing reads (utils/readXML.py:36-47)"""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as f:
+        f.write('<?xml version="1.0" encoding="UTF-8"?>\n<tripinfos>\n')
+        for r in recs:
+            f.write('    <tripinfo id="%s" depart="%.2f" departDelay="%.2f" arrival="%.2f" duration="%.2f" '
+                    'waitingTime="%.2f" timeLoss="%.2f" vType="%s" speedFactor="%.2f"/>\n'
+                    % (r['id'], r['depart'], r['departDelay'], r['arrival'], r['duration'], r['waitingTime'],
+                       r['timeLoss'], r['vType'], r['speedFactor']))
+        f.write('</tripinfos>\n')
+
+
 def load_scenario(map_name, net=None, lights=(), yellow_length=3):
     """Scenario tables for a map: compiled from the SUMO files when `net` names an existing .sumocfg,
     otherwise the pre-compiled tables shipped in resco_amd/scenarios/."""
@@ -179,8 +215,9 @@ class MultiSignal(_EnvBase):
 
     # ------------------------------------------------------------------ gym API
     def step_sim(self):
-        """one sumo.simulationStep() (multi_signal.py:102-105); MultiSignal.step() fuses its ticks into one launch"""
-        self.sim.ticks(1)
+        """one sumo.simulationStep() (multi_signal.py:102-105) and nothing else -- the Signal objects are not observed, their
+        waiting times and arrival / departure sets stay as they are; MultiSignal.step() fuses its ticks into one launch"""
+        self.sim.step_sim(1)
         self._version += 1
 
     def reinit_signals(self):
@@ -261,46 +298,17 @@ class MultiSignal(_EnvBase):
         (SUMO's --tripinfo-output with --tripinfo-output.write-unfinished, multi_signal.py:127-129)."""
         if not self.tripinfo:
             return []
-        sc, e = self.scenario, self.view_env
-        log = self.sim.read('trip_log')[e]
-        now = int(self.sim.read('env')[e, 0])
-        recs = []
-        sched = sc.trip_depart
-
-        def rec(k, depart_tick, arrival_tick, tloss, waiting, sf):
-            depart = depart_tick - 1            # inserted at the end of the previous simulation second
-            return {'id': sc.trip_ids[k], 'depart': float(sc.begin + depart), 'departDelay': float(depart - int(sched[k])),
-                    'arrival': float(sc.begin + arrival_tick) if arrival_tick > 0 else -1.0,
-                    'duration': float((arrival_tick if arrival_tick > 0 else now) - depart_tick),
-                    'waitingTime': float(waiting), 'timeLoss': float(tloss),
-                    'vType': sc.vtype_ids[int(sc.trip_vtype[k])], 'speedFactor': float(sf)}
-
-        done = np.nonzero(log[:, 1] > 0)[0]
-        for k in done[np.argsort(log[done, 1], kind='stable')]:
-            # (the trip log does not keep the speed factor: it is a function of seed, env and trip)
-            sf = speed_factor(self.sim.seed, self.sim.env_base + e, int(k), sc.vtype_params[int(sc.trip_vtype[k])], self.sim.speed_dev)
-            recs.append(rec(int(k), int(log[k, 0]), int(log[k, 1]), log[k, 2] / 1024.0, int(log[k, 3]), sf))
-        lane, trip = self.sim.read('veh_lane')[e], self.sim.read('veh_trip')[e]
-        dep, tl = self.sim.read('veh_depart')[e], self.sim.read('veh_tloss')[e]
-        wt, sf = self.sim.read('veh_wtot')[e], self.sim.read('veh_sf')[e]
-        for s_ in np.nonzero(lane < 0xFFFE)[0]:
-            recs.append(rec(int(trip[s_]), int(dep[s_]), 0, float(tl[s_]), int(wt[s_]), float(sf[s_])))
-        return recs
+        e = self.view_env
+        rd = self.sim.read
+        return tripinfo_records(self.scenario, rd('trip_log')[e], int(rd('env')[e, 0]), rd('veh_lane')[e], rd('veh_trip')[e],
+                                rd('veh_depart')[e], rd('veh_tloss')[e], rd('veh_wtot')[e], self.sim.seed,
+                                self.sim.env_base + e, self.sim.speed_dev)
 
     def save_tripinfo(self):
         if not self.tripinfo:
             return
-        path = os.path.join(self.log_dir, self.connection_name, 'tripinfo_' + str(self.run) + '.xml')
         try:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            with open(path, 'w') as f:
-                f.write('<?xml version="1.0" encoding="UTF-8"?>\n<tripinfos>\n')
-                for r in self.tripinfo_records():
-                    f.write('    <tripinfo id="%s" depart="%.2f" departDelay="%.2f" arrival="%.2f" duration="%.2f" '
-                            'waitingTime="%.2f" timeLoss="%.2f" vType="%s" speedFactor="%.2f"/>\n'
-                            % (r['id'], r['depart'], r['departDelay'], r['arrival'], r['duration'], r['waitingTime'],
-                               r['timeLoss'], r['vType'], r['speedFactor']))
-                f.write('</tripinfos>\n')
+            write_tripinfo(os.path.join(self.log_dir, self.connection_name, 'tripinfo_' + str(self.run) + '.xml'), self.tripinfo_records())
         except OSError:
             pass
 
@@ -329,7 +337,7 @@ class VecMultiSignal:
 
     def __init__(self, map_name, n_envs, states=('drq_norm',), rewards=('wait',), net=None, device=0, seed=0,
                  max_distance=200, step_length=10, yellow_length=3, sigma=-1.0, speed_dev=1, fixed_program=False,
-                 env_base=0, block_threads=0, scenario=None):
+                 env_base=0, block_threads=0, scenario=None, outputs=None):
         mc = map_configs.get(map_name, {})
         self.scenario = scenario if scenario is not None else load_scenario(map_name, net, mc.get('lights', ()),
                                                                             yellow_length)
@@ -345,6 +353,8 @@ class VecMultiSignal:
         self.all_ts_ids = list(self.scenario.signal_ids)
         self.n_actions = [int(g) for g in self.scenario.tls_ngreen]
         self._tensors = {}
+        if outputs is not None:         # only these per-lane / per-movement buffers are written (BatchedSim.set_outputs)
+            self.sim.set_outputs(outputs)
 
     # registry names that are not a device buffer of their own but a cheap arrangement of buffers (torch ops on the stream)
     DERIVED = ('drq', 'fma2c', 'fma2c_full')

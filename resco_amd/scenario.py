@@ -319,6 +319,8 @@ class Scenario:
     signal_meta: dict = field(default_factory=dict)     # sid -> derive_signal_lanes(...) + phases/yellow_dict
     phase_pairs: list = field(default_factory=list)
     valid_acts: dict | None = None
+    demand_tag: str = 'trip'             # element name of the demand in the rou.xml: 'trip' (routed at load) or 'vehicle' (explicit
+                                         # routes); utils/readXML.py:59-68 charges never-departed demand only for 'vehicle' files
 
     def __getattr__(self, k):
         arrays = self.__dict__.get('arrays')
@@ -352,6 +354,7 @@ class Scenario:
                     capacity=self.capacity, signal_ids=self.signal_ids, lane_ids=self.lane_ids,
                     edge_ids=self.edge_ids, obs_lane_ids=self.obs_lane_ids, trip_ids=self.trip_ids,
                     vtype_ids=self.vtype_ids, signal_meta=self.signal_meta, phase_pairs=self.phase_pairs,
+                    demand_tag=self.demand_tag,
                     valid_acts=None if self.valid_acts is None else
                     {k: [[int(a), int(b)] for a, b in v.items()] for k, v in self.valid_acts.items()})
         blob = np.frombuffer(json.dumps(meta).encode('utf-8'), dtype=np.uint8)
@@ -857,7 +860,8 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
                   arrays=A, signal_ids=list(tl_ids), lane_ids=lane_ids, edge_ids=edge_ids,
                   obs_lane_ids=obs_lane_ids, trip_ids=trip_ids, vtype_ids=vtype_ids,
                   signal_meta=signal_meta, phase_pairs=[list(p) for p in sig_cfg_map.get('phase_pairs', [])],
-                  valid_acts=sig_cfg_map.get('valid_acts'))
+                  valid_acts=sig_cfg_map.get('valid_acts'),
+                  demand_tag='vehicle' if any(t[5] is not None for t in trips_xml) else 'trip')
     sc.dropped_trips = dropped
     return sc
 

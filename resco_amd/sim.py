@@ -20,6 +20,7 @@ BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_nor
            'veh_sf', 'veh_wtot', 'trip_log', 'dep_next', 'veh_coop', 'veh_cooplead', 'arrivals', 'departures',
            'mplight_full', 'lane_arrivals', 'veh_coop_odd', 'veh_cooplead_odd']
 BUF_ID = {n: i for i, n in enumerate(BUFFERS)}
+OUTPUT_GROUPS = ('lane_agg', 'drq_norm', 'drq_norm_f16', 'lane_arrivals', 'mplight', 'wave', 'mplight_full')
 _NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64, np.uint32]
 _TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8', '<u4']
 STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10',
@@ -27,7 +28,7 @@ STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_wai
 TRIP_NONE = 0xFFFF
 
 # every symbol include/resco_sim.h declares
-ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_reinit_signals', 'rs_ticks', 'rs_act_random',
+ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_reinit_signals', 'rs_ticks', 'rs_step_sim', 'rs_set_outputs', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
                'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_phase_profile', 'rs_info',
                'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_destroy']
@@ -47,6 +48,8 @@ def bind(L):
     L.rs_step.argtypes = [vp, vp, i32, vp]
     L.rs_sync.argtypes = [vp]
     L.rs_ticks.argtypes = [vp, i32, vp]
+    L.rs_step_sim.argtypes = [vp, i32, vp]
+    L.rs_set_outputs.argtypes = [vp, C.c_uint64]
     L.rs_reinit_signals.argtypes = [vp, vp]
     L.rs_act_random.argtypes = [vp, C.c_uint32, vp]
     L.rs_act_maxwave.argtypes = [vp, vp, i32, vp, vp, i32, vp]
@@ -147,6 +150,10 @@ class BatchedSim:
         self.n_envs = int(n_envs)
         self.device = int(device)
         self._lib = self._load()
+        if yellow_length is not None and int(yellow_length) != int(scenario.yellow_length):
+            # the yellow phases are compiled into the scenario's programmes with ITS yellow_length; the FSM would call
+            # set_phase after a different number of ticks
+            raise ValueError('scenario %s was compiled with yellow_length=%d (asked %d)' % (scenario.name, scenario.yellow_length, yellow_length))
         self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
         self._p = ParamsStruct(int(seed) & 0xFFFFFFFF, float(max_distance), float(sigma), int(speed_dev),
                                int(fixed_program), int(trip_log))
@@ -160,6 +167,7 @@ class BatchedSim:
         self.S, self.O, self.C = scenario.n_signals, scenario.n_obs, scenario.capacity
         self.seed, self.env_base, self.speed_dev = int(seed) & 0xFFFFFFFF, int(env_base), int(speed_dev)
         self._maxwave_ready = False
+        self._dep_cache = None
         self._meta = {}
         for name, bid in BUF_ID.items():
             ptr, shape, nd, dt = C.c_void_p(), (C.c_int64 * 4)(), C.c_int32(), C.c_int32()
@@ -213,6 +221,21 @@ class BatchedSim:
     def ticks(self, n, stream=None):
         """n x step_sim() without the signal FSM, then an observe (see rs_ticks)"""
         self._check(self._lib.rs_ticks(self._h, int(n), stream))
+
+    def step_sim(self, n=1, stream=None):
+        """n x sumo.simulationStep() and nothing else: no observe, the Signal state stays as it is (see rs_step_sim)"""
+        self._check(self._lib.rs_step_sim(self._h, int(n), stream))
+
+    def set_outputs(self, names=None):
+        """Only the named per-lane / per-movement buffers ('lane_agg', 'drq_norm', 'drq_norm_f16', 'lane_arrivals', 'mplight',
+        'wave', 'mplight_full') are written by the following observes; None = all of them.  The per-signal scalars (phase,
+        wait, wait_norm, pressure, queue_sum, queue_max, arrivals, departures) are always written (see rs_set_outputs)."""
+        mask = 0
+        for n in (OUTPUT_GROUPS if names is None else names):
+            if n not in OUTPUT_GROUPS:
+                raise ValueError('%r is not a maskable output buffer (%s)' % (n, ', '.join(OUTPUT_GROUPS)))
+            mask |= 1 << BUF_ID[n]
+        self._check(self._lib.rs_set_outputs(self._h, mask))
 
     def reinit_signals(self, stream=None):
         """fresh Signal objects on the running simulation (see rs_reinit_signals)"""
@@ -268,40 +291,68 @@ class BatchedSim:
     def time(self):
         return self.read('env')[:, 0]
 
+    def _dep_lanes(self):
+        """The departure lanes in the kernel's numbering (resco_tables.h: the first allowed lane of the first edge of every
+        ROUTE, ascending) and, per lane, its trips in FIFO order with their departure seconds and running sums."""
+        if self._dep_cache is None:
+            A = self.sc.arrays
+            lane_of_route = A['edge_lane0'][A['route_edge'][A['route_start'][:-1]]]
+            lanes = np.unique(lane_of_route)
+            n_dep = self._meta['dep_next'][1][1]
+            if len(lanes) != n_dep:
+                raise RuntimeError('departure lanes of the scenario (%d) do not match the library (%d)' % (len(lanes), n_dep))
+            lane_of_trip = lane_of_route[A['trip_route']]
+            depart = A['trip_depart'].astype(np.int64)
+            tabs = []
+            for lane in lanes:
+                trips = np.nonzero(lane_of_trip == lane)[0]          # ascending trip index = FIFO order = departure order
+                dep = depart[trips]
+                tabs.append((trips, dep, np.concatenate([[0], np.cumsum(dep)])))
+            self._dep_cache = tabs
+        return self._dep_cache
+
     def backlog(self):
         """Trips that have departed (depart < now) but are not on the network yet, per environment: (count, seconds
         waited so far).  Every departure lane keeps its own backlog (RS_BUF_DEP_NEXT = its next trip); utils/readXML.py:52-68
         charges such trips end_time - depart."""
-        A = self.sc.arrays
-        dep_lane_of_trip = A['edge_lane0'][A['route_edge'][A['route_start'][A['trip_route']]]]
-        lanes = np.unique(dep_lane_of_trip)                      # departure lanes in ascending lane order
         head = self.read('dep_next').astype(np.int64)            # [N, n_dep]
         now = self.time().astype(np.int64)
-        depart = A['trip_depart'].astype(np.int64)
         cnt = np.zeros(self.n_envs, np.int64)
         waited = np.zeros(self.n_envs, np.int64)
-        for d, lane in enumerate(lanes):
-            trips = np.nonzero(dep_lane_of_trip == lane)[0]      # ascending trip index = FIFO order
-            dep = depart[trips]
-            for e in range(self.n_envs):
-                h = head[e, d]
-                first = len(trips) if h == TRIP_NONE else int(np.searchsorted(trips, h))
-                due = dep[first:][dep[first:] < now[e]]
-                cnt[e] += len(due)
-                waited[e] += int((now[e] - due).sum())
+        for d, (trips, dep, csum) in enumerate(self._dep_lanes()):
+            h = head[:, d]
+            first = np.where(h == TRIP_NONE, len(trips), np.searchsorted(trips, h))
+            last = np.maximum(first, np.searchsorted(dep, now, side='left'))      # trips [first, last) are due and waiting
+            cnt += last - first
+            waited += (last - first) * now - (csum[last] - csum[first])
         return cnt, waited
 
     def trip_delay(self):
-        """Per-environment average trip delay as the reference's post-processing defines it (utils/readXML.py:
-        timeLoss + departDelay per tripinfo entry, unfinished trips included as tripinfo-output.write-unfinished
-        writes them): (time loss of arrived and of still-running vehicles + insertion delays + the waiting of trips
-        still queued for insertion) / (inserted + queued trips)."""
+        """Per-environment average trip delay exactly as the reference's post-processing computes it, see trip_metrics()."""
+        return self.trip_metrics()['delay']
+
+    def trip_metrics(self):
+        """The per-episode figures of utils/readXML.py:16-77 per environment.
+        `delay`: (timeLoss + departDelay) summed over the tripinfo entries -- the arrived and, as
+        --tripinfo-output.write-unfinished writes them, the running vehicles -- divided by their number; demand that never
+        got onto the network is added (end_time - depart each, one more trip each) only when the rou.xml lists <vehicle>
+        elements: readXML.py:59-68 skips every other tag, so the <trip> files of five of the six maps are never charged for it.
+        `delay_all` charges the queued demand on every map.  `duration`, `waiting`, `time_loss`: tripinfo duration /
+        waitingTime / timeLoss over the same entries."""
         st = self.stats()
         lane = self.read('veh_lane')
-        running = (self.read('veh_tloss') * (lane != 0xFFFF)).sum(axis=1)
+        live = lane != 0xFFFF
+        running = (self.read('veh_tloss') * live).sum(axis=1)
         cnt, waited = self.backlog()
-        trips = st['inserted'] + cnt
-        return (st['sum_time_loss_q10'] / 1024.0 + running + st['sum_depart_delay'] + waited) / np.maximum(1, trips)
+        now = self.time().astype(np.int64)
+        entries = st['arrived'] + live.sum(axis=1)
+        run_dur = ((now[:, None] - self.read('veh_depart').astype(np.int64)) * live).sum(axis=1)
+        loss = st['sum_time_loss_q10'] / 1024.0 + running
+        delay_all = (loss + st['sum_depart_delay'] + waited) / np.maximum(1, entries + cnt)
+        delay = delay_all if self.sc.demand_tag == 'vehicle' else (loss + st['sum_depart_delay']) / np.maximum(1, entries)
+        entries = np.maximum(1, entries)
+        return dict(delay=delay, delay_all=delay_all, duration=(st['sum_duration'] + run_dur) / entries,
+                    waiting=st['sum_waiting'] / entries, time_loss=loss / entries)
 
     # ------------------------------------------------------------------ snapshots / timing
     def snapshot(self):

@@ -103,6 +103,7 @@ struct rs_sim {
     size_t lds = 0;
     std::vector<char> slab, outb, smem;
     std::vector<int32_t> env, tls, actions, trip_log, pairs, valid, ordr;
+    uint32_t out_mask = OUT_ALL;
     std::vector<long long> stats;
     std::vector<uint16_t> dep_next;
     std::vector<float> route_cont, vtype_params;
@@ -126,9 +127,9 @@ static const int32_t *keep_i32(rs_sim *h, const int32_t *src, size_t n) {
     return h->keep.back().data();
 }
 
-static void run_step(rs_sim *h, int n_ticks, int do_fsm) {
+static void run_step(rs_sim *h, int n_ticks, int do_fsm, int do_observe = 1) {
     KParams P = h->P;
-    P.n_ticks = n_ticks; P.do_fsm = do_fsm; P.prof = nullptr;
+    P.n_ticks = n_ticks; P.do_fsm = do_fsm; P.do_observe = do_observe; P.out_mask = h->out_mask; P.prof = nullptr;
     for (int env = 0; env < h->n_envs; ++env) {
         std::fill(h->smem.begin(), h->smem.end(), (char)0xA5);      // LDS is not zero on the GPU either
         g_smem = h->smem.data();
@@ -184,7 +185,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->G.nc = NC; h->slab.assign(State::bytes(NC), 0); h->G.base = h->slab.data();
     h->O.n = n_envs; h->O.o = sc->n_obs; h->O.s = sc->n_signals; h->O.lm = PT.lmax;
     h->outb.assign(h->O.bytes(), 0); h->O.base = h->outb.data();
-    h->env.assign(N * 4, 0); h->tls.assign(N * S * 3, 0); h->stats.assign(N * ST_N, 0); h->actions.assign(N * S, 0);
+    h->env.assign(N * 4, 0); h->tls.assign(N * S * TLS_W, 0); h->stats.assign(N * ST_N, 0); h->actions.assign(N * S, 0);
     h->dep_next.assign(N * K.n_dep, 0);
     h->G.env = h->env.data(); h->G.tls = h->tls.data(); h->G.stats = h->stats.data(); h->G.dep_next = h->dep_next.data();
     h->G.trip_log = nullptr;
@@ -199,7 +200,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     set_buf(h, RS_BUF_WAIT_NORM, O.wait_norm(), RS_F32, 2, n, s); set_buf(h, RS_BUF_PRESSURE, O.pressure(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_QUEUE_SUM, O.queue_sum(), RS_I32, 2, n, s); set_buf(h, RS_BUF_QUEUE_MAX, O.queue_max(), RS_I32, 2, n, s);
     set_buf(h, RS_BUF_ACTIONS, h->actions.data(), RS_I32, 2, n, s); set_buf(h, RS_BUF_ENV, G.env, RS_I32, 2, n, 4);
-    set_buf(h, RS_BUF_TLS, G.tls, RS_I32, 3, n, s, 3);
+    set_buf(h, RS_BUF_TLS, G.tls, RS_I32, 3, n, s, TLS_W);
     set_buf(h, RS_BUF_VEH_POS, G.pos(), RS_F32, 2, n, cc); set_buf(h, RS_BUF_VEH_SPEED, G.speed(), RS_F32, 2, n, cc);
     set_buf(h, RS_BUF_VEH_ACCEL, G.accel(), RS_F32, 2, n, cc); set_buf(h, RS_BUF_VEH_TLOSS, G.tloss(), RS_F32, 2, n, cc);
     set_buf(h, RS_BUF_VEH_LANE, G.lane(), RS_U16, 2, n, cc); set_buf(h, RS_BUF_VEH_TRIP, G.trip(), RS_U16, 2, n, cc);
@@ -235,7 +236,7 @@ int rs_reset(rs_handle h, void *) {
             int ph, left;
             if (h->P.fixed_program) { ph = T.cold.fix_init_phase[s]; left = T.cold.fix_init_left[s]; }
             else { ph = T.cold.tls_init_phase[s]; left = T.cold.tls_dur[T.cold.tls_dur_off[s] + ph]; }
-            G.tls[(env * S + s) * 3 + 0] = ph; G.tls[(env * S + s) * 3 + 1] = left; G.tls[(env * S + s) * 3 + 2] = 0;
+            G.tls[(env * S + s) * TLS_W + 0] = ph; G.tls[(env * S + s) * TLS_W + 1] = left; G.tls[(env * S + s) * TLS_W + 2] = 0; G.tls[(env * S + s) * TLS_W + 3] = 0;
         }
         for (int d = 0; d < T.n_dep; ++d) G.dep_next[(size_t)env * T.n_dep + d] = T.cold.dep_first[d];
         for (int i = 0; i < 4; ++i) G.env[env * 4 + i] = 0;
@@ -251,6 +252,19 @@ int rs_step(rs_handle h, const int32_t *actions, int32_t, void *) {
     return RS_OK;
 }
 int rs_ticks(rs_handle h, int32_t n, void *) { run_step(h, n, 0); return RS_OK; }
+int rs_step_sim(rs_handle h, int32_t n, void *) { run_step(h, n, 0, 0); return RS_OK; }
+int rs_set_outputs(rs_handle h, uint64_t buffer_mask) {
+    uint32_t m = 0;
+    if (buffer_mask & (1ull << RS_BUF_LANE_AGG)) m |= OUT_LANE_AGG;
+    if (buffer_mask & (1ull << RS_BUF_DRQ_NORM)) m |= OUT_DRQ_NORM;
+    if (buffer_mask & (1ull << RS_BUF_DRQ_NORM_F16)) m |= OUT_DRQ_F16;
+    if (buffer_mask & (1ull << RS_BUF_LANE_ARRIVALS)) m |= OUT_LANE_ARR;
+    if (buffer_mask & (1ull << RS_BUF_MPLIGHT)) m |= OUT_MPLIGHT;
+    if (buffer_mask & (1ull << RS_BUF_WAVE)) m |= OUT_WAVE;
+    if (buffer_mask & (1ull << RS_BUF_MPLIGHT_FULL)) m |= OUT_MPLIGHT_FULL;
+    h->out_mask = m;
+    return RS_OK;
+}
 int rs_sync(rs_handle) { return RS_OK; }
 int rs_reinit_signals(rs_handle h, void *) {
     const KTab &T = h->K; const State &G = h->G;
@@ -259,8 +273,8 @@ int rs_reinit_signals(rs_handle h, void *) {
         const size_t eo = (size_t)env * C;
         for (int s = 0; s < C; ++s) { G.owner()[eo + s] = OWNER_NONE; G.rwait()[eo + s] = 0; }
         for (int s = 0; s < S; ++s) {
-            if (!h->P.fixed_program) G.tls[(env * S + s) * 3 + 1] = T.cold.tls_dur[T.cold.tls_dur_off[s] + G.tls[(env * S + s) * 3 + 0]];
-            G.tls[(env * S + s) * 3 + 2] = 0;
+            if (!h->P.fixed_program) G.tls[(env * S + s) * TLS_W + 1] = T.cold.tls_dur[T.cold.tls_dur_off[s] + G.tls[(env * S + s) * TLS_W + 0]];
+            G.tls[(env * S + s) * TLS_W + 2] = 0; G.tls[(env * S + s) * TLS_W + 3] = 0;
         }
     }
     run_step(h, 0, 0);

@@ -1,5 +1,6 @@
 """GPU (-m gpu): the HIP library through the C ABI vs the CPU oracle (bit-exact) and vs the golden outputs
 of the reference's own Python, plus size-independent properties at the BASELINE sizes."""
+import json
 import os
 import tempfile
 
@@ -306,11 +307,40 @@ def test_trip_log_and_tripinfo_output():
     assert sum(float(t.get('duration')) for t in fin) == ts['sum_duration']
     assert sum(float(t.get('departDelay')) for t in trips) == ts['sum_depart_delay']
     assert all(float(t.get('depart')) >= 25200 for t in trips)
-    # BatchedSim.trip_delay() is utils/readXML.py's episode figure: (timeLoss + departDelay) per tripinfo entry,
-    # plus the trips still queued for insertion, which the reference charges from their scheduled departure
-    total = sum(float(t.get('timeLoss')) + float(t.get('departDelay')) for t in trips) + float(waited)
-    assert abs(delay - total / (len(trips) + int(n_queued))) < 0.02
+    # BatchedSim.trip_delay() is utils/readXML.py's episode figure: (timeLoss + departDelay) per tripinfo entry; the
+    # trips still queued for insertion are charged (delay_all) only for <vehicle> demand files -- cologne1 lists <trip>s
+    total = sum(float(t.get('timeLoss')) + float(t.get('departDelay')) for t in trips)
+    assert abs(delay - total / len(trips)) < 0.02
+    assert abs(env.sim.trip_metrics()['delay_all'][0] - (total + float(waited)) / (len(trips) + int(n_queued))) < 0.02
     env.close()
+
+
+@pytest.mark.parametrize('name', ['cologne1', 'cologne3'])
+def test_trip_metrics_equal_what_the_reference_reads(name):
+    """f-4 closed against its consumer: tests/golden/readxml_<map>.json holds what the reference's unmodified
+    utils/readXML.py:16-77 computed (build container, tests/golden/make_readxml_fixture.py) from a tripinfo_1.xml written by
+    this package's writer for one episode of the hashed random policy; the same episode through the C ABI must give the
+    same per-episode averages from BatchedSim.trip_metrics() -- cologne1 (<trip> demand: 189 trips never get onto the
+    network and readXML leaves them out) and cologne3 (<vehicle> demand: readXML charges them)."""
+    from resco_amd.sim import BatchedSim
+    with open(os.path.join(ROOT, 'tests', 'golden', 'readxml_%s.json' % name)) as f:
+        fx = json.load(f)
+    sc = load_scenario(name)
+    sim = BatchedSim(sc, 2, seed=fx['seed'], max_distance=fx['max_distance'], trip_log=1)
+    for k in range(360):
+        sim.act_random(k)
+        sim.step(None)
+    m = sim.trip_metrics()
+    st = sim.stats()
+    assert int(st['arrived'][0]) == fx['arrived'] and int(st['arrived'][0] + st['active'][0]) == fx['entries']
+    assert int(sim.backlog()[0][0]) == fx['queued_never_departed']
+    # (the XML carries two decimals per entry; on <vehicle> files readXML's never-departed rule -- scheduled later than the
+    #  last vehicle that did depart -- is an approximation of the insertion backlogs this build keeps per lane)
+    tol = 2e-4 if sc.demand_tag == 'trip' else 1e-3
+    assert abs(m['delay'][0] / fx['readXML']['timeLoss'] - 1.0) < tol
+    assert abs(m['duration'][0] / fx['readXML']['duration'] - 1.0) < 1e-6
+    assert abs(m['waiting'][0] / fx['readXML']['waitingTime'] - 1.0) < 1e-6
+    sim.close()
 
 
 def test_full_episode_done_rule_and_metrics_file():
@@ -785,69 +815,124 @@ def test_fused_policy_sampling_mode_follows_the_softmax():
     env.close()
 
 
-# ------------------------------------------------------------------------------------------------ model fidelity band
-# Published delay medians of the reference (resco_benchmark/utils/avg_timeLoss.py:49-51,60-62,83-85 and the rows of the
-# other maps): average trip delay (timeLoss + departDelay, utils/readXML.py) of the static controllers under SUMO.
-# The dynamics here are this build's own model (PARITY-UNPINNED vs SUMO), calibrated against these
-# figures: the band keeps a model change from silently moving them.
-REF_DELAY = {
-    ('cologne1', 'FIXED'): 56.85, ('cologne1', 'MAXWAVE'): 27.94, ('cologne1', 'MAXPRESSURE'): 31.09,
-    ('cologne3', 'FIXED'): 39.04, ('cologne3', 'MAXWAVE'): 21.95, ('cologne3', 'MAXPRESSURE'): 28.05,
-    ('cologne8', 'FIXED'): 64.21, ('cologne8', 'MAXWAVE'): 21.85, ('cologne8', 'MAXPRESSURE'): 29.71,
-    ('ingolstadt1', 'FIXED'): 39.47, ('ingolstadt1', 'MAXWAVE'): 27.99, ('ingolstadt1', 'MAXPRESSURE'): 23.61,
-    ('ingolstadt7', 'FIXED'): 91.45, ('ingolstadt7', 'MAXWAVE'): 80.31, ('ingolstadt7', 'MAXPRESSURE'): 46.41,
-    ('ingolstadt21', 'FIXED'): 130.37, ('ingolstadt21', 'MAXWAVE'): 69.61, ('ingolstadt21', 'MAXPRESSURE'): 115.61,
+# ------------------------------------------------------------------------------------------------ model fidelity bands
+# The reference ships no tests, but it holds measured results of its own SUMO runs: per-episode averages in
+# resco_benchmark/utils/avg_timeLoss.py, avg_duration.py, avg_waitingTime.py, avg_queue.py (produced by utils/readXML.py:16-114
+# and utils/readCSV.py:30-80).  tests/golden/make_ref_bands.py reduces them (build container) to tests/golden/ref_bands.json:
+#   FIXED / MAXWAVE / MAXPRESSURE   delay = median over the published episodes of avg_timeLoss.py (:49-51, 60-62, 83-85, ...)
+#   STOCHASTIC                      delay / duration / waiting / queue of EPISODE 1 of the IDQN rows of the four arrays: epsilon
+#                                   decays linearly from 1 over 80 episodes (agents/pfrl_dqn.py:65-70, main.py:91-92), so episode 1
+#                                   is the uniform random policy seen through IDQN's 200 m detectors
+#   free_flow_residual              duration - delay of the trained IDQN episodes: the travel time of the routes at the speed
+#                                   limits -- independent of the controller, it pins routing, lane lengths and speed limits
+# The dynamics are this build's own model (PARITY-UNPINNED vs SUMO); these are the only reference-held
+# numbers that depend on them.  Default band: +-35 % of the reference figure.  EXCEPT lists every cell that is outside it,
+# with explicit bounds around what this model measures (64 environments, median) and the reason:
+#  * ingolstadt21 FIXED (2.1 x): TLS 243641585 is over-saturated from two sides under its own programme -- 535 trips per hour
+#    turn left from -201201945#0.78 on ONE lane with 20 s of green per 86 s and meet gneJ257 (red for 40 s of 90 s, different
+#    cycle length) 12 m later; 843 per hour arrive on the two lanes of 23166741#5 with 26 s of green.  With the E-left demand
+#    removed the map still runs at 160 s (oracle/fidelity_eval.py what-if): the excess is spread over the network.  Round 2
+#    measured 2.5 x; the occupation rule of model v4 brought it to 2.1 x.
+#  * ingolstadt21 MAXWAVE / MAXPRESSURE (8.4 x / 5.4 x): the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2} maps the
+#    wave of the S approach (S-S + S-E, 843 veh/h) to green phase 0 = 'rGgG', in which that approach is red (phase order = the
+#    tlLogic's file order exactly as multi_signal.py:52-59 extracts it); the wave of the 12 m W approach that would select the
+#    S phase can never exceed the S queue: the greedy policies pick action 0 in 360 of 360 steps and starve S for the whole
+#    episode.  The same test runs them with that one entry remapped to {4: 0, 7: 1, 2: 2} (each pair to a phase that serves
+#    it) and bands THAT against the published medians at the map's FIXED ratio.
+#  * STOCHASTIC on cologne1 / cologne3 / ingolstadt7: the random policy saturates these maps in SUMO (delay > duration: most of
+#    it is insertion backlog, where a few per cent of capacity move the figure by tens of per cent; the reference's own early
+#    episodes spread over 216-379 s on cologne1 and 132-323 s on cologne3).  This model discharges a little more per green.
+#  * cologne3 / cologne8 MAXPRESSURE and cologne3 MAXWAVE are bimodal in the reference itself (means 162 / 48 / 91 s against
+#    medians 28 / 30 / 22 s): medians are compared.
+BAND = (0.65, 1.35)
+EXCEPT = {
+    ('ingolstadt21', 'FIXED', 'delay'): (1.0, 2.4),
+    ('ingolstadt21', 'MAXWAVE', 'delay'): (6.0, 10.0), ('ingolstadt21', 'MAXPRESSURE', 'delay'): (4.0, 6.5),
+    ('ingolstadt21', 'MAXWAVE*', 'delay'): (1.0, 2.6), ('ingolstadt21', 'MAXPRESSURE*', 'delay'): (0.8, 2.4),
+    ('ingolstadt21', 'STOCHASTIC', 'delay'): (0.9, 1.5),
+    ('cologne1', 'STOCHASTIC', 'delay'): (0.5, 1.0), ('cologne1', 'STOCHASTIC', 'duration'): (0.45, 0.9),
+    ('cologne1', 'STOCHASTIC', 'waiting'): (0.35, 0.8), ('cologne1', 'STOCHASTIC', 'queue'): (0.4, 0.8),
+    ('cologne3', 'STOCHASTIC', 'delay'): (0.15, 0.6), ('cologne3', 'STOCHASTIC', 'duration'): (0.2, 0.6),
+    ('cologne3', 'STOCHASTIC', 'waiting'): (0.1, 0.5), ('cologne3', 'STOCHASTIC', 'queue'): (0.3, 0.8),
+    ('ingolstadt7', 'STOCHASTIC', 'delay'): (0.6, 1.0), ('cologne8', 'STOCHASTIC', 'waiting'): (0.6, 1.1),
 }
-BAND = 0.35
-# Known exceptions, with the evidence (DESIGN.md section 2 has the traces):
-#  * ingolstadt21 FIXED: 486 of the 539 trips per hour on -201201945#0.78 turn left at TLS 243641585 on ONE lane and meet
-#    the next signal (gneJ257: red for 40 s of 90 s) 12 m later; the two programmes have different cycle lengths (86 / 90
-#    s), so much of the 20 s of green is lost to a full 12 m edge: 208 vehicles per hour get through, the queue spills
-#    back along the -201201945 corridor (exception 1).  Measured ~2.0-2.5 x the published median;
-#    the test keeps it below 3 x.
-#  * ingolstadt21 MAXWAVE / MAXPRESSURE: the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2} maps the pressure of
-#    the S approach (movements S-S + S-E, 841 veh/h) to green phase 0 = 'rGgG', in which that approach is red (phase
-#    order = the tlLogic's file order, exactly as multi_signal.py:52-59 extracts it): the greedy policies starve it for
-#    the whole episode.  Not a dynamics question; excluded.
-#  * cologne3 / cologne8 MAXPRESSURE and cologne3 MAXWAVE are bimodal in the reference itself (published means 162 / 48 /
-#    91 s against medians 28 / 30 / 22 s: some of its episodes gridlock); the median over the environments is compared.
-#  * ingolstadt7 MAXWAVE: in 15 - 25 % of the environments the episode runs as the reference's does (52 - 87 s against its
-#    80 s); in the others the junction cluster_306484187_... freezes from about step 220 on.  A vehicle that needs an E-N lane
-#    (red) stands at the head of an E-S lane (green) waiting for a gap in the standing queue next to it, so the E-S wave stops
-#    falling; MAXWAVE keeps choosing pair 10 = [N-N, E-S], whose action 1 = 'rrrrrrGGGGrr' serves N-W + E-S but not N-N
-#    (valid_acts {8: 0, 10: 1, 3: 2, 0: 3}), and N-N's saturated wave (12 = all that fits into 50 m) outweighs every other
-#    pair as long as E-S does not discharge (S-S, the only way out, saturates at 4 on its 11.8 m lanes): ~172 s.  In SUMO
-#    the E-S lanes discharge and pair 0 = [S-S, N-N] takes over.  The stuck lane changer is a known gap of the lane-change
-#    model; the test keeps the median below 2.4 x.
-EXCEPT = {('ingolstadt21', 'FIXED'): (1.0, 3.0), ('ingolstadt21', 'MAXWAVE'): None, ('ingolstadt21', 'MAXPRESSURE'): None,
-          ('ingolstadt7', 'MAXWAVE'): (0.65, 2.4)}
+MAXD = {'FIXED': 200, 'MAXWAVE': 50, 'MAXPRESSURE': 200, 'STOCHASTIC': 200}
+
+
+def _ref_bands():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_bands.json')) as f:
+        return json.load(f)
+
+
+def _episode_metrics(sc, policy, n_envs=64, seed=0):
+    """one whole episode of `policy` on the device for n_envs environments: the reference's four per-episode figures"""
+    from resco_amd.sim import BatchedSim
+    sim = BatchedSim(sc, n_envs, seed=seed, max_distance=MAXD[policy.rstrip('*')], fixed_program=1 if policy == 'FIXED' else 0)
+    q = np.zeros(n_envs)
+    for k in range(360):
+        if policy.startswith('MAX'):
+            sim.act_maxwave(1 if policy.startswith('MAXPRESSURE') else 0)
+        elif policy == 'STOCHASTIC':
+            sim.act_random(k)
+        sim.step(None)
+        q += sim.read('queue_sum').sum(axis=1) / (sc.n_signals + 1.0)      # utils/readCSV.py:32-46
+    m = sim.trip_metrics()
+    m['queue'] = q / 360.0
+    sim.close()
+    return m
 
 
 @pytest.mark.parametrize('name', ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'])
-def test_delay_band(name):
-    """64 environments x one whole episode of FIXED / MAXWAVE / MAXPRESSURE on the device: the median average trip delay
-    stays within +-35 % of the reference's published median (known exceptions above)."""
-    from resco_amd.sim import BatchedSim
+def test_reference_result_bands(name):
+    """64 environments x one whole episode of FIXED / MAXWAVE / MAXPRESSURE / STOCHASTIC on the device against every figure the
+    reference holds for them (delay for all four, duration / waitingTime / queue for the random policy, the free-flow
+    residual for the routes): all 24 delay cells and 18 more are asserted, none skipped."""
+    import copy
     sc = load_scenario(name)
-    failures = []
-    for policy in ('FIXED', 'MAXWAVE', 'MAXPRESSURE'):
-        band = EXCEPT.get((name, policy), (1.0 - BAND, 1.0 + BAND))
-        if band is None:
-            continue
-        md = {'FIXED': 200, 'MAXWAVE': 50, 'MAXPRESSURE': 200}[policy]
-        sim = BatchedSim(sc, 64, seed=0, max_distance=md, fixed_program=1 if policy == 'FIXED' else 0)
-        for k in range(360):
-            if policy != 'FIXED':
-                sim.act_maxwave(1 if policy == 'MAXPRESSURE' else 0)
-            sim.step(None)
-        delays = sim.trip_delay()
-        delay = float(np.median(delays))
-        ratio = delay / REF_DELAY[(name, policy)]
-        sim.close()
-        print('delay band %s %s: %.1f s = %.2f x the published %.1f s (all environments: median %.1f, quartiles %.1f / %.1f)'
-              % (name, policy, delay, ratio, REF_DELAY[(name, policy)], np.median(delays), np.percentile(delays, 25), np.percentile(delays, 75)))
+    ref = _ref_bands()[name]
+    failures, lines = [], []
+
+    def check(policy, metric, value, target):
+        band = EXCEPT.get((name, policy, metric), (0.9, 1.1) if metric == 'free_flow' else BAND)
+        ratio = value / target
+        lines.append('band %-12s %-12s %-9s %8.2f / %8.2f = %.2f  [%.2f, %.2f]' % (name, policy, metric, value, target, ratio, band[0], band[1]))
         if not band[0] <= ratio <= band[1]:
-            failures.append('%s %s: delay %.1f s = %.2f x the published %.1f s' % (name, policy, delay, ratio, REF_DELAY[(name, policy)]))
+            failures.append(lines[-1])
+
+    med = {}
+    for policy in ('FIXED', 'MAXWAVE', 'MAXPRESSURE', 'STOCHASTIC'):
+        m = _episode_metrics(sc, policy)
+        med[policy] = {k: float(np.median(v)) for k, v in m.items()}
+        check(policy, 'delay', med[policy]['delay'], ref[policy]['delay'])
+        if policy == 'STOCHASTIC':
+            for metric in ('duration', 'waiting', 'queue'):
+                check(policy, metric, med[policy][metric], ref[policy][metric])
+    if name == 'ingolstadt21':
+        sc2 = copy.copy(sc)
+        sc2.valid_acts = dict(sc.valid_acts)
+        sc2.valid_acts['243641585'] = {4: 0, 7: 1, 2: 2}
+        for policy in ('MAXWAVE*', 'MAXPRESSURE*'):
+            m = _episode_metrics(sc2, policy)
+            med[policy] = {k: float(np.median(v)) for k, v in m.items()}
+            check(policy, 'delay', med[policy]['delay'], ref[policy.rstrip('*')]['delay'])
+    # The travel time of the routes at the speed limits: duration - (timeLoss + departDelay), the reference's figure from
+    # its trained IDQN episodes.  Comparable when (nearly) all trips finish: under the map's best static controller, or --
+    # ingolstadt21, which no static controller keeps fluid -- with every fourth trip only (FIXED programme).  Band +-10 %.
+    if name != 'ingolstadt21':
+        best = min(('MAXWAVE', 'MAXPRESSURE'), key=lambda p: med[p]['delay'])
+        check(best, 'free_flow', med[best]['duration'] - med[best]['delay'], ref['free_flow_residual'])
+    else:
+        sc3 = copy.copy(sc)
+        sc3.arrays = dict(sc.arrays)
+        keep = np.arange(0, sc.n_trips, 4)
+        for f in ('trip_depart', 'trip_route', 'trip_vtype'):
+            sc3.arrays[f] = np.ascontiguousarray(sc.arrays[f][keep])
+        cum = np.zeros(sc.horizon + 1, np.int64)
+        np.add.at(cum, sc3.arrays['trip_depart'][sc3.arrays['trip_depart'] <= sc.horizon], 1)
+        sc3.arrays['trips_cum'] = np.cumsum(cum).astype(np.int32)
+        m = {k: float(np.median(v)) for k, v in _episode_metrics(sc3, 'FIXED').items()}
+        check('FIXED/4', 'free_flow', m['duration'] - m['delay'], ref['free_flow_residual'])
+    print('\n'.join(lines))
     assert not failures, failures
 
 
@@ -872,6 +957,132 @@ def _oracle_replay(sc, seed, env_index, actions, max_distance=200.0):
     for a in actions:
         o.step(a)
     return o
+
+
+def test_step_sim_and_output_mask_on_the_device():
+    """rs_step_sim (simulationStep() only: the Signal objects are not observed, multi_signal.py:102-105) and rs_set_outputs
+    (only the requested per-lane / per-movement buffers are written) through the C ABI against the oracle."""
+    from resco_amd.sim import BatchedSim
+    from oracle.pyoracle import OracleEnv
+    sc = load_scenario('ingolstadt7')
+    n, seed = 3, 6
+    sim = BatchedSim(sc, n, seed=seed)
+    orcs = [OracleEnv(sc, env_index=e, seed=seed, sigma=-1.0, speed_dev=1) for e in range(n)]
+    for o in orcs:
+        o.observe()
+
+    def both(k):
+        sim.act_random(k)
+        sim.step(None)
+        for e, o in enumerate(orcs):
+            o.step(preroll_actions(sc, seed, e, k))
+
+    for k in range(60):
+        both(k)
+    before = sim.outputs(INT_BUFS + FLT_BUFS)
+    sim.step_sim(5)
+    sim.step_sim(6)
+    for o in orcs:
+        for _ in range(11):
+            o.tick()
+    after = sim.outputs(INT_BUFS + FLT_BUFS)
+    for b in INT_BUFS + FLT_BUFS:
+        np.testing.assert_array_equal(before[b], after[b], err_msg=b)
+    both(60)
+    assert_env_equal(sim, orcs, 60)         # waiting times, arrivals and the departures collected over the quiet ticks
+    old = sim.outputs(INT_BUFS + FLT_BUFS)
+    sim.set_outputs(['drq_norm', 'mplight'])
+    for k in range(61, 75):
+        both(k)
+    new = sim.outputs(INT_BUFS + FLT_BUFS)
+    for e, o in enumerate(orcs):
+        ref = o.outputs()
+        for b in ('drq_norm', 'mplight', 'phase', 'wait', 'wait_norm', 'pressure', 'queue_sum', 'queue_max', 'arrivals', 'departures'):
+            np.testing.assert_array_equal(new[b][e], ref[b], err_msg=b)
+    for b in ('lane_agg', 'wave', 'mplight_full'):
+        np.testing.assert_array_equal(new[b], old[b], err_msg=b)
+    sim.set_outputs(None)
+    both(75)
+    assert_env_equal(sim, orcs, 75)
+    sim.close()
+
+
+def test_config2_cologne1_1024_maxpressure_full_episode():
+    """BASELINE config 2 at its size: cologne1 x 1024 environments x 360 env-steps with MaxPressure ON THE DEVICE
+    (rs_act_maxwave(1), agents/maxpressure.py:13-18): invariants for every environment, and three sampled environments
+    replayed on the oracle with the recorded actions -- lane aggregates, rewards.pressure (rewards.py:28-41), rewards.wait
+    and the vehicles bit-identical at the end of the episode and half way through."""
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('cologne1')
+    N, seed, picks = 1024, 2, [0, 511, 1023]
+    sim = BatchedSim(sc, N, seed=seed)
+    rec, mid = [], None
+    for k in range(360):
+        sim.act_maxwave(1)
+        sim.sync()
+        rec.append(sim.read('actions')[picks].copy())
+        sim.step(None)
+        if k in (179, 359):
+            st = _episode_invariants(sim, sc, k)
+        if k == 179:
+            mid = {b: sim.read(b)[picks].copy() for b in ('lane_agg', 'pressure', 'wait', 'mplight')}
+    assert (st['ticks'] == 3600).all() and np.median(st['arrived']) > 1900
+    out = {b: sim.read(b) for b in ('lane_agg', 'mplight', 'pressure', 'wait', 'wait_norm', 'queue_sum', 'veh_pos', 'veh_speed', 'veh_lane')}
+    for j, e in enumerate(picks):
+        o = _oracle_replay(sc, seed, e, [r[j] for r in rec[:180]])
+        for b in ('lane_agg', 'pressure', 'wait', 'mplight'):
+            np.testing.assert_array_equal(mid[b][j], o.outputs()[b])
+        for r in rec[180:]:
+            o.step(r[j])
+        ref, v = o.outputs(), o.vehicles()
+        for b in ('lane_agg', 'mplight', 'pressure', 'wait', 'wait_norm', 'queue_sum'):
+            np.testing.assert_array_equal(out[b][e], ref[b])
+        np.testing.assert_array_equal(out['veh_lane'][e], v['lane'])
+        live = v['lane'] != 0xFFFF
+        np.testing.assert_array_equal(out['veh_pos'][e][live], v['pos'][live])
+        np.testing.assert_array_equal(out['veh_speed'][e][live], v['speed'][live])
+    sim.close()
+
+
+def test_two_handles_two_threads_two_streams_equal_one_batch():
+    """"No global state" (include/resco_sim.h): two handles on ONE device, each driven by its own host thread on its own
+    HIP stream, reproduce the two halves of a single 2N-environment handle bit for bit (the way 8 GPUs are driven from 8
+    threads or processes)."""
+    import threading
+    import torch
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario('cologne8')
+    n, seed, steps = 96, 11, 60
+    whole = BatchedSim(sc, 2 * n, seed=seed)
+    halves = [BatchedSim(sc, n, seed=seed, env_base=0), BatchedSim(sc, n, seed=seed, env_base=n)]
+    for k in range(steps):
+        whole.act_random(k)
+        whole.step(None)
+    whole.sync()
+    errors = []
+
+    def drive(h):
+        try:
+            stream = torch.cuda.Stream()
+            for k in range(steps):
+                h.act_random(k, stream=stream.cuda_stream)
+                h.step(None, stream=stream.cuda_stream)
+            stream.synchronize()
+        except Exception as exc:        # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=drive, args=(h,)) for h in halves]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for b in ('lane_agg', 'mplight', 'pressure', 'wait', 'phase', 'veh_pos', 'veh_speed', 'veh_lane', 'veh_trip', 'stats', 'env'):
+        w = whole.read(b)
+        np.testing.assert_array_equal(w[:n], halves[0].read(b))
+        np.testing.assert_array_equal(w[n:], halves[1].read(b))
+    for h in halves + [whole]:
+        h.close()
 
 
 def test_config4_cologne8_per_gpu_share_full_episode():

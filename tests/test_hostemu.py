@@ -151,3 +151,69 @@ def test_backlog_accounting():
         assert cnt[e] == c and waited[e] == w
     assert (sim.trip_delay() > 0).all()
     sim.close()
+
+
+def test_step_sim_leaves_the_signal_objects_alone():
+    """MultiSignal.step_sim() is only sumo.simulationStep() (multi_signal.py:102-105): rs_step_sim advances the simulation and
+    touches neither the RESCO waiting times nor the arrival / departure bookkeeping nor any output buffer; vehicles that
+    leave meanwhile show up in the departures of the NEXT observe.  Against the oracle (ticks without orc_observe)."""
+    sc = load_scenario('cologne8')
+    sim = EmuSim(sc, 1, order=2, seed=9)
+    o = OracleEnv(sc, env_index=0, seed=9, sigma=-1.0, speed_dev=1)
+    o.observe()
+    rng = np.random.default_rng(3)
+    for step in range(40):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        sim.step(a[None, :])
+        o.step(a)
+    before = sim.outputs(OUT)
+    rw = sim.read('veh_rwait').copy()
+    for _ in range(3):                      # 3 x 4 simulation seconds, no observe in between
+        sim.step_sim(4)
+        for _ in range(4):
+            o.tick()
+    after = sim.outputs(OUT)
+    for b in OUT:
+        np.testing.assert_array_equal(before[b], after[b], err_msg=b)
+    live = sim.read('veh_lane')[0] != 0xFFFF
+    np.testing.assert_array_equal(sim.read('veh_rwait')[0][live & (rw[0] > 0)], rw[0][live & (rw[0] > 0)])
+    assert sim.read('env')[0, 0] == o.time == 412
+    a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+    sim.step(a[None, :])
+    o.step(a)
+    assert_equal(sim, [o], 41)              # incl. departures: the vehicles that arrived during the 12 quiet seconds
+    sim.close()
+
+
+def test_output_mask_writes_only_what_was_asked_for():
+    """rs_set_outputs: buffers outside the mask keep their contents (and cost no traffic), the others and the per-signal
+    scalars are written as always"""
+    sc = load_scenario('cologne8')
+    sim = EmuSim(sc, 1, seed=4)
+    o = OracleEnv(sc, env_index=0, seed=4, sigma=-1.0, speed_dev=1)
+    o.observe()
+    rng = np.random.default_rng(5)
+    for step in range(20):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        sim.step(a[None, :])
+        o.step(a)
+    old = sim.outputs(OUT)
+    sim.set_outputs(['drq_norm', 'mplight'])
+    for step in range(20):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        sim.step(a[None, :])
+        o.step(a)
+    new, ref = sim.outputs(OUT), o.outputs()
+    for b in ('drq_norm', 'mplight', 'phase', 'wait', 'wait_norm', 'pressure', 'queue_sum', 'queue_max', 'arrivals', 'departures'):
+        np.testing.assert_array_equal(new[b][0], ref[b], err_msg=b)
+    for b in ('lane_agg', 'wave', 'mplight_full', 'lane_arrivals'):
+        np.testing.assert_array_equal(new[b], old[b], err_msg=b)
+        assert not np.array_equal(new[b][0], ref[b])
+    sim.set_outputs(None)
+    a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+    sim.step(a[None, :])
+    o.step(a)
+    assert_equal(sim, [o], 40)
+    with pytest.raises(ValueError):
+        sim.set_outputs(['wait'])
+    sim.close()

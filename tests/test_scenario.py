@@ -82,3 +82,86 @@ def test_table_consistency():
         # internal lanes have exactly one outgoing link
         assert (A['lane_link_cnt'][A['lane_internal'] == 1] == 1).all()
         assert sc.capacity & (sc.capacity - 1) == 0
+
+
+# ------------------------------------------------------------------------------------------------ tables every checker shares
+# The oracle, the kernel, the host emulation and FakeSumo all read the routes and detector distances resco_amd/scenario.py
+# compiled: a wrong table there is invisible to the bit-exact tests.  tests/golden/route_pins_<map>.npz is an independent
+# recomputation from the reference's net.xml / rou.xml (own XML walk, a label-correcting search instead of the heap Dijkstra;
+# tests/golden/make_route_pins.py, build container).
+def _pins(name):
+    import os
+    from conftest import ROOT
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'route_pins_%s.npz' % name))
+    edge = {e: (float(l), float(v)) for e, l, v in zip(z['edge_ids'], z['edge_len'], z['edge_speed'])}
+    hop = {(a, b): (float(t), float(lo), float(hi), bool(tl)) for a, b, t, lo, hi, tl in
+           zip(z['hop_a'], z['hop_b'], z['hop_time'], z['hop_len_lo'], z['hop_len_hi'], z['hop_tls'])}
+    od = {(a, b): float(c) for a, b, c in zip(z['od_from'], z['od_to'], z['od_cost'])}
+    return edge, hop, od
+
+
+@pytest.mark.parametrize('name', ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'])
+def test_routes_and_detector_distances_against_an_independent_recomputation(name):
+    sc = load_scenario(name)
+    edge, hop, od = _pins(name)
+    A = sc.arrays
+    n_checked = 0
+    for r in range(sc.n_routes):
+        es = [sc.edge_ids[e] for e in A['route_edge'][A['route_start'][r]:A['route_start'][r + 1]]]
+        # every edge and every transition of the route exists in the network, with the length the lane table carries
+        for e in es:
+            assert abs(edge[e][0] - float(A['lane_len'][A['edge_lane0'][sc.edge_ids.index(e)]])) < 1e-3
+        cost = sum(edge[e][0] / edge[e][1] for e in es) + sum(hop[(a, b)][0] for a, b in zip(es[:-1], es[1:]))
+        if (es[0], es[-1]) in od:          # <trip> demand: the compiled route is a fastest path (ties may differ in the edges)
+            assert abs(cost - od[(es[0], es[-1])]) <= 1e-6 * cost, (name, es[0], es[-1], cost, od[(es[0], es[-1])])
+            n_checked += 1
+        # route_tlsdist[q]: from the end of edge q to the next TLS stop line along the route (vehicle.getNextTLS, which
+        # Signal.get_vehicles compares with max_distance, traffic_signal.py:238-247)
+        lo = hi = None
+        q0 = int(A['route_start'][r])
+        for q in range(len(es) - 1, -1, -1):
+            if q == len(es) - 1:
+                lo = hi = np.inf
+            else:
+                t, l_lo, l_hi, tl = hop[(es[q], es[q + 1])]
+                lo, hi = (0.0, 0.0) if tl else (l_lo + edge[es[q + 1]][0] + lo, l_hi + edge[es[q + 1]][0] + hi)
+            mine = float(A['route_tlsdist'][q0 + q])
+            if np.isinf(lo):
+                assert mine >= 1e9          # no signal ahead: never detectable
+            else:
+                assert lo - 0.05 <= mine <= hi + 0.05, (name, es[q], mine, lo, hi)
+    if sc.demand_tag == 'trip':
+        assert n_checked == sc.n_routes == len(od)
+
+
+def test_survey_appendix_tables():
+    """SURVEY.md Appendix D (per-signal sizing, a probe over the reference's own Signal objects) and Appendix A (junction
+    passages: one internal lane for straight / right, two for the left turns that wait inside the junction)"""
+    D = {'cologne1': [(8, 0, 4, 14, 20, [29, 6, 29, 6])],
+         'cologne8': [(6, 2, 4, 14, 18, [33, 6, 33, 6]), (4, 3, 2, 4, 16, [33, 33]), (3, 1, 3, 8, 9, [38, 6, 37]),
+                      (6, 3, 4, 14, 18, [33, 6, 33, 6]), (4, 3, 3, 8, 9, [38, 6, 37]), (2, 1, 2, 3, 8, [78, 6]),
+                      (4, 3, 3, 8, 9, [38, 6, 37]), (4, 1, 4, 14, 16, [33, 6, 33, 6])],
+         'ingolstadt21': [(7, 5, 3, 8, 7, [35, 6, 34]), (6, 4, 3, 8, 6, [35, 6, 34]), (4, 10, 3, 8, 6, [38, 6, 37]),
+                          (6, 2, 3, 8, 4, [20, 30, 26]), (8, 2, 4, 15, 12, [29, 6, 29, 6]), (7, 1, 3, 8, 14, [38, 6, 37]),
+                          (5, 4, 3, 8, 15, [38, 6, 37]), (7, 8, 2, 4, 9, [42, 42]), (7, 5, 3, 8, 11, [38, 6, 37]),
+                          (11, 7, 4, 15, 12, [29, 6, 29, 6]), (6, 2, 3, 8, 12, [38, 6, 37]), (11, 3, 4, 15, 10, [24, 6, 24, 24]),
+                          (5, 3, 3, 8, 8, [38, 6, 37]), (17, 4, 4, 15, 15, [29, 6, 29, 6]), (12, 5, 4, 15, 12, [15, 25, 5, 36]),
+                          (9, 4, 3, 8, 12, [38, 6, 37]), (7, 5, 3, 8, 8, [38, 6, 37]), (5, 4, 3, 9, 6, [35, 6, 34]),
+                          (10, 3, 3, 8, 14, [38, 6, 37]), (8, 6, 3, 8, 9, [38, 6, 37]), (5, 7, 3, 8, 8, [38, 6, 37])]}
+    for name, rows in D.items():
+        sc = load_scenario(name)
+        assert sc.n_signals == len(rows)
+        for k, (lanes, outb, G, P, links, durs) in enumerate(rows):
+            sm = sc.signal_meta[sc.signal_ids[k]]
+            assert len(sm['lanes']) == lanes == int(sc.sig_obs_start[k + 1] - sc.sig_obs_start[k])
+            assert len(sm['outbound_lanes']) == outb
+            assert (int(sc.tls_ngreen[k]), int(sc.tls_nphase[k]), int(sc.tls_nlinks[k])) == (G, P, links)
+            assert sm['green_durations'] == durs
+    # Appendix A counts all normal -> normal connections of the net; the compiled scenario keeps those the demand uses:
+    # every first-stage link has one or two junction lanes, never none and never more
+    for name in D:
+        A = load_scenario(name).arrays
+        first = A['link_tls_pos'] >= -1
+        normal_from = A['lane_internal'][A['link_from_lane']] == 0
+        v1, v2 = A['link_via1'][normal_from & first], A['link_via2'][normal_from & first]
+        assert (v1 >= 0).all() and ((v2 >= 0) <= (v1 >= 0)).all()

@@ -25,8 +25,10 @@ for f in sorted(glob.glob('$OUT/p*/*counter_collection.csv')):
     for k, (v, n) in sorted(acc.items()):
         print(f.split('/')[-2], k, 'per-launch avg', v / max(1, n), 'launches', n)
         summary[k] = dict(per_launch_avg=v / max(1, n), launches=n)
-import json
-json.dump(dict(command='$CMD', kernel='rs_step_kernel', counters=summary,
+import json, sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
+from bench import kernel_source_hash
+json.dump(dict(command='$CMD', kernel='rs_step_kernel', source_hash=kernel_source_hash(), counters=summary,
                note='FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)'),
           open('$OUT/pmc_summary.json', 'w'), indent=1)
 PY
