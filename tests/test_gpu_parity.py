@@ -298,6 +298,7 @@ def test_trip_log_and_tripinfo_output():
     ts = env.trip_stats()
     (n_queued,), (waited,) = env.sim.backlog()
     delay = env.sim.trip_delay()[0]
+    delay_all = env.sim.trip_metrics()['delay_all'][0]
     env.reset()                                   # closes episode 1: writes metrics_1.csv and tripinfo_1.xml
     root = ET.parse(os.path.join(tmp, env.connection_name, 'tripinfo_1.xml')).getroot()
     trips = list(root)
@@ -311,7 +312,7 @@ def test_trip_log_and_tripinfo_output():
     # trips still queued for insertion are charged (delay_all) only for <vehicle> demand files -- cologne1 lists <trip>s
     total = sum(float(t.get('timeLoss')) + float(t.get('departDelay')) for t in trips)
     assert abs(delay - total / len(trips)) < 0.02
-    assert abs(env.sim.trip_metrics()['delay_all'][0] - (total + float(waited)) / (len(trips) + int(n_queued))) < 0.02
+    assert abs(delay_all - (total + float(waited)) / (len(trips) + int(n_queued))) < 0.02
     env.close()
 
 
