@@ -146,6 +146,37 @@ def run_timed(sim, steps, warmup, barrier, sync, reduce_max):
     return elapsed, kernel_ms, launches, st0, st1
 
 
+def bind_to_gpu_numa_node(local_rank):
+    """N > 1: every rank is one host thread issuing ~2 launches per 0.1-2 ms; pin it to the cores of the NUMA node its GPU hangs
+    off (sysfs), so that 8 ranks do not migrate across sockets.  Best effort: returns the node or None."""
+    try:
+        import glob
+        import torch
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), 'pci_bus_id') else None
+        node = None
+        for dev in glob.glob('/sys/class/drm/card*/device'):
+            real = os.path.realpath(dev)
+            if bus is not None and ('%02x:' % bus) not in os.path.basename(real):
+                continue
+            n = int(open(os.path.join(real, 'numa_node')).read())
+            if n >= 0:
+                node = n
+                break
+        if node is None:
+            return None
+        cpus = []
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            a, _, b = part.partition('-')
+            cpus += list(range(int(a), int(b or a) + 1))
+        cpus = sorted(set(cpus) & os.sched_getaffinity(0))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        pass
+    return None
+
+
 def effective_cores():
     """host cores this process may really use: affinity mask, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -223,6 +254,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     torch.cuda.set_device(local)
+    numa = bind_to_gpu_numa_node(local) if world > 1 else None
     dist = None
     if world > 1 or os.environ.get('RESCO_BENCH_FORCE_DIST') == '1':      # the env var exercises the RCCL path at N=1
         import torch.distributed as dist
@@ -277,7 +309,8 @@ def main():
                    'episode_window': [w0, w0 + args.steps], 'untimed_fast_forward_steps': w0 - args.warmup,
                    'block_threads': info['block_threads'], 'lds_bytes_per_env': info['lds_bytes'],
                    'outputs_per_step': list(OUTPUTS) + ['wait', 'wait_norm', 'pressure', 'phase', 'queue_sum', 'queue_max', 'arrivals', 'departures'],
-                   'parallelism': 'env-batch split x%d, no collective on the data path' % world},
+                   'parallelism': 'env-batch split x%d, no collective on the data path' % world,
+                   'rank0_numa_node': numa},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'traffic_note': traffic_note,

@@ -8,7 +8,10 @@ SRC = os.path.join(HERE, 'csrc', 'resco_sim.hip')
 LIB = os.path.join(HERE, 'csrc', 'libresco_sim.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: fp32 results must equal the CPU oracle bit-for-bit (no FMA fusion)
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+# -disable-machine-licm: the step kernel's tick loop is long and register-starved (80 VGPRs for three workgroups per CU); with
+#   machine LICM every 32-bit literal of the loop body is hoisted into a VGPR of its own and five values end up in scratch,
+#   written per thread and tick: 110 MB of HBM writes per launch at 4096 environments and 2.5 % of the time (profiles/r03_*)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-mllvm', '-disable-machine-licm', '-fPIC', '-shared',
          '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(HERE, 'csrc')]
 
 

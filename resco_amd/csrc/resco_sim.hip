@@ -98,6 +98,8 @@ struct DevExec {
             t0 = t1;
         }
     }
+    // tid / 64 as a wave-uniform value: what is derived from it (the roles of the waves inside a phase) stays in scalar registers
+    __device__ __forceinline__ int wave_of(int tid) const { return __builtin_amdgcn_readfirstlane(tid >> 6); }
     // time a wave spends in one role of a phase: sum of the 100 MHz ticks in the low 40 bits, number of waves above
     __device__ __forceinline__ unsigned long long role_begin() const { return prof ? wall_clock64() : 0ull; }
     __device__ __forceinline__ void role_end(int id, unsigned long long start) const {

@@ -6,6 +6,7 @@
 //                           the phase for the optional per-phase timers: 0-2 load, 4 plan, 5 check, 6 move, 11-14 observe)
 //   ex.role_begin/role_end  optional timers of what one WAVE does inside a phase (ids 3, 7-10, 15)
 //   ex.B                    threads per workgroup (a multiple of 64)
+//   ex.wave_of(tid)         tid / 64, known to be the same for the 64 threads of a wave (a scalar on the GPU)
 // On the GPU (resco_sim.hip) one workgroup = one environment; the state lives in LDS for the whole env-step and phase() is
 // `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same source for the host (tests/hostemu), where
 // phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never reads what another thread writes in the same
@@ -1059,7 +1060,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         // one after the other adds up on the critical path of the phase): the first waves take the lists of the vehicles with
         // the long code paths, the others share the slots on the short path.
         ex.phase(4, [&](int tid) {
-            const int wv = tid >> 6, ln = tid & 63;
+            const int wv = ex.wave_of(tid), ln = tid & 63;          // (the wave index is wave-uniform: the role variables stay scalar)
             const int nh = L.sc[SC_NH], nlc = L.sc[SC_NLC];
             int hwv = (nh + 63) >> 6, lwv = (nlc + 63) >> 6;            // waves for the look-ahead list, the lane-change list
             // a list overflowed, or the lists leave no wave for the slots: every thread handles its slots in full, in two passes
@@ -1111,7 +1112,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             int active = 0, halted = 0, top = 0;
             // the first waves take the list of the vehicles that leave their lane, the last one the insertions (when there are
             // any), the others share the slots
-            const int wv = tid >> 6, ln = tid & 63;
+            const int wv = ex.wave_of(tid), ln = tid & 63;
             const int nmh = L.sc[SC_NMH + (t & 1)];
             int mwv = (nmh + 63) >> 6, iwv = 0;
             for (int i = 0; i < (T.n_dep + 31) / 32; ++i) if (L.insm[i]) iwv = 1;

@@ -73,6 +73,7 @@ static long rs_dbg_chain = 0;         // chain-walk steps of the current phase (
 struct HostExec {
     unsigned long long role_begin() const { return 0ull; }
     void role_end(int, unsigned long long) const {}
+    int wave_of(int tid) const { return tid >> 6; }
     int B;
     int order;          // 0 ascending, 1 descending, 2 shuffled (a different permutation in every phase)
     uint32_t rng = 12345u;
