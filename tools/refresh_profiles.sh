@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the measured evidence of the current build on the MI355X box (run through gpurun); outputs land in
-# gpurun_out/$TAG/ and are copied into profiles/ (named per round) by hand afterwards.
-#   gpurun --timeout 1200 -- 'TAG=r02 bash tools/refresh_profiles.sh'
+# gpurun_out/$TAG/ and are copied into profiles/ (named per round) afterwards (tools/collect_profiles.py).
+#   gpurun --timeout 1500 -- 'TAG=r03 bash tools/refresh_profiles.sh'
 set -u
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-final}
@@ -10,14 +10,21 @@ mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench_default.log 2>/dev/null
 tail -1 $OUT/bench_default.log > $OUT/bench_default.json
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_window.log 2>/dev/null
+tail -1 $OUT/bench_driver_window.log > $OUT/bench_driver_window.json
 python tools/phase_profile.py ingolstadt21 4096 0 > $OUT/phase_profile.txt 2>/dev/null
 python tools/phase_profile.py ingolstadt21 256 0 > $OUT/phase_profile_one_workgroup_per_cu.txt 2>/dev/null
+python tools/graph_ab.py > $OUT/graph_ab.jsonl 2>/dev/null
+python tools/bench_configs.py > $OUT/bench_configs.jsonl 2>/dev/null
+python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_reference_result_bands -s 2>&1 | grep "^band\|passed\|failed" > $OUT/reference_bands.txt
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the contract line (default --steps / --warmup), CPU baseline off: per-kernel time by rocprofv3
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
 grep '^{"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
-cd $R && bash tools/pmc_passes.sh $TAG/pmc 300 60 > $OUT/pmc_passes.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_dw -o ${TAG}_dw -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_dw_under_rocprof.log 2>&1
+cd $R && bash tools/pmc_passes.sh $TAG/pmc_s300_w60 300 60 > $OUT/pmc_passes_s300_w60.log 2>&1
+bash tools/pmc_passes.sh $TAG/pmc_s20_w5 20 5 > $OUT/pmc_passes_s20_w5.log 2>&1
 [ "${DIAG:-1}" = 1 ] && bash tools/pmc_diag.sh $TAG/pmcdiag > $OUT/pmc_diag.log 2>&1
 head -5 $OUT/prof/${TAG}_kernel_stats.csv
-tail -3 $OUT/pmc_passes.log
+tail -3 $OUT/pmc_passes_s300_w60.log
 cut -c1-300 $OUT/bench_default.json
