@@ -16,7 +16,7 @@ python tools/phase_profile.py ingolstadt21 4096 0 > $OUT/phase_profile.txt 2>/de
 python tools/phase_profile.py ingolstadt21 256 0 > $OUT/phase_profile_one_workgroup_per_cu.txt 2>/dev/null
 python tools/graph_ab.py > $OUT/graph_ab.jsonl 2>/dev/null
 python tools/bench_configs.py > $OUT/bench_configs.jsonl 2>/dev/null
-python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_reference_result_bands -s 2>&1 | grep "^band\|passed\|failed" > $OUT/reference_bands.txt
+python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_reference_result_bands -s 2>&1 | grep -o "band .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/reference_bands.txt
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the contract line (default --steps / --warmup), CPU baseline off: per-kernel time by rocprofv3
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
