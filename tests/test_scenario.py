@@ -165,3 +165,60 @@ def test_survey_appendix_tables():
         normal_from = A['lane_internal'][A['link_from_lane']] == 0
         v1, v2 = A['link_via1'][normal_from & first], A['link_via2'][normal_from & first]
         assert (v1 >= 0).all() and ((v2 >= 0) <= (v1 >= 0)).all()
+
+
+@pytest.mark.parametrize('name', ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'])
+def test_junction_tables_against_an_independent_recomputation(name):
+    """tests/golden/junction_pins_<map>.json.gz (tests/golden/make_junction_pins.py, build container, own reading of net.xml):
+    every link of the compiled scenario that leaves a normal lane has the traffic light, link index, minor / cont flags and the
+    prohibitors (<request response>) of its <connection>; route_cont equals the lane-level recursion over the connections."""
+    import gzip
+    import json
+    import os
+    from conftest import ROOT
+    with gzip.open(os.path.join(ROOT, 'tests', 'golden', 'junction_pins_%s.json.gz' % name), 'rt') as f:
+        pins = json.load(f)
+    sc = load_scenario(name)
+    A = sc.arrays
+    lid = sc.lane_ids
+
+    def key(k):
+        return '%s>%s' % (lid[int(A['link_from_lane'][k])], lid[int(A['link_dest_lane'][k])])
+
+    n_first = 0
+    for k in range(sc.n_links):
+        if A['lane_internal'][A['link_from_lane'][k]]:
+            continue
+        n_first += 1
+        ref = pins['links'][key(k)]
+        tls = int(A['link_tls'][k])
+        assert (sc.signal_ids[tls] if tls >= 0 else None) == (ref['tl'] if ref['tl'] in sc.signal_ids else None)
+        if tls >= 0:
+            assert int(A['link_tls_pos'][k]) == ref['idx']
+        assert int(A['link_minor'][k]) == ref['minor'] and int(A['link_cont'][k]) == ref['cont']
+        assert (int(A['link_via1'][k]) >= 0) + (int(A['link_via2'][k]) >= 0) == min(ref['n_via'], 2)
+        mine = sorted(key(int(f)) for f in A['foe_link'][A['link_foe_start'][k]:A['link_foe_start'][k] + A['link_foe_cnt'][k]])
+        # the scenario keeps only the connections the demand uses: prohibitors nobody ever drives are dropped
+        assert mine == [f for f in ref['foes'] if f in used_keys(sc)], (key(k), mine, ref['foes'])
+    assert n_first > 0
+    # continuation lengths
+    cont = A['route_cont']
+    for r in range(sc.n_routes):
+        q0 = int(A['route_start'][r])
+        for c, row in enumerate(pins['cont'][r]):
+            e = int(A['route_edge'][q0 + c])
+            for kk in range(int(A['edge_nlanes'][e])):
+                want = row[lid[int(A['edge_lane0'][e]) + kk]]
+                got = float(cont[q0 + c, kk])
+                assert abs(min(got, 1e6) - min(want, 1e6)) <= 1e-3 * max(1.0, min(want, 1e6)), (name, r, c, kk, got, want)
+
+
+_USED = {}
+
+
+def used_keys(sc):
+    if sc.name not in _USED:
+        A = sc.arrays
+        _USED[sc.name] = {'%s>%s' % (sc.lane_ids[int(A['link_from_lane'][k])], sc.lane_ids[int(A['link_dest_lane'][k])])
+                          for k in range(sc.n_links) if not A['lane_internal'][A['link_from_lane'][k]]}
+    return _USED[sc.name]
