@@ -183,13 +183,17 @@ def sumo_baseline(map_name, budget_s=20.0):
                        % (cores, budget_s, map_name, kind))
 
 
-def diff_vs_sumo(map_name, steps=60, seed=0):
-    """phase indices and per-lane vehicle counts: SUMO (sigma 0, speedDev 0) vs rs_step (parity mode), same action script"""
+def diff_vs_sumo(map_name, steps=60, seed=0, sim_cls=None):
+    """phase indices and per-lane vehicle counts: SUMO (sigma 0, speedDev 0) vs rs_step (parity mode), same action script.
+    sim_cls: the simulator class to put next to SUMO (default BatchedSim = the HIP library; the CPU test of this runner passes
+    the host emulation of the kernel and a stand-in for libsumo, tests/test_sumo_runner.py)"""
     import numpy as np
-    from resco_amd.sim import BatchedSim
+    if sim_cls is None:
+        from resco_amd.sim import BatchedSim as sim_cls
     loop = SumoLoop(map_name, seed=seed, deterministic=True)
     sc = loop.sc
-    sim = BatchedSim(sc, 1, seed=seed, sigma=0.0, speed_dev=0, max_distance=1.0e9)
+    sim = sim_cls(sc, 1, seed=seed, sigma=0.0, speed_dev=0, max_distance=1.0e9)
+    obs_lane = np.asarray(sc.obs_lane)
     rng = np.random.default_rng(seed)
     phase_equal, count_equal, count_abs, n_cmp = 0, 0, 0.0, 0
     rows = []
@@ -199,8 +203,9 @@ def diff_vs_sumo(map_name, steps=60, seed=0):
         sim.step(np.asarray([acts], np.int32))
         ph_s, cnt_s = loop.observe()
         ph_g = sim.read('phase')[0].tolist()
-        agg = sim.read('lane_agg')[0]
-        cnt_g = (agg[:, 0] + agg[:, 1]).astype(int).tolist()            # queue + approach = vehicles on the lane
+        lanes_now = sim.read('veh_lane')[0]
+        per_lane = np.bincount(lanes_now[lanes_now != 0xFFFF].astype(np.int64), minlength=sc.n_lanes)
+        cnt_g = [int(per_lane[l]) if l >= 0 else -1 for l in obs_lane]   # lane.getLastStepVehicleNumber of every configured lane
         phase_equal += int(ph_s == ph_g)
         valid = [i for i, c_ in enumerate(cnt_s) if c_ >= 0]
         count_equal += sum(1 for i in valid if cnt_s[i] == cnt_g[i])
