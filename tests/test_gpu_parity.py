@@ -1008,6 +1008,66 @@ def test_step_sim_and_output_mask_on_the_device():
     sim.close()
 
 
+def test_edge_cases_capacity_invalid_actions_and_create_errors():
+    """Through the C ABI: (1) the network full -- due trips wait in their lane's backlog, never dropped, bit-identical to the
+    oracle; (2) action entries that are no phase index leave the signal alone; actions as a HOST array, a DEVICE tensor and the
+    staged buffer give the same step; (3) rs_create refuses what it cannot run and says why."""
+    import copy
+    import torch
+    from resco_amd.sim import BatchedSim
+    from oracle.pyoracle import OracleEnv
+    sc = copy.copy(load_scenario('cologne1'))
+    sc.capacity = 64
+    sim = BatchedSim(sc, 2, seed=1)
+    orcs = [OracleEnv(sc, env_index=e, seed=1, sigma=-1.0, speed_dev=1) for e in range(2)]
+    for o in orcs:
+        o.observe()
+    a = np.zeros((2, sc.n_signals), np.int32)
+    for k in range(150):
+        sim.step(a)
+        for o in orcs:
+            o.step(a[0])
+    st = sim.stats()
+    assert (st['active'] <= 64).all() and (st['pending'] > 0).all()
+    assert_env_equal(sim, orcs, 149)
+    sim.close()
+
+    sc = load_scenario('cologne8')
+    sims = [BatchedSim(sc, 2, seed=2) for _ in range(3)]
+    orcs = [OracleEnv(sc, env_index=e, seed=2, sigma=-1.0, speed_dev=1) for e in range(2)]
+    for o in orcs:
+        o.observe()
+    rng = np.random.default_rng(7)
+    for k in range(24):
+        a = np.stack([rng.integers(0, sc.tls_ngreen) for _ in range(2)]).astype(np.int32)
+        if k % 3 == 1:
+            a[0, k % sc.n_signals] = -1
+        if k % 3 == 2:
+            a[1, (k * 5) % sc.n_signals] = 99
+        sims[0].step(a)                                                     # host array
+        sims[1].step(torch.as_tensor(a, device='cuda'))                     # device tensor
+        sims[2].tensor('actions').copy_(torch.as_tensor(a))                 # staged in RS_BUF_ACTIONS
+        torch.cuda.synchronize()
+        sims[2].step(None)
+        for e, o in enumerate(orcs):
+            o.step(a[e])
+    for s_ in sims:
+        assert_env_equal(s_, orcs, 23)
+        s_.close()
+
+    for kw, frag in ((dict(block_threads=100), 'multiple of 64'), (dict(block_threads=-1024), '128-VGPR'), (dict(device=99), 'hipSetDevice')):
+        with pytest.raises(RuntimeError) as ei:
+            BatchedSim(sc, 1, **kw)
+        assert frag in str(ei.value), str(ei.value)
+    bad = copy.copy(sc)
+    bad.capacity = 100
+    with pytest.raises(RuntimeError) as ei:
+        BatchedSim(bad, 1)
+    assert 'capacity' in str(ei.value)
+    with pytest.raises(ValueError):
+        BatchedSim(sc, 1, yellow_length=5)                                   # the yellow phases are compiled for 3 s
+
+
 def test_config2_cologne1_1024_maxpressure_full_episode():
     """BASELINE config 2 at its size: cologne1 x 1024 environments x 360 env-steps with MaxPressure ON THE DEVICE
     (rs_act_maxwave(1), agents/maxpressure.py:13-18): invariants for every environment, and three sampled environments

@@ -217,3 +217,47 @@ def test_output_mask_writes_only_what_was_asked_for():
     with pytest.raises(ValueError):
         sim.set_outputs(['wait'])
     sim.close()
+
+
+def test_capacity_exhausted_trips_wait_in_their_backlog():
+    """The slot capacity is a hard limit of the working memory: when the network holds `capacity` vehicles the due trips stay in
+    their lane's backlog (stats['pending']) and enter as slots become free, lower lane first -- never dropped, and identically
+    in the kernel and the oracle."""
+    import copy
+    sc = copy.copy(load_scenario('cologne1'))
+    sc.capacity = 64                                    # a quarter of what the jammed map needs
+    sim = EmuSim(sc, 1, order=2, seed=1)
+    o = OracleEnv(sc, env_index=0, seed=1, sigma=-1.0, speed_dev=1)
+    o.observe()
+    full = 0
+    for step in range(150):
+        a = np.zeros(sc.n_signals, np.int32)            # one phase for ever: the other approaches jam
+        sim.step(a[None, :])
+        o.step(a)
+        st = sim.stats()
+        assert st['active'][0] <= 64
+        full += int(st['active'][0] == 64 and st['pending'][0] > 0)
+    assert full > 20                                     # the limit was really hit, with trips waiting
+    assert_equal(sim, [o], 149)
+    assert sim.stats()['pending'][0] == o.stats()['pending'] > 0
+    sim.close()
+
+
+def test_out_of_range_actions_keep_the_current_phase():
+    """An action that is not a phase index of the signal leaves it alone (the reference would raise inside TraCI; the batched
+    ABI must not fault on a bad entry of an [N, S] array): kernel == oracle, and the signal's phase does not change."""
+    sc = load_scenario('cologne8')
+    sim = EmuSim(sc, 1, seed=2)
+    o = OracleEnv(sc, env_index=0, seed=2, sigma=-1.0, speed_dev=1)
+    o.observe()
+    rng = np.random.default_rng(7)
+    for step in range(30):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        if step % 3 == 1:
+            a[step % sc.n_signals] = -1
+        if step % 3 == 2:
+            a[(step * 5) % sc.n_signals] = 99
+        sim.step(a[None, :])
+        o.step(a)
+        assert_equal(sim, [o], step)
+    sim.close()
