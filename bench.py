@@ -148,33 +148,28 @@ def run_timed(sim, steps, warmup, barrier, sync, reduce_max):
 
 def bind_to_gpu_numa_node(local_rank):
     """N > 1: every rank is one host thread issuing ~2 launches per 0.1-2 ms; pin it to the cores of the NUMA node its GPU hangs
-    off (sysfs), so that 8 ranks do not migrate across sockets.  Best effort: returns the node or None."""
+    off (PCI address from the HIP runtime -> sysfs), so that 8 ranks do not migrate across sockets.  Best effort and
+    conservative: without a PCI address, a NUMA node or usable cores nothing is changed.  Returns the node or None."""
     try:
-        import glob
         import torch
-        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), 'pci_bus_id') else None
-        node = None
-        for dev in glob.glob('/sys/class/drm/card*/device'):
-            real = os.path.realpath(dev)
-            if bus is not None and ('%02x:' % bus) not in os.path.basename(real):
-                continue
-            n = int(open(os.path.join(real, 'numa_node')).read())
-            if n >= 0:
-                node = n
-                break
-        if node is None:
+        prop = torch.cuda.get_device_properties(local_rank)
+        if not all(hasattr(prop, a) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')):
+            return None
+        dev = '/sys/bus/pci/devices/%04x:%02x:%02x.0' % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id)
+        node = int(open(os.path.join(dev, 'numa_node')).read())
+        if node < 0:
             return None
         cpus = []
         for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
             a, _, b = part.partition('-')
             cpus += list(range(int(a), int(b or a) + 1))
         cpus = sorted(set(cpus) & os.sched_getaffinity(0))
-        if cpus:
-            os.sched_setaffinity(0, cpus)
-            return node
+        if len(cpus) < 2:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
     except Exception:
-        pass
-    return None
+        return None
 
 
 def effective_cores():

@@ -1217,6 +1217,20 @@ def test_config5_ingolstadt21_idqn_rollout_full_episode():
     sim.close()
 
 
+def test_numa_binding_of_a_rank_is_harmless():
+    """bench.py pins every rank of an N > 1 run to the NUMA node of its GPU: on whatever box this runs the call must either
+    bind to a non-empty subset of the allowed cores or change nothing"""
+    import bench
+    before = os.sched_getaffinity(0)
+    try:
+        node = bench.bind_to_gpu_numa_node(0)
+        after = os.sched_getaffinity(0)
+        assert after and after <= before
+        assert (node is None and after == before) or (node is not None and len(after) >= 2)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_bench_runs_through_rccl_at_one_gpu():
     """bench.py with RESCO_BENCH_FORCE_DIST=1: the N > 1 code path (process group on RCCL, barrier, MAX all-reduce) on one GPU"""
     import json
