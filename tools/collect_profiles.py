@@ -25,7 +25,7 @@ for a, b in (('bench_default.json', 'bench_default.json'), ('bench_driver_window
              ('bench_under_rocprof.json', 'bench_under_rocprof.json'), ('phase_profile.txt', 'phase_profile.txt'),
              ('phase_profile_one_workgroup_per_cu.txt', 'phase_profile_one_workgroup_per_cu.txt'),
              ('graph_ab.jsonl', 'graph_ab.jsonl'), ('bench_configs.jsonl', 'bench_configs.jsonl'),
-             ('reference_bands.txt', 'reference_bands.txt'), ('prof/%s_kernel_stats.csv' % tag, 'kernel_stats.csv'),
+             ('reference_bands.txt', 'reference_bands.txt'), ('idqn_rollout.jsonl', 'idqn_rollout.jsonl'), ('prof/%s_kernel_stats.csv' % tag, 'kernel_stats.csv'),
              ('prof_dw/%s_dw_kernel_stats.csv' % tag, 'driver_window_kernel_stats.csv'),
              ('pmc_s300_w60/pmc_summary.json', 'pmc_s300_w60.json'), ('pmc_s20_w5/pmc_summary.json', 'pmc_s20_w5.json'),
              ('pmcdiag/diag_summary.json', 'pmc_diag.json')):

@@ -16,6 +16,7 @@ python tools/phase_profile.py ingolstadt21 4096 0 > $OUT/phase_profile.txt 2>/de
 python tools/phase_profile.py ingolstadt21 256 0 > $OUT/phase_profile_one_workgroup_per_cu.txt 2>/dev/null
 python tools/graph_ab.py > $OUT/graph_ab.jsonl 2>/dev/null
 python tools/bench_configs.py > $OUT/bench_configs.jsonl 2>/dev/null
+(python tools/idqn_rollout.py 1024; python tools/idqn_rollout.py 4096) 2>/dev/null | grep '^{' > $OUT/idqn_rollout.jsonl
 python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_reference_result_bands -s 2>&1 | grep -o "band .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/reference_bands.txt
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the contract line (default --steps / --warmup), CPU baseline off: per-kernel time by rocprofv3
