@@ -244,6 +244,7 @@ static thread_local std::string g_create_err;
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            (void)hipGetLastError();    /* the error is reported here: do not leave it for the next hipGetLastError() */ \
             return RS_EHIP;                                                                        \
         }                                                                                          \
     } while (0)
@@ -304,7 +305,8 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     if (!sc || !p || !out || n_envs <= 0) { g_create_err = "rs_create: bad argument"; return RS_EINVAL; }
     rs_sim *h = new (std::nothrow) rs_sim();
     if (!h) return RS_ENOMEM;
-    auto fail = [&](int rc) { g_create_err = h->err; rs_destroy(h); return rc; };
+    auto fail = [&](int rc) { g_create_err = h->err; (void)hipGetLastError(); rs_destroy(h); return rc; };
+    (void)hipGetLastError();        // a stale error of this thread (another library's, an earlier failed call) is not ours
     h->device = device_id; h->n_envs = n_envs; h->env_base = env_base;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { h->err = "no HIP device visible (this library has no CPU fallback)"; return fail(RS_EHIP); }
