@@ -212,7 +212,7 @@ static int32_t strategic_dir_at(const orc_env *e, int32_t route, int32_t cursor,
     int32_t off = (dr <= dl ? dr : dl) + extra;
     float la = (v > RM_LOOK_MIN_SPEED ? v : RM_LOOK_MIN_SPEED) * RM_LOOK_TIME + RM_LOOK_BASE;
     int32_t bl = sc->edge_lane0[sc->route_edge[sc->route_start[route] + cursor]] + ((dr <= dl) ? kk - dr : kk + dl);
-    if (*rem - (float)e->lane_cnt[bl] * e->occ_unit >= la * (float)off) return 0;
+    if (*rem - (float)e->lane_cnt[bl] * (e->occ_unit * RM_OCC_FACTOR) >= la * (float)off) return 0;
     return (dr <= dl) ? -1 : +1;
 }
 static inline int32_t tls_state(const orc_env *e, int32_t link) {

@@ -208,7 +208,7 @@ struct PackedTables {
             for (int k = 0; k < sc->n_trips; ++k) cnt[sc->trip_vtype[k]] += 1;
             int best = 0;
             for (int v = 1; v < sc->n_vtypes; ++v) if (cnt[v] > cnt[best]) best = v;
-            occ_unit = sc->vtype_params[best * VT_COLS + VT_LENGTH] + sc->vtype_params[best * VT_COLS + VT_MINGAP];
+            occ_unit = (sc->vtype_params[best * VT_COLS + VT_LENGTH] + sc->vtype_params[best * VT_COLS + VT_MINGAP]) * RM_OCC_FACTOR;
         }
         if (sc->capacity >= NIL) { err = "capacity exceeds the 11-bit slot ids of the grid cells"; return false; }
         std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
