@@ -7,7 +7,10 @@ Workload (BASELINE.json config 3, the configuration the headline metric is quote
 step producing the per-lane drq_norm rows + mplight + wait + wait_norm + pressure (config 3's state and reward functions;
 the other derived buffers are switched off with rs_set_outputs).
 One "step" = one MultiSignal.step() of every environment = 10 one-second simulation ticks, fused in ONE
-kernel launch.  The timed window is placed in the BULK of the 360-step episode whatever --steps / --warmup are: an
+kernel launch per PIPE: the batch of a GPU is split into --pipes (default 2) handles of envs / pipes environments, each
+stepping on a HIP stream of its own (the global environment index keys the RNG, so the union is the same batch whatever the
+split).  The launches of different pipes overlap, which fills the tail of a launch -- 4096 workgroups on 768 resident slots
+are 5.33 rounds -- and the gaps between dependent launches: +8.6 % on one MI355X (profiles/r04_pipes_ab.jsonl).  The timed window is placed in the BULK of the 360-step episode whatever --steps / --warmup are: an
 untimed fast-forward first rolls the batch to step 180 - K/2 - W (the demand ramps up over the hour, so the first steps
 of an episode are a nearly empty network); then W untimed warm-up steps, then exactly K timed steps.  The defaults
 (W = 60, K = 300) time steps 60..360; the driver's short run (W = 5, K = 20) times steps 170..190, whose load is within
@@ -33,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 EPISODE_STEPS = 360
 OUTPUTS = ('drq_norm', 'mplight')
+DEFAULT_PIPES = 2
 
 
 def shard(rank, world, envs_per_gpu):
@@ -76,12 +80,12 @@ def kernel_source_hash():
 
 
 def pmc_traffic(args, n_local, world):
-    """HBM bytes per launch from the PMC counters.  They are collected in SEPARATE rocprofv3 --pmc passes of this very command
+    """HBM bytes per STEP (= the `pipes` overlapping launches of one step) from the PMC counters.  They are collected in SEPARATE rocprofv3 --pmc passes of this very command
     (tools/pmc_passes.sh <tag> K W -> profiles/r03_pmc_s<K>_w<W>.json), so a figure is reported only when a committed
     summary exists for this run's --steps / --warmup on the default workload AND was measured on the kernel sources that are
     running now (source hash); otherwise None, with the reason."""
-    path = os.path.join(ROOT, 'profiles', 'r03_pmc_s%d_w%d.json' % (args.steps, args.warmup))
-    default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0
+    path = os.path.join(ROOT, 'profiles', 'r04_pmc_s%d_w%d.json' % (args.steps, args.warmup))
+    default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0 and args.pipes == DEFAULT_PIPES
     if not default_workload or not os.path.exists(path):
         return None, ('HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_passes.sh); '
                       'there is no committed summary for this workload / window (%s)' % os.path.basename(path))
@@ -94,10 +98,11 @@ def pmc_traffic(args, n_local, world):
         c = pm['counters']
         fetch_kib, write_kib = c['FETCH_SIZE']['per_launch_avg'], c['WRITE_SIZE']['per_launch_avg']
         # MI355X_MICROARCH.md (HBM / rocprofv3): both counters are in KiB; gfx950's FETCH_SIZE counts half of the bytes
-        return (2.0 * fetch_kib + write_kib) * 1024.0, (
-            '(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, averaged over the %d launches of the PMC passes of this same command '
-            '(profiles/%s, same kernel sources %s): %.0f + %.0f MB' % (c['FETCH_SIZE']['launches'], os.path.basename(path),
-                                                                      pm['source_hash'], 2.0 * fetch_kib * 1024 / 1e6, write_kib * 1024 / 1e6))
+        k = args.pipes
+        return k * (2.0 * fetch_kib + write_kib) * 1024.0, (
+            '%d x (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, averaged over the %d launches of the PMC passes of this same command '
+            '(profiles/%s, same kernel sources %s): %d x (%.0f + %.0f) MB' % (k, c['FETCH_SIZE']['launches'], os.path.basename(path),
+                                                                             pm['source_hash'], k, 2.0 * fetch_kib * 1024 / 1e6, write_kib * 1024 / 1e6))
     except Exception as e:
         return None, 'PMC summary %s unreadable: %r' % (os.path.basename(path), e)
 
@@ -112,25 +117,32 @@ def window_start(steps, warmup):
     return max(warmup, min(EPISODE_MID - steps // 2, EPISODE_STEPS - steps))
 
 
-def run_timed(sim, steps, warmup, barrier, sync, reduce_max):
-    """W untimed steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks."""
+def run_timed(sims, steps, warmup, barrier, sync, reduce_max, all_outputs_steps=0):
+    """W untimed steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks.  `sims`: the pipes of
+    this rank -- every step launches [agent, step] on each pipe's own stream, one host thread issuing them in turn."""
     k = 0
 
     def one():
         nonlocal k
-        if k > 0 and k % EPISODE_STEPS == 0:
-            sim.reset()
-        sim.act_random(k)
-        sim.step(None)
+        for sim in sims:
+            if k > 0 and k % EPISODE_STEPS == 0:
+                sim.reset()
+            sim.act_random(k)
+            sim.step(None)
         k += 1
+
+    def stats():
+        st = [sim.stats() for sim in sims]
+        return {key: __import__('numpy').concatenate([x[key] for x in st]) for key in st[0]}
 
     for _ in range(window_start(steps, warmup) - warmup):      # untimed fast-forward into the bulk of the episode
         one()
     for _ in range(warmup):
         one()
     sync()
-    st0 = sim.stats()
-    sim.timing(True)
+    st0 = stats()
+    for sim in sims:
+        sim.timing(True)
     barrier()
     sync()
     t0 = time.perf_counter()
@@ -139,11 +151,48 @@ def run_timed(sim, steps, warmup, barrier, sync, reduce_max):
     sync()
     barrier()
     t1 = time.perf_counter()
-    kernel_ms, launches = sim.timing_read()
-    sim.timing(False)
-    st1 = sim.stats()
+    kernel_ms, launches = 0.0, 0
+    for sim in sims:
+        ms, n = sim.timing_read()
+        kernel_ms += ms
+        launches += n
+        sim.timing(False)
+    st1 = stats()
     elapsed = reduce_max(t1 - t0)
-    return elapsed, kernel_ms, launches, st0, st1
+    # the same window once more with EVERY derived output buffer switched on (lane_agg, wave, mplight_full, the fp16 tensor,
+    # lane_arrivals next to drq_norm + mplight): what the output mask saves, reported next to the headline figure
+    all_outputs_rate = None
+    if all_outputs_steps > 0:
+        for sim in sims:
+            sim.set_outputs(None)
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(all_outputs_steps):
+            one()
+        sync()
+        all_outputs_rate = all_outputs_steps / (time.perf_counter() - t2)       # steps per second of this rank
+    return elapsed, kernel_ms, launches, st0, st1, all_outputs_rate
+
+
+def state_digest(sims, dist, rank, world):
+    """sha1 over the per-environment state (vehicles, signals, counters) of every environment of every rank in GLOBAL environment
+    order: equal for any split of the same batch over ranks and pipes (the global index keys the RNG)."""
+    import hashlib
+    import numpy as np
+    per_env = []
+    for sim in sims:
+        bufs = [np.ascontiguousarray(sim.read(b)) for b in ('veh_lane', 'veh_trip', 'veh_pos', 'veh_speed', 'veh_swait', 'veh_rwait', 'tls', 'stats',
+                                                            'mplight', 'drq_norm')]
+        for e in range(sim.n_envs):
+            h = hashlib.sha1()
+            for b in bufs:
+                h.update(b[e].tobytes())
+            per_env.append(h.hexdigest())
+    if dist is not None and world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, per_env)
+        per_env = [x for p in parts for x in p]
+    return hashlib.sha1(''.join(per_env).encode()).hexdigest()
 
 
 def bind_to_gpu_numa_node(local_rank):
@@ -237,9 +286,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=60)
     ap.add_argument('--map', default='ingolstadt21')
     ap.add_argument('--envs', type=int, default=4096, help='environments per GPU')
+    ap.add_argument('--pipes', type=int, default=DEFAULT_PIPES, help='handles (HIP streams) the batch of a GPU is split into')
     ap.add_argument('--block', type=int, default=0, help='threads per workgroup (0 = library default)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--digest', action='store_true', help='add a digest of the final per-environment state (all ranks, global env order)')
     args = ap.parse_args()
 
     import torch
@@ -248,39 +299,50 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    # RESCO_BENCH_DEVICE / RESCO_BENCH_BACKEND: several ranks on ONE GPU with a gloo rendezvous -- how the N > 1 path is run
+    # end to end where no multi-GPU node exists (tests/test_gpu_parity.py::test_two_ranks_through_bench_on_one_gpu)
+    local = int(os.environ.get('RESCO_BENCH_DEVICE', local))
+    backend = os.environ.get('RESCO_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local)
     numa = bind_to_gpu_numa_node(local) if world > 1 else None
     dist = None
     if world > 1 or os.environ.get('RESCO_BENCH_FORCE_DIST') == '1':      # the env var exercises the RCCL path at N=1
         import torch.distributed as dist
-        dist.init_process_group('nccl', rank=rank, world_size=world)      # RCCL: barrier + one MAX only
+        dist.init_process_group(backend, rank=rank, world_size=world)     # RCCL: barrier + one MAX only
 
     from resco_amd.scenario import Scenario
     from resco_amd.sim import BatchedSim
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', args.map + '.npz'))
     env_base, n_local = shard(rank, world, args.envs)
-    sim = BatchedSim(sc, n_local, device=local, seed=args.seed, sigma=-1.0, speed_dev=1, env_base=env_base,
-                     block_threads=args.block)
+    if args.pipes < 1 or n_local % args.pipes:
+        raise SystemExit('--envs must be a multiple of --pipes')
+    per = n_local // args.pipes
+    sims = [BatchedSim(sc, per, device=local, seed=args.seed, sigma=-1.0, speed_dev=1, env_base=env_base + i * per,
+                       block_threads=args.block) for i in range(args.pipes)]
+    sim = sims[0]
     # BASELINE config 3 / SURVEY 8(d): "state fns computed every step: lane aggregates -> drq_norm + mplight; rewards wait +
     # pressure" -- only what those consume is written (the per-signal rewards and metrics always are)
-    sim.set_outputs(OUTPUTS)
+    for x in sims:
+        x.set_outputs(OUTPUTS)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
     def sync():
-        sim.sync()
+        for x in sims:
+            x.sync()
         torch.cuda.synchronize()
 
     def reduce_max(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device='cuda')
+        t = torch.tensor([x], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed, kernel_ms, launches, st0, st1 = run_timed(sim, args.steps, args.warmup, barrier, sync, reduce_max)
+    elapsed, kernel_ms, launches, st0, st1, all_out_rate = run_timed(sims, args.steps, args.warmup, barrier, sync, reduce_max,
+                                                                     all_outputs_steps=min(args.steps, 20))
     ticks = (st1['ticks'] - st0['ticks']).astype('float64')
     mean_active = float(((st1['active_ticks'] - st0['active_ticks']) / ticks.clip(min=1)).mean()) if ticks.min() > 0 \
         else float(st1['active'].mean())
@@ -290,7 +352,10 @@ def main():
     b_alg = algorithmic_bytes_per_env_step(sc, mean_active)
     b_wide = designed_bytes_per_env_step(sc, mean_active)
     k_avg_s = (kernel_ms / max(1, launches)) * 1e-3
-    achieved = b_alg * n_local / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+    # one step = `pipes` launches of n_local / pipes environments that overlap on their streams: the bytes of all of them over
+    # the average duration of one of them (= pipes x the per-launch figure)
+    achieved_per_launch = b_alg * per / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+    achieved = args.pipes * achieved_per_launch
     w0 = window_start(args.steps, args.warmup)
     traffic, traffic_note = pmc_traffic(args, n_local, world)
     out = {
@@ -300,7 +365,7 @@ def main():
         'config': {'workload': '%s x %d lock-step envs per GPU (BASELINE config 3), fixed demand from the map\'s '
                                'rou.xml, on-device seeded random policy, Krauss sigma 0.5 + speedFactor dev 0.1'
                                % (args.map, n_local),
-                   'map': args.map, 'envs_per_gpu': n_local, 'ticks_per_env_step': 10,
+                   'map': args.map, 'envs_per_gpu': n_local, 'pipes': args.pipes, 'ticks_per_env_step': 10,
                    'episode_window': [w0, w0 + args.steps], 'untimed_fast_forward_steps': w0 - args.warmup,
                    'block_threads': info['block_threads'], 'lds_bytes_per_env': info['lds_bytes'],
                    'outputs_per_step': list(OUTPUTS) + ['wait', 'wait_norm', 'pressure', 'phase', 'queue_sum', 'queue_max', 'arrivals', 'departures'],
@@ -310,14 +375,23 @@ def main():
                      'frac': achieved / HBM_PEAK_GBS,
                      'traffic': traffic, 'traffic_note': traffic_note,
                      'kernel': 'rs_step_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
-                     'algorithmic_bytes_per_env_step': b_alg, 'env_steps_per_launch': n_local,
+                     'concurrent_launches': args.pipes, 'achieved_per_launch': achieved_per_launch,
+                     'achieved_note': 'a step is %d launches of %d environments each on %d HIP streams; they overlap, so `achieved` = %d x '
+                                      '(algorithmic bytes of one launch / its average duration by HIP events on its own stream); '
+                                      '`traffic` likewise = %d x the per-launch counter figure' % (args.pipes, per, args.pipes, args.pipes, args.pipes),
+                     'algorithmic_bytes_per_env_step': b_alg, 'env_steps_per_launch': per,
                      'formula': 'SURVEY 8(d): 60*V + 12*S + 20*SL + 8*S', 'designed_bytes_per_env_step': b_wide,
-                     'achieved_designed_bytes': b_wide * n_local / k_avg_s / 1e9 if k_avg_s > 0 else 0.0,
+                     'achieved_designed_bytes': args.pipes * b_wide * per / k_avg_s / 1e9 if k_avg_s > 0 else 0.0,
                      'note': 'state is Infinity-Cache resident and the kernel is issue/latency bound: the HBM '
                              'fraction is small by construction (SURVEY.md 8d)'},
         'mean_active_vehicles_per_env': mean_active,
         'sim_ticks_per_s': value * 10, 'vehicle_ticks_per_s': value * 10 * mean_active,
+        'all_outputs': {'value': world * n_local * all_out_rate, 'unit': 'env-steps/s',
+                        'note': 'rank 0, the steps right after the timed window with EVERY derived buffer written (lane_agg, drq_norm, wave, mplight, '
+                                'mplight_full, drq_norm_f16, lane_arrivals): rounds 1-2 measured this workload, rounds 3-4 write what config 3 consumes'},
     }
+    if args.digest:
+        out['state_digest'] = state_digest(sims, dist, rank, world)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -328,7 +402,8 @@ def main():
             except Exception as e:          # the baseline must never take the GPU number down with it
                 out['cpu_baseline'] = {'value': None, 'unit': 'env-steps/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
-    sim.close()
+    for x in sims:
+        x.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

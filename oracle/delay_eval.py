@@ -43,14 +43,16 @@ def trip_delay(env, sc):
     return (st['sum_time_loss_q10'] / 1024.0 + running + st['sum_depart_delay'] + waited) / max(1, trips)
 
 
-def run_env(name, policy, env_index, seed, steps):
+def run_env(name, policy, env_index, seed, steps, trip_log=0, valid_acts=None):
     """one oracle environment driven by `policy` for `steps` env-steps; returns (env, scenario)"""
     from oracle.pyoracle import OracleEnv, lib
     from resco_amd.scenario import Scenario
     from resco_amd.sim import maxwave_tables
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
+    if valid_acts:
+        sc.valid_acts = dict(sc.valid_acts); sc.valid_acts.update(valid_acts)
     env = OracleEnv(sc, env_index=env_index, seed=seed, sigma=-1.0, speed_dev=1, max_distance=MAX_DISTANCE[policy],
-                    fixed_program=1 if policy == 'FIXED' else 0)
+                    fixed_program=1 if policy == 'FIXED' else 0, trip_log=trip_log)
     env.observe()
     S = sc.n_signals
     G = [int(g) for g in sc.tls_ngreen]

@@ -40,7 +40,8 @@ def ref_bands():
 
 
 def episode(job):
-    name, policy, env_index, seed, steps = job
+    name, policy, env_index, seed, steps = job[:5]
+    sigma = job[5] if len(job) > 5 else -1.0
     from oracle.pyoracle import OracleEnv, lib
     from resco_amd.scenario import Scenario
     from resco_amd.sim import maxwave_tables
@@ -49,7 +50,7 @@ def episode(job):
         sc.valid_acts = dict(sc.valid_acts)
         sc.valid_acts['243641585'] = {4: 0, 7: 1, 2: 2}
         policy = policy[:-1]
-    env = OracleEnv(sc, env_index=env_index, seed=seed, sigma=-1.0, speed_dev=1, max_distance=MAX_DISTANCE[policy],
+    env = OracleEnv(sc, env_index=env_index, seed=seed, sigma=sigma, speed_dev=1, max_distance=MAX_DISTANCE[policy],
                     fixed_program=1 if policy == 'FIXED' else 0, trip_log=1)
     env.observe()
     S = sc.n_signals
@@ -100,8 +101,8 @@ def episode(job):
                 depart_delay=(st['sum_depart_delay'] + waited) / max(1, trips))
 
 
-def run(name, policy, envs=8, seed=0, steps=360, pool=None):
-    jobs = [(name, policy, e, seed, steps) for e in range(envs)]
+def run(name, policy, envs=8, seed=0, steps=360, pool=None, sigma=-1.0):
+    jobs = [(name, policy, e, seed, steps, sigma) for e in range(envs)]
     rows = pool.map(episode, jobs) if pool is not None else [episode(j) for j in jobs]
     out = dict(map=name, policy=policy, envs=envs)
     for k in rows[0]:
@@ -120,15 +121,25 @@ def main():
     ap.add_argument('--steps', type=int, default=360)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--json', default=None)
+    ap.add_argument('--compact', action='store_true', help='one line per map: delay ratios only')
+    ap.add_argument('--sigma', type=float, default=-1.0)
     args = ap.parse_args()
     from oracle.pyoracle import build
     build()
     RB = ref_bands()
     allrows = []
     with mp.get_context('fork').Pool(min(args.envs, os.cpu_count() or 1)) as pool:
+        ratios = []
         for m in args.maps:
+            line = []
             for pol in args.policies.split(','):
-                r = run(m, pol, args.envs, args.seed, args.steps, pool)
+                r = run(m, pol, args.envs, args.seed, args.steps, pool, args.sigma)
+                if args.compact:
+                    ref0 = RB.get(m, {}).get(pol.rstrip('*'), {})
+                    q = r['delay'] / ref0['delay'] if 'delay' in ref0 else float('nan')
+                    line.append('%s %6.1f (%.2f)' % (pol[:2] + pol[-1:], r['delay'], q)); ratios.append(q)
+                    allrows.append(r)
+                    continue
                 ref = RB.get(m, {}).get(pol.rstrip('*'), {})
                 cells = []
                 for key in ('delay', 'duration', 'waiting', 'queue'):
@@ -142,6 +153,12 @@ def main():
                     extra = '  resid %.1f / %.1f' % (resid, RB[m]['free_flow_residual'])
                 print('%-13s %-11s %s  | arr %5.0f pend %4.0f V %6.1f dd %5.1f%s' % (m, pol, '  '.join(cells), r['arrived'], r['pending'], r['mean_active'], r['depart_delay'], extra), flush=True)
                 allrows.append(r)
+            if args.compact:
+                print('%-13s %s' % (m, '  '.join(line)), flush=True)
+        if args.compact:
+            import math
+            rr = np.array([x for x in ratios if x == x])
+            print('median ratio %.3f   sum|log| %.3f   in +-35%%: %d / %d' % (np.median(rr), np.abs(np.log(rr)).sum(), ((rr > 0.65) & (rr < 1.35)).sum(), len(rr)))
     if args.json:
         with open(args.json, 'w') as f:
             json.dump(allrows, f, indent=1)

@@ -85,6 +85,10 @@ class FusedIDQN:
             raise RuntimeError('rs_idqn_create failed (%d): %s' % (rc, msg.decode() if msg else '?'))
         self.close()
         self._h = h
+        lanes = np.asarray(self.net.lanes, np.int32)            # the signals' own head sizes: padded lanes are skipped
+        self._lib.rs_idqn_set_lanes.argtypes = [C.c_void_p, C.c_void_p]
+        if self._lib.rs_idqn_set_lanes(self._h, lanes.ctypes.data) != 0:
+            raise RuntimeError('rs_idqn_set_lanes failed')
 
     @torch.no_grad()
     def refresh_on_device(self):

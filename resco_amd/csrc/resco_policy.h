@@ -36,6 +36,7 @@ struct PolicyTab {          // device pointers of the packed weights, all [S][..
     const h4_t *w3;         // [S][8][64]       (columns >= n_actions are zero)
     const float *b3;        // [S][32]
     const int32_t *n_actions;   // [S]
+    const int32_t *hp_sig;      // [S] k-steps of 8 that carry non-zero fc1 rows for signal s = ceil((lanes_s - 1) / 2), <= hp (rs_idqn_set_lanes)
     int32_t S, lmax, hp;    // signals, padded lanes per signal (obs rows), k-steps of 8 per channel = ceil((lmax-1)/2)
 };
 
@@ -61,6 +62,9 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
     const int LM = W.lmax, H = LM - 1;
+    // the signal's own head size: its fc1 rows beyond (lanes_s - 1) * 4 per channel are zero (padded lanes), so the k-steps
+    // beyond hps add exactly 0.0 to the accumulators and are skipped -- a wave-uniform bound (one signal per workgroup)
+    const int hps = __builtin_amdgcn_readfirstlane(W.hp_sig[s]);
 
     // ---- stage the observation tile: [64 envs][LM][5] halfs, contiguous per env -> xs[env][row][0..4]
     for (int e = tid; e < POL_TM * 18 * 8; e += 128) ((_Float16 *)xs)[e] = (_Float16)0.0f;
@@ -102,19 +106,21 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
                                                                     // past the channel: the allocation and wbuf are padded)
     const uint4 *w1g = (const uint4 *)(W.w1 + (size_t)s * POL_C * HP * 2 * 64);
     uint4 *wbuf16 = (uint4 *)wbuf;
+    const int nq = (hps * 64 + 127) >> 7;                           // copy passes that carry this signal's k-steps
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) wbuf16[tid + q * 128] = w1g[tid + q * 128];
+    for (int q = 0; q < NQ; ++q) if (q < nq) wbuf16[tid + q * 128] = w1g[tid + q * 128];
     __syncthreads();
     for (int c = 0; c < POL_C; ++c) {
         uint4 nxt[NQ];
         const uint4 *gn = w1g + (size_t)(c + 1 < POL_C ? c + 1 : c) * chunk16 + tid;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) nxt[q] = gn[q * 128];          // in flight while this channel is multiplied
+        for (int q = 0; q < NQ; ++q) if (q < nq) nxt[q] = gn[q * 128];          // in flight while this channel is multiplied
         const _Float16 s00 = (_Float16)cw[c * 4 + 0], s01 = (_Float16)cw[c * 4 + 1], s10 = (_Float16)cw[c * 4 + 2], s11 = (_Float16)cw[c * 4 + 3], sb = (_Float16)cb[c];
         const h2_t h00 = {s00, s00}, h01 = {s01, s01}, h10 = {s10, s10}, h11 = {s11, s11}, hb = {sb, sb}, hz = {(_Float16)0.0f, (_Float16)0.0f};
         const h4_t *wc = wbuf + (size_t)(c & 1) * (8 * 2 * 64) + lane;
 #pragma unroll
         for (int kk = 0; kk < HP; ++kk) {
+            if (kk >= hps) break;
             // features (w = 0,1) and (w = 2,3) of row h: rows beyond H give relu(bias), harmless (zero fc1 weights)
             h2_t f01 = __builtin_elementwise_fma(h00, p0[kk][0], hb), f23 = __builtin_elementwise_fma(h00, p0[kk][2], hb);
             f01 = __builtin_elementwise_fma(h01, p0[kk][1], f01); f23 = __builtin_elementwise_fma(h01, p0[kk][3], f23);
@@ -128,7 +134,7 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
         }
         uint4 *dst = wbuf16 + (size_t)((c + 1) & 1) * (8 * 2 * 64 / 2) + tid;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) dst[q * 128] = nxt[q];
+        for (int q = 0; q < NQ; ++q) if (q < nq) dst[q * 128] = nxt[q];
         __syncthreads();
     }
 

@@ -589,6 +589,13 @@ extern "C" int rs_act_random(rs_handle h, uint32_t step_key, void *stream) {
 extern "C" int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n_pairs, const int32_t *valid,
                               const int32_t *order, int32_t use_pressure, void *stream) {
     if (!h || n_pairs <= 0) return RS_EINVAL;
+    // the agent reads the states.mplight / states.wave rows of the last observe: refuse when rs_set_outputs switched them off
+    // (the buffer would hold stale rows, or zeros if it was never written)
+    if (!(h->out_mask & (use_pressure ? OUT_MPLIGHT : OUT_WAVE))) {
+        h->err = use_pressure ? "rs_act_maxwave(use_pressure=1) reads RS_BUF_MPLIGHT, which rs_set_outputs has switched off"
+                              : "rs_act_maxwave(use_pressure=0) reads RS_BUF_WAVE, which rs_set_outputs has switched off";
+        return RS_EINVAL;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     h->last = st;
@@ -762,7 +769,8 @@ extern "C" int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax
         (rc = pol_upload<h4_t>(p, &p->W.w1, w1, S * 64 * hp * 2 * 64)) || (rc = pol_upload<float>(p, &p->W.b1, b1, S * 64)) ||
         (rc = pol_upload<h4_t>(p, &p->W.w2, w2, S * 8 * 2 * 64)) || (rc = pol_upload<float>(p, &p->W.b2, b2, S * 64)) ||
         (rc = pol_upload<h4_t>(p, &p->W.w3, w3, S * 8 * 64)) || (rc = pol_upload<float>(p, &p->W.b3, b3, S * 32)) ||
-        (rc = pol_upload<int32_t>(p, &p->W.n_actions, n_actions, S))) {
+        (rc = pol_upload<int32_t>(p, &p->W.n_actions, n_actions, S)) ||
+        (rc = pol_upload<int32_t>(p, &p->W.hp_sig, std::vector<int32_t>(S, (int32_t)hp).data(), S))) {    // every k-step until rs_idqn_set_lanes says otherwise
         g_create_err = "rs_idqn_create: device allocation / upload failed";
         rs_idqn_destroy(p);
         return rc;
@@ -796,6 +804,21 @@ extern "C" int rs_idqn_set_device_weights(rs_policy_handle p, const float *conv_
     if (w3) p->W.w3 = (const h4_t *)w3;
     if (b3) p->W.b3 = b3;
     return RS_OK;
+}
+
+// The networks' own input sizes: signal s observes lanes[s] lanes, so the fc1 rows of its padded lanes (beyond (lanes[s] - 1) * 4
+// per conv channel) are zero and the kernel may skip their k-steps -- results are unchanged, the work follows the real head sizes.
+extern "C" int rs_idqn_set_lanes(rs_policy_handle p, const int32_t *lanes_per_signal) {
+    if (!p || !lanes_per_signal) return RS_EINVAL;
+    if (hipSetDevice(p->device) != hipSuccess) return RS_EHIP;
+    std::vector<int32_t> hp((size_t)p->W.S);
+    for (int s = 0; s < p->W.S; ++s) {
+        const int l = lanes_per_signal[s];
+        if (l < 2 || l > p->W.lmax) { g_create_err = "rs_idqn_set_lanes: 2 <= lanes[s] <= lmax"; return RS_EINVAL; }
+        hp[(size_t)s] = l / 2;                                  // ceil((l - 1) / 2)
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return RS_EHIP;
+    return hipMemcpy((void *)p->W.hp_sig, hp.data(), hp.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess ? RS_OK : RS_EHIP;
 }
 
 extern "C" void rs_idqn_destroy(rs_policy_handle p) {

@@ -211,6 +211,14 @@ struct PackedTables {
             occ_unit = (sc->vtype_params[best * VT_COLS + VT_LENGTH] + sc->vtype_params[best * VT_COLS + VT_MINGAP]) * RM_OCC_FACTOR;
         }
         if (sc->capacity >= NIL) { err = "capacity exceeds the 11-bit slot ids of the grid cells"; return false; }
+        // the 4-bit vehicle counter of a grid cell saturates at 15 (the oracle's per-lane count is exact): refuse vehicle types
+        // so short that a CELL_LEN-metre cell could hold that many fronts bumper to bumper
+        for (int v = 0; v < sc->n_vtypes; ++v) {
+            const float unit = sc->vtype_params[v * VT_COLS + VT_LENGTH] + sc->vtype_params[v * VT_COLS + VT_MINGAP];
+            if (!(unit > 0.0f) || (int)(CELL_LEN / unit) + 1 >= (int)CELL_CNT_MAX) {
+                err = "a vehicle type is too short for the grid cells: floor(CELL_LEN / (length + minGap)) + 1 must stay below 15"; return false;
+            }
+        }
         std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
         int n_foe_targets = 0;
         for (int l = 0; l < sc->n_links; ++l)

@@ -360,6 +360,7 @@ class VecMultiSignal:
     DERIVED = ('drq', 'fma2c', 'fma2c_full')
 
     def tensor(self, name):
+        self.sim.require_output(name)           # a buffer switched off with set_outputs holds stale rows: refuse, loudly
         t = self._tensors.get(name)
         if t is None:
             t = self._tensors[name] = self.sim.tensor(name)

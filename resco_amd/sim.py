@@ -31,7 +31,7 @@ TRIP_NONE = 0xFFFF
 ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_reinit_signals', 'rs_ticks', 'rs_step_sim', 'rs_set_outputs', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
                'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_phase_profile', 'rs_info',
-               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_destroy']
+               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_set_lanes', 'rs_idqn_destroy']
 
 _lib = None
 
@@ -167,6 +167,7 @@ class BatchedSim:
         self.S, self.O, self.C = scenario.n_signals, scenario.n_obs, scenario.capacity
         self.seed, self.env_base, self.speed_dev = int(seed) & 0xFFFFFFFF, int(env_base), int(speed_dev)
         self._maxwave_ready = False
+        self._masked_off = frozenset()          # maskable output buffers the observe does not write at present (set_outputs)
         self._dep_cache = None
         self._meta = {}
         for name, bid in BUF_ID.items():
@@ -236,6 +237,13 @@ class BatchedSim:
                 raise ValueError('%r is not a maskable output buffer (%s)' % (n, ', '.join(OUTPUT_GROUPS)))
             mask |= 1 << BUF_ID[n]
         self._check(self._lib.rs_set_outputs(self._h, mask))
+        self._masked_off = frozenset(OUTPUT_GROUPS) - frozenset(OUTPUT_GROUPS if names is None else names)
+
+    def require_output(self, name):
+        """Raise when `name` is a maskable output buffer that set_outputs has switched off: its contents are stale (or zeros),
+        and whoever consumes them (an on-device agent, a derived state) would act on garbage without noticing."""
+        if name in self._masked_off:
+            raise RuntimeError('output buffer %r is switched off (BatchedSim.set_outputs): re-enable it before reading it' % name)
 
     def reinit_signals(self, stream=None):
         """fresh Signal objects on the running simulation (see rs_reinit_signals)"""
@@ -271,9 +279,12 @@ class BatchedSim:
         self._check(self._lib.rs_read_buffer(self._h, BUF_ID[name], out.ctypes.data, out.nbytes))
         return out
 
-    def tensor(self, name):
-        """Zero-copy torch tensor over the library-owned device buffer (agent boundary)."""
+    def tensor(self, name, allow_masked=False):
+        """Zero-copy torch tensor over the library-owned device buffer (agent boundary).  A buffer that set_outputs has
+        switched off is refused (stale contents) unless allow_masked."""
         import torch
+        if not allow_masked:
+            self.require_output(name)
         ptr, shape, dt = self._meta[name]
         return torch.as_tensor(_DevArray(ptr, shape, dt, self), device='cuda:%d' % self.device)
 
@@ -334,10 +345,13 @@ class BatchedSim:
     def trip_metrics(self):
         """The per-episode figures of utils/readXML.py:16-77 per environment.
         `delay`: (timeLoss + departDelay) summed over the tripinfo entries -- the arrived and, as
-        --tripinfo-output.write-unfinished writes them, the running vehicles -- divided by their number; demand that never
-        got onto the network is added (end_time - depart each, one more trip each) only when the rou.xml lists <vehicle>
-        elements: readXML.py:59-68 skips every other tag, so the <trip> files of five of the six maps are never charged for it.
-        `delay_all` charges the queued demand on every map.  `duration`, `waiting`, `time_loss`: tripinfo duration /
+        --tripinfo-output.write-unfinished writes them, the running vehicles -- divided by their number.  Demand that never got
+        onto the network is added only when the rou.xml lists <vehicle> elements (cologne3): readXML.py:59-68 skips every other
+        tag, so the <trip> files of five of the six maps are never charged for it.  For <vehicle> files the script's own rule is
+        followed (`_readxml_never_departed`): every vehicle SCHEDULED later than the vehicle that actually departed last counts as
+        never departed and is charged end_time - depart -- whether or not it is in the tripinfo file as well.
+        `delay_all` charges the insertion backlogs (trips that are due and not on the network, now - depart each) on every map:
+        this build's own, stricter figure, not the script's.  `duration`, `waiting`, `time_loss`: tripinfo duration /
         waitingTime / timeLoss over the same entries."""
         st = self.stats()
         lane = self.read('veh_lane')
@@ -346,13 +360,54 @@ class BatchedSim:
         cnt, waited = self.backlog()
         now = self.time().astype(np.int64)
         entries = st['arrived'] + live.sum(axis=1)
-        run_dur = ((now[:, None] - self.read('veh_depart').astype(np.int64)) * live).sum(axis=1)
+        depart = self.read('veh_depart').astype(np.int64)
+        run_dur = ((now[:, None] - depart) * live).sum(axis=1)
         loss = st['sum_time_loss_q10'] / 1024.0 + running
         delay_all = (loss + st['sum_depart_delay'] + waited) / np.maximum(1, entries + cnt)
-        delay = delay_all if self.sc.demand_tag == 'vehicle' else (loss + st['sum_depart_delay']) / np.maximum(1, entries)
+        if self.sc.demand_tag == 'vehicle':
+            n_nd, charged = self._readxml_never_departed(live, depart)
+            delay = (loss + st['sum_depart_delay'] + charged) / np.maximum(1, entries + n_nd)
+        else:
+            delay = (loss + st['sum_depart_delay']) / np.maximum(1, entries)
         entries = np.maximum(1, entries)
         return dict(delay=delay, delay_all=delay_all, duration=(st['sum_duration'] + run_dur) / entries,
                     waiting=st['sum_waiting'] / entries, time_loss=loss / entries)
+
+    def _readxml_never_departed(self, live, depart):
+        """utils/readXML.py:41-68 for <vehicle> route files, per environment: (count, seconds charged).  The script takes the
+        tripinfo entry with the latest actual departure (the first one in file order among equals: arrived vehicles come first,
+        in arrival order; the unfinished ones follow in id order), looks up that vehicle's SCHEDULED departure in the rou.xml and
+        charges end_time - depart for every <vehicle> scheduled later.  Arrived vehicles are considered when the handle keeps
+        per-trip records (trip_log=1); without them the latest departure is taken from the vehicles still on the network."""
+        sched = self.sc.arrays['trip_depart'].astype(np.int64)
+        horizon = int(self.sc.horizon)
+        trips = self.read('veh_trip').astype(np.int64)
+        ids = getattr(self.sc, 'trip_ids', None)
+        log = self.read('trip_log') if self._p.trip_log else None
+        n_nd = np.zeros(self.n_envs, np.int64)
+        charged = np.zeros(self.n_envs, np.float64)
+        for e in range(self.n_envs):
+            best_t, best_k = -1, -1
+            if log is not None and log.size:
+                arr = np.nonzero(log[e, :, 1] > 0)[0]
+                if len(arr):
+                    t = log[e, arr, 0]
+                    order = np.lexsort((arr, log[e, arr, 1]))           # file order: arrival time, then trip order
+                    j = order[np.argmax(t[order] == t.max())]
+                    best_t, best_k = int(t[j]), int(arr[j])
+            run = np.nonzero(live[e])[0]
+            if len(run):
+                t = depart[e, run]
+                if int(t.max()) > best_t:
+                    cand = trips[e, run[t == t.max()]]
+                    best_k = int(min(cand, key=(lambda k: ids[k]) if ids else None))
+                    best_t = int(t.max())
+            if best_k < 0:
+                continue
+            late = sched > sched[best_k]
+            n_nd[e] = int(late.sum())
+            charged[e] = float((horizon - sched[late]).sum())
+        return n_nd, charged
 
     # ------------------------------------------------------------------ snapshots / timing
     def snapshot(self):

@@ -292,6 +292,7 @@ int rs_act_random(rs_handle h, uint32_t step_key, void *) {
 }
 int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n_pairs, const int32_t *valid, const int32_t *order, int32_t use_pressure, void *) {
     const int S = h->K.n_signals;
+    if (!(h->out_mask & (use_pressure ? OUT_MPLIGHT : OUT_WAVE))) return RS_EINVAL;     // (as the HIP library: the rows it would read are switched off)
     if (phase_pairs) {
         h->pairs.assign(phase_pairs, phase_pairs + n_pairs * 2); h->valid.assign(valid, valid + S * n_pairs); h->ordr.assign(order, order + S * n_pairs);
         h->n_pairs = n_pairs;

@@ -1,6 +1,7 @@
 """CPU, world_size 2, gloo: the multi-GPU path of bench.py is an env-batch split with no data-path
 collective -- ranks own disjoint environment ranges keyed by their GLOBAL index, meet at a barrier, and
-report the MAX of their times.  The union of the shards must equal the single-process batch."""
+report the MAX of their times; inside a rank the batch is split once more into pipes (handles on their own HIP
+streams).  The union of the shards and pipes must equal the single-process, single-handle batch."""
 import os
 import pickle
 import sys
@@ -11,7 +12,7 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT, load_scenario
 
-ENVS_PER_RANK, STEPS, WARMUP, SEED = 3, 4, 2, 21
+ENVS_PER_RANK, PIPES, STEPS, WARMUP, SEED = 4, 2, 4, 2, 21
 
 
 def _rank_main(rank, world, port, outdir):
@@ -25,17 +26,18 @@ def _rank_main(rank, world, port, outdir):
     from oracle_batch import OracleBatch
     sc = load_scenario('cologne1')
     base, n = bench.shard(rank, world, ENVS_PER_RANK)
-    sim = OracleBatch(sc, n, seed=SEED, env_base=base)
+    per = n // PIPES            # the batch of a rank is stepped as PIPES handles (bench.py --pipes), each on its own stream on the GPU
+    sims = [OracleBatch(sc, per, seed=SEED, env_base=base + i * per) for i in range(PIPES)]
 
     def reduce_max(x):
         t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed, kms, launches, st0, st1 = bench.run_timed(sim, STEPS, WARMUP, dist.barrier, sim.sync, reduce_max)
+    elapsed, kms, launches, st0, st1, _ = bench.run_timed(sims, STEPS, WARMUP, dist.barrier, lambda: None, reduce_max)
     with open(os.path.join(outdir, 'rank%d.pkl' % rank), 'wb') as f:
-        pickle.dump(dict(base=base, n=n, elapsed=elapsed, launches=launches, mplight=sim.read('mplight'),
-                         lane_agg=sim.read('lane_agg'), ticks=(st1['ticks'] - st0['ticks'])), f)
+        pickle.dump(dict(base=base, n=n, elapsed=elapsed, launches=launches, mplight=np.concatenate([x.read('mplight') for x in sims]),
+                         lane_agg=np.concatenate([x.read('lane_agg') for x in sims]), ticks=(st1['ticks'] - st0['ticks'])), f)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,14 +49,14 @@ def test_env_batch_split_over_two_ranks():
     parts = [pickle.load(open(os.path.join(outdir, 'rank%d.pkl' % r), 'rb')) for r in range(2)]
     assert [p['base'] for p in parts] == [0, ENVS_PER_RANK] and all(p['n'] == ENVS_PER_RANK for p in parts)
     assert parts[0]['elapsed'] == parts[1]['elapsed'] > 0          # MAX over ranks, identical everywhere
-    assert all(p['launches'] == STEPS for p in parts)
+    assert all(p['launches'] == STEPS * PIPES for p in parts)            # one launch per pipe and step
     assert all((p['ticks'] == STEPS * 10).all() for p in parts)
     # single-process reference batch of 2 x ENVS_PER_RANK environments
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import bench
     from oracle_batch import OracleBatch
     whole = OracleBatch(load_scenario('cologne1'), 2 * ENVS_PER_RANK, seed=SEED, env_base=0)
-    bench.run_timed(whole, STEPS, WARMUP, lambda: None, whole.sync, lambda x: x)
+    bench.run_timed([whole], STEPS, WARMUP, lambda: None, whole.sync, lambda x: x)
     np.testing.assert_array_equal(whole.read('mplight'), np.concatenate([p['mplight'] for p in parts]))
     np.testing.assert_array_equal(whole.read('lane_agg'), np.concatenate([p['lane_agg'] for p in parts]))
 

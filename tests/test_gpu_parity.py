@@ -827,35 +827,39 @@ def test_fused_policy_sampling_mode_follows_the_softmax():
 #   free_flow_residual              duration - delay of the trained IDQN episodes: the travel time of the routes at the speed
 #                                   limits -- independent of the controller, it pins routing, lane lengths and speed limits
 # The dynamics are this build's own model (PARITY-UNPINNED vs SUMO); these are the only reference-held
-# numbers that depend on them.  Default band: +-35 % of the reference figure.  EXCEPT lists every cell that is outside it,
-# with explicit bounds around what this model measures (64 environments, median) and the reason:
-#  * ingolstadt21 FIXED (2.1 x): TLS 243641585 is over-saturated from two sides under its own programme -- 535 trips per hour
-#    turn left from -201201945#0.78 on ONE lane with 20 s of green per 86 s and meet gneJ257 (red for 40 s of 90 s, different
-#    cycle length) 12 m later; 843 per hour arrive on the two lanes of 23166741#5 with 26 s of green.  With the E-left demand
-#    removed the map still runs at 160 s (oracle/fidelity_eval.py what-if): the excess is spread over the network.  Round 2
-#    measured 2.5 x; the occupation rule of model v4 brought it to 2.1 x.
-#  * ingolstadt21 MAXWAVE / MAXPRESSURE (6.4 x / 4.4 x): the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2} maps the
-#    wave of the S approach (S-S + S-E, 843 veh/h) to green phase 0 = 'rGgG', in which that approach is red (phase order = the
-#    tlLogic's file order exactly as multi_signal.py:52-59 extracts it); the wave of the 12 m W approach that would select the
-#    S phase can never exceed the S queue: the greedy policies pick action 0 in 360 of 360 steps and starve S for the whole
-#    episode.  The same test runs them with that one entry remapped to {4: 0, 7: 1, 2: 2} (each pair to a phase that serves
-#    it): MAXWAVE then gives 1.15 x the published median (default band), MAXPRESSURE 1.58 x.
-#  * STOCHASTIC on cologne1 / cologne3 / ingolstadt7: the random policy saturates these maps in SUMO (delay > duration: most of
-#    it is insertion backlog, where a few per cent of capacity move the figure by tens of per cent; the reference's own early
-#    episodes spread over 216-379 s on cologne1 and 132-323 s on cologne3).  This model discharges a little more per green.
+# numbers that depend on them.  ONE band: +-35 % of the reference figure.  What is known to lie outside it is listed in KNOWN_GAPS
+# and tested as an expected failure -- not banded around:
+#  * ingolstadt21 FIXED (2.1 x): profiles/r04_ingolstadt21_approaches.txt.  40 % of the delay sits on ONE movement -- 490 veh/h on
+#    one lane of -201201945#0.78 with 20 s of green per 86 s, turning left 12 m later through gneJ257's permissive internal
+#    junction (90 s cycle: the offset drifts through every value; 8 vehicles per cycle in phase, 4 out of phase, 211 veh/h served)
+#    -- and 22 % on the S approach (right-turn lane at 515 veh/h against a measured discharge of 12 per cycle = 504 veh/h).  Both
+#    are at or beyond their physical capacity under the net's own programme in any Krauss simulation; near saturation a few per
+#    cent of capacity are a factor of two in delay.  With half the demand the map runs at 96 s.
+#  * ingolstadt21 MAXWAVE / MAXPRESSURE as configured (6.4 x / 4.4 x): the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2}
+#    maps the wave of the S approach (841 trips/h) to green 0 = 'rGgG', in which that approach is red (phase order = the tlLogic's
+#    file order exactly as multi_signal.py:52-59 extracts it): 0 of its 841 trips arrive in the hour.  No simulator reaches the
+#    published 69.6 s with that mapping (the vehicles stored on the approach alone are worth 59 s per tripinfo entry); with the
+#    entry rotated to {4: 0, 7: 1, 2: 2} MAXWAVE gives 1.15 x (default band), MAXPRESSURE 1.58 x.
+#  * STOCHASTIC on cologne1 / cologne3: the random policy saturates these maps in SUMO (delay > duration: most of it is insertion
+#    backlog; the reference's own early episodes spread over 216-379 s on cologne1 and 132-323 s on cologne3).  This model
+#    discharges more per green second under 7 s greens.
 #  * cologne3 / cologne8 MAXPRESSURE and cologne3 MAXWAVE are bimodal in the reference itself (means 162 / 48 / 91 s against
 #    medians 28 / 30 / 22 s): medians are compared.
+# The held-out counterpart (figures no model constant was tuned on) is tests/test_gpu_heldout.py.
 BAND = (0.65, 1.35)
-EXCEPT = {
-    ('ingolstadt21', 'FIXED', 'delay'): (1.0, 2.4),
-    ('ingolstadt21', 'MAXWAVE', 'delay'): (5.0, 8.0), ('ingolstadt21', 'MAXPRESSURE', 'delay'): (3.5, 5.5),
-    ('ingolstadt21', 'MAXPRESSURE*', 'delay'): (1.0, 1.9),            # (MAXWAVE*: 1.15 x, inside the default band)
-    ('ingolstadt21', 'STOCHASTIC', 'delay'): (0.9, 1.5),
-    ('cologne1', 'STOCHASTIC', 'delay'): (0.5, 1.0), ('cologne1', 'STOCHASTIC', 'duration'): (0.45, 0.9),
-    ('cologne1', 'STOCHASTIC', 'waiting'): (0.35, 0.8), ('cologne1', 'STOCHASTIC', 'queue'): (0.4, 0.8),
-    ('cologne3', 'STOCHASTIC', 'delay'): (0.15, 0.6), ('cologne3', 'STOCHASTIC', 'duration'): (0.2, 0.6),
-    ('cologne3', 'STOCHASTIC', 'waiting'): (0.1, 0.5), ('cologne3', 'STOCHASTIC', 'queue'): (0.3, 0.8),
-    ('ingolstadt7', 'STOCHASTIC', 'delay'): (0.6, 1.0), ('cologne8', 'STOCHASTIC', 'waiting'): (0.6, 1.1),
+# Cells that are KNOWN to be outside the default band.  They are NOT part of the pass criterion of test_reference_result_bands (the
+# default band is the only one); test_reference_result_known_gaps asserts the default band for each of them as an expected
+# failure (xfail, non-strict: a model that closes a gap turns it into an XPASS), and the value is an UPPER bound on the ratio --
+# a regression guard only, never a lower bound above 1.
+KNOWN_GAPS = {
+    ('ingolstadt21', 'FIXED', 'delay'): 2.4,            # 2.1 x: profiles/r04_ingolstadt21_approaches.txt, DESIGN.md section 2
+    ('ingolstadt21', 'MAXWAVE', 'delay'): 8.0,          # 6.4 x / 4.4 x as configured: the S approach of TLS 243641585 is never served
+    ('ingolstadt21', 'MAXPRESSURE', 'delay'): 5.5,      #   (valid_acts maps its wave to a phase in which it is red); unreachable on SUMO too
+    ('ingolstadt21', 'MAXPRESSURE*', 'delay'): 1.9,     # 1.58 x with the entry rotated (MAXWAVE*: 1.15 x, inside the default band)
+    ('cologne1', 'STOCHASTIC', 'delay'): None,          # 0.68 x: at the edge of the band
+    ('cologne1', 'STOCHASTIC', 'duration'): None, ('cologne1', 'STOCHASTIC', 'waiting'): None, ('cologne1', 'STOCHASTIC', 'queue'): None,
+    ('cologne3', 'STOCHASTIC', 'delay'): None, ('cologne3', 'STOCHASTIC', 'duration'): None,
+    ('cologne3', 'STOCHASTIC', 'waiting'): None, ('cologne3', 'STOCHASTIC', 'queue'): None,
 }
 MAXD = {'FIXED': 200, 'MAXWAVE': 50, 'MAXPRESSURE': 200, 'STOCHASTIC': 200}
 
@@ -883,31 +887,24 @@ def _episode_metrics(sc, policy, n_envs=64, seed=0):
     return m
 
 
-@pytest.mark.parametrize('name', ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'])
-def test_reference_result_bands(name):
-    """64 environments x one whole episode of FIXED / MAXWAVE / MAXPRESSURE / STOCHASTIC on the device against every figure the
-    reference holds for them (delay for all four, duration / waitingTime / queue for the random policy, the free-flow
-    residual for the routes): all 24 delay cells and 18 more are asserted, none skipped."""
+_BAND_CACHE = {}
+
+
+def _band_cells(name):
+    """every (policy, metric, value, reference figure) cell of one map: 64 environments x one whole episode per controller"""
+    if name in _BAND_CACHE:
+        return _BAND_CACHE[name]
     import copy
     sc = load_scenario(name)
     ref = _ref_bands()[name]
-    failures, lines = [], []
-
-    def check(policy, metric, value, target):
-        band = EXCEPT.get((name, policy, metric), (0.9, 1.1) if metric == 'free_flow' else BAND)
-        ratio = value / target
-        lines.append('band %-12s %-12s %-9s %8.2f / %8.2f = %.2f  [%.2f, %.2f]' % (name, policy, metric, value, target, ratio, band[0], band[1]))
-        if not band[0] <= ratio <= band[1]:
-            failures.append(lines[-1])
-
-    med = {}
+    cells, med = [], {}
     for policy in ('FIXED', 'MAXWAVE', 'MAXPRESSURE', 'STOCHASTIC'):
         m = _episode_metrics(sc, policy)
         med[policy] = {k: float(np.median(v)) for k, v in m.items()}
-        check(policy, 'delay', med[policy]['delay'], ref[policy]['delay'])
+        cells.append((policy, 'delay', med[policy]['delay'], ref[policy]['delay']))
         if policy == 'STOCHASTIC':
             for metric in ('duration', 'waiting', 'queue'):
-                check(policy, metric, med[policy][metric], ref[policy][metric])
+                cells.append((policy, metric, med[policy][metric], ref[policy][metric]))
     if name == 'ingolstadt21':
         sc2 = copy.copy(sc)
         sc2.valid_acts = dict(sc.valid_acts)
@@ -915,13 +912,13 @@ def test_reference_result_bands(name):
         for policy in ('MAXWAVE*', 'MAXPRESSURE*'):
             m = _episode_metrics(sc2, policy)
             med[policy] = {k: float(np.median(v)) for k, v in m.items()}
-            check(policy, 'delay', med[policy]['delay'], ref[policy.rstrip('*')]['delay'])
+            cells.append((policy, 'delay', med[policy]['delay'], ref[policy.rstrip('*')]['delay']))
     # The travel time of the routes at the speed limits: duration - (timeLoss + departDelay), the reference's figure from
     # its trained IDQN episodes.  Comparable when (nearly) all trips finish: under the map's best static controller, or --
     # ingolstadt21, which no static controller keeps fluid -- with every fourth trip only (FIXED programme).  Band +-10 %.
     if name != 'ingolstadt21':
         best = min(('MAXWAVE', 'MAXPRESSURE'), key=lambda p: med[p]['delay'])
-        check(best, 'free_flow', med[best]['duration'] - med[best]['delay'], ref['free_flow_residual'])
+        cells.append((best, 'free_flow', med[best]['duration'] - med[best]['delay'], ref['free_flow_residual']))
     else:
         sc3 = copy.copy(sc)
         sc3.arrays = dict(sc.arrays)
@@ -932,9 +929,46 @@ def test_reference_result_bands(name):
         np.add.at(cum, sc3.arrays['trip_depart'][sc3.arrays['trip_depart'] <= sc.horizon], 1)
         sc3.arrays['trips_cum'] = np.cumsum(cum).astype(np.int32)
         m = {k: float(np.median(v)) for k, v in _episode_metrics(sc3, 'FIXED').items()}
-        check('FIXED/4', 'free_flow', m['duration'] - m['delay'], ref['free_flow_residual'])
+        cells.append(('FIXED/4', 'free_flow', m['duration'] - m['delay'], ref['free_flow_residual']))
+    _BAND_CACHE[name] = cells
+    return cells
+
+
+@pytest.mark.parametrize('name', ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'])
+def test_reference_result_bands(name):
+    """64 environments x one whole episode of FIXED / MAXWAVE / MAXPRESSURE / STOCHASTIC on the device against every figure the
+    reference holds for them (delay for all four, duration / waitingTime / queue for the random policy, the free-flow residual
+    for the routes).  ONE pass criterion: the default band (+-35 %; +-10 % for the free-flow residual).  The cells listed in
+    KNOWN_GAPS are reported and only guarded from above here; test_reference_result_known_gaps holds them to the default band as
+    expected failures."""
+    failures, lines = [], []
+    for policy, metric, value, target in _band_cells(name):
+        ratio = value / target
+        key = (name, policy, metric)
+        band = (0.9, 1.1) if metric == 'free_flow' else BAND
+        if key in KNOWN_GAPS:
+            ub = KNOWN_GAPS[key]
+            lines.append('band %-12s %-12s %-9s %8.2f / %8.2f = %.2f  KNOWN GAP (default band [%.2f, %.2f]%s)' % (
+                name, policy, metric, value, target, ratio, band[0], band[1], '; guard: ratio <= %.1f' % ub if ub else ''))
+            if ub is not None and ratio > ub:
+                failures.append(lines[-1])
+            continue
+        lines.append('band %-12s %-12s %-9s %8.2f / %8.2f = %.2f  [%.2f, %.2f]' % (name, policy, metric, value, target, ratio, band[0], band[1]))
+        if not band[0] <= ratio <= band[1]:
+            failures.append(lines[-1])
     print('\n'.join(lines))
     assert not failures, failures
+
+
+@pytest.mark.parametrize('cell', sorted(KNOWN_GAPS), ids=lambda c: '-'.join(c))
+@pytest.mark.xfail(strict=False, reason='known fidelity gap of the own microsimulation model against the reference-held SUMO figures (DESIGN.md section 2)')
+def test_reference_result_known_gaps(cell):
+    name, policy, metric = cell
+    for p, m, value, target in _band_cells(name):
+        if (p, m) == (policy, metric):
+            assert BAND[0] <= value / target <= BAND[1], (cell, value, target, value / target)
+            return
+    raise AssertionError('no such cell: %r' % (cell,))
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs 4 and 5
@@ -1244,7 +1278,35 @@ def test_bench_runs_through_rccl_at_one_gpu():
     assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0]          # one JSON line, and it is the last one
     line = json.loads(lines[0])
     assert line['n_gpus'] == 1 and line['steps'] == 6 and line['value'] > 0 and line['roofline']['frac'] > 0
+    assert line['config']['pipes'] == 2 and line['roofline']['concurrent_launches'] == 2 and line['roofline']['env_steps_per_launch'] == 128
+    assert line['all_outputs']['value'] > 0
     assert line['config']['episode_window'][1] - line['config']['episode_window'][0] == 6
+
+
+def test_two_ranks_through_bench_on_one_gpu():
+    """The N > 1 launch of the contract (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) end to end
+    through the real HIP path where no multi-GPU node exists: two ranks, both on device 0 (RESCO_BENCH_DEVICE), gloo rendezvous
+    (RESCO_BENCH_BACKEND), each with two pipes, the NUMA binding executed.  The union of the two shards (global environment index
+    = rank * envs + local index) must equal ONE process stepping the 2N batch: the state digests over all environments agree."""
+    import json
+    import subprocess
+    port = 29600 + (os.getpid() % 300)
+    common = ['--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--digest']
+    env = dict(os.environ, RESCO_BENCH_DEVICE='0', RESCO_BENCH_BACKEND='gloo')
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--envs', '128'] + common,
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1                                         # rank 0 prints the one line
+    a = json.loads(lines[0])
+    assert a['n_gpus'] == 2 and a['config']['envs_per_gpu'] == 128 and a['config']['pipes'] == 2 and a['value'] > 0
+    assert a['scaling'] == 'weak' and 'x2' in a['config']['parallelism']
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--envs', '256', '--pipes', '1'] + common,
+                         env=dict(os.environ), capture_output=True, text=True, timeout=170)
+    assert one.returncode == 0, one.stderr[-2000:]
+    b = json.loads([l for l in one.stdout.strip().splitlines() if l.startswith('{"metric"')][0])
+    assert a['state_digest'] == b['state_digest']
 
 
 def test_arrival_departure_counters_and_mplight_full_batched():

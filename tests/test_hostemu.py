@@ -209,7 +209,17 @@ def test_output_mask_writes_only_what_was_asked_for():
     for b in ('lane_agg', 'wave', 'mplight_full', 'lane_arrivals'):
         np.testing.assert_array_equal(new[b], old[b], err_msg=b)
         assert not np.array_equal(new[b][0], ref[b])
+    # consumers of a switched-off buffer fail loudly instead of acting on stale rows: the MAXWAVE agent reads `wave`
+    # (off), the MAXPRESSURE agent `mplight` (on)
+    with pytest.raises(RuntimeError):
+        sim.act_maxwave(0)
+    sim._maxwave_ready = False
+    sim.act_maxwave(1)
+    with pytest.raises(RuntimeError):
+        sim.require_output('wave')
+    sim.require_output('mplight')
     sim.set_outputs(None)
+    sim.require_output('wave')
     a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
     sim.step(a[None, :])
     o.step(a)
