@@ -44,37 +44,44 @@ __device__ __forceinline__ uint32_t pol_hash(uint32_t seed, uint32_t a, uint32_t
     return d_hash(seed, a, b, c, d);
 }
 
-// HP (k-steps of 8 per conv channel = ceil(H / 2)) is a template parameter: the eight k-steps become straight-line
-// code, so the LDS fragment reads of later steps are issued ahead of the MFMAs of earlier ones
+struct PolicySmem {
+    __attribute__((aligned(16))) _Float16 xs[POL_TM][18][8];       // obs tile, rows padded to 8 halfs, +1 zero row
+    __attribute__((aligned(16))) _Float16 ys[2][32][POL_C + 8];    // per wave: activations for the next layer's A fragments
+    float qs[2][32][POL_QMAX];
+    __attribute__((aligned(16))) h4_t wbuf[2 * 8 * 2 * 64];        // fc1 fragments of two conv channels
+};
+
+// HP = the k-steps of 8 per conv channel THIS signal needs (ceil((lanes_s - 1) / 2)) as a template parameter: the k-steps become
+// straight-line code, so the LDS fragment reads of later steps are issued ahead of the MFMAs of earlier ones.  The packed fc1
+// fragments keep the layout of the widest signal (W.hp k-steps per channel); a narrower signal reads the first HP of them -- the
+// others belong to padded lanes, whose fc1 rows are zero: skipping them changes no result.
 template <int HP>
-__global__ void __launch_bounds__(128)
-rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, int mode, float eps, uint32_t seed, uint32_t step_key,
-                       const uint32_t *__restrict__ dyn, int32_t *__restrict__ actions, float *__restrict__ q_out) {
-    // dyn != NULL: epsilon (float bits) and step key come from device memory, so that a captured HIP graph of the
-    // env-step can be replayed with values an earlier node of the same graph computed
-    if (dyn) { eps = __uint_as_float(dyn[0]); step_key = dyn[1]; }
-    __shared__ __attribute__((aligned(16))) _Float16 xs[POL_TM][18][8];       // obs tile, rows padded to 8 halfs, +1 zero row
-    __shared__ __attribute__((aligned(16))) _Float16 ys[2][32][POL_C + 8];    // per wave: activations for the next layer's A fragments
-    __shared__ float qs[2][32][POL_QMAX];
-    __shared__ __attribute__((aligned(16))) h4_t wbuf[2 * 8 * 2 * 64];        // fc1 fragments of two conv channels
+__device__ __forceinline__ void
+idqn_forward_body(PolicySmem &sm, const PolicyTab &W, const __half *__restrict__ obs, int n_envs, int mode, float eps, uint32_t seed,
+                  uint32_t step_key, int32_t *__restrict__ actions, float *__restrict__ q_out) {
+    auto &xs = sm.xs; auto &ys = sm.ys; auto &qs = sm.qs; auto &wbuf = sm.wbuf;
     const int s = blockIdx.y;
     const int m0 = blockIdx.x * POL_TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, g = lane >> 5;
     const int LM = W.lmax, H = LM - 1;
-    // the signal's own head size: its fc1 rows beyond (lanes_s - 1) * 4 per channel are zero (padded lanes), so the k-steps
-    // beyond hps add exactly 0.0 to the accumulators and are skipped -- a wave-uniform bound (one signal per workgroup)
-    const int hps = __builtin_amdgcn_readfirstlane(W.hp_sig[s]);
 
-    // ---- stage the observation tile: [64 envs][LM][5] halfs, contiguous per env -> xs[env][row][0..4]
-    for (int e = tid; e < POL_TM * 18 * 8; e += 128) ((_Float16 *)xs)[e] = (_Float16)0.0f;
-    __syncthreads();
-    for (int e = tid; e < POL_TM * LM * 5; e += 128) {
-        const int m = e / (LM * 5), r = e - m * (LM * 5);
-        if (m0 + m < n_envs) {
-            const __half v = obs[((size_t)(m0 + m) * W.S + s) * LM * 5 + r];
-            xs[m][r / 5][r % 5] = *(const _Float16 *)&v;
+    // ---- stage the observation tile: [64 envs][LM][5] halfs, contiguous per env -> xs[env][row][0..7] (five values + zeros).
+    //      One thread per (env, row): five 2-byte loads, ONE 16-byte LDS store that also clears the row's padding.  Only the rows
+    //      this signal's k-steps read (0 .. 2 HP) are staged; rows the tensor does not have, and environments beyond the batch,
+    //      are zero.
+    constexpr int NR = 2 * HP + 1;
+    const int nrow = LM < NR ? LM : NR;
+    for (int p = tid; p < POL_TM * NR; p += 128) {
+        const int m = p / NR, row = p - m * NR;
+        union { uint4 q; _Float16 h[8]; } u;
+        u.q = uint4{0u, 0u, 0u, 0u};
+        if (row < nrow && m0 + m < n_envs) {
+            const _Float16 *src = (const _Float16 *)obs + ((size_t)(m0 + m) * W.S + s) * LM * 5 + row * 5;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) u.h[j] = src[j];
         }
+        *(uint4 *)&xs[m][row][0] = u.q;
     }
     __syncthreads();
 
@@ -101,26 +108,24 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
     f16x_t acc0 = {0}, acc1 = {0};
     const float *cw = W.conv_w + (size_t)s * POL_C * 4;
     const float *cb = W.conv_b + (size_t)s * POL_C;
-    constexpr int chunk16 = HP * 64;                                // 16-byte units per channel: HP * 2 * 64 * 8 B / 16
-    constexpr int NQ = (chunk16 + 127) / 128;                       // copy passes of the 128 threads (the last one may run
+    const int chunk16 = W.hp * 64;                                  // 16-byte units per channel in memory: W.hp * 2 * 64 * 8 B / 16
+    constexpr int NQ = (HP * 64 + 127) / 128;                       // copy passes of the 128 threads (the last one may run
                                                                     // past the channel: the allocation and wbuf are padded)
-    const uint4 *w1g = (const uint4 *)(W.w1 + (size_t)s * POL_C * HP * 2 * 64);
+    const uint4 *w1g = (const uint4 *)(W.w1 + (size_t)s * POL_C * W.hp * 2 * 64);
     uint4 *wbuf16 = (uint4 *)wbuf;
-    const int nq = (hps * 64 + 127) >> 7;                           // copy passes that carry this signal's k-steps
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) if (q < nq) wbuf16[tid + q * 128] = w1g[tid + q * 128];
+    for (int q = 0; q < NQ; ++q) wbuf16[tid + q * 128] = w1g[tid + q * 128];
     __syncthreads();
     for (int c = 0; c < POL_C; ++c) {
         uint4 nxt[NQ];
         const uint4 *gn = w1g + (size_t)(c + 1 < POL_C ? c + 1 : c) * chunk16 + tid;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) if (q < nq) nxt[q] = gn[q * 128];          // in flight while this channel is multiplied
+        for (int q = 0; q < NQ; ++q) nxt[q] = gn[q * 128];          // in flight while this channel is multiplied
         const _Float16 s00 = (_Float16)cw[c * 4 + 0], s01 = (_Float16)cw[c * 4 + 1], s10 = (_Float16)cw[c * 4 + 2], s11 = (_Float16)cw[c * 4 + 3], sb = (_Float16)cb[c];
         const h2_t h00 = {s00, s00}, h01 = {s01, s01}, h10 = {s10, s10}, h11 = {s11, s11}, hb = {sb, sb}, hz = {(_Float16)0.0f, (_Float16)0.0f};
         const h4_t *wc = wbuf + (size_t)(c & 1) * (8 * 2 * 64) + lane;
 #pragma unroll
         for (int kk = 0; kk < HP; ++kk) {
-            if (kk >= hps) break;
             // features (w = 0,1) and (w = 2,3) of row h: rows beyond H give relu(bias), harmless (zero fc1 weights)
             h2_t f01 = __builtin_elementwise_fma(h00, p0[kk][0], hb), f23 = __builtin_elementwise_fma(h00, p0[kk][2], hb);
             f01 = __builtin_elementwise_fma(h01, p0[kk][1], f01); f23 = __builtin_elementwise_fma(h01, p0[kk][3], f23);
@@ -134,7 +139,7 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
         }
         uint4 *dst = wbuf16 + (size_t)((c + 1) & 1) * (8 * 2 * 64 / 2) + tid;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) if (q < nq) dst[q * 128] = nxt[q];
+        for (int q = 0; q < NQ; ++q) dst[q * 128] = nxt[q];
         __syncthreads();
     }
 
@@ -217,5 +222,26 @@ rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, 
             if (q_out)
                 for (int a = 0; a < POL_QMAX; ++a) q_out[((size_t)m * W.S + s) * POL_QMAX + a] = a < na ? qs[wave][lane][a] : -INFINITY;
         }
+    }
+}
+
+// One workgroup = one signal: the body is chosen by the signal's own head size (a workgroup-uniform switch).  W.hp_sig[s] == W.hp
+// for every signal until rs_idqn_set_lanes has told the library the networks' real input sizes.
+__global__ void __launch_bounds__(128)
+rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, int mode, float eps, uint32_t seed, uint32_t step_key,
+                       const uint32_t *__restrict__ dyn, int32_t *__restrict__ actions, float *__restrict__ q_out) {
+    // dyn != NULL: epsilon (float bits) and step key come from device memory, so that a captured HIP graph of the
+    // env-step can be replayed with values an earlier node of the same graph computed
+    if (dyn) { eps = __uint_as_float(dyn[0]); step_key = dyn[1]; }
+    __shared__ PolicySmem sm;
+    switch (__builtin_amdgcn_readfirstlane(W.hp_sig[blockIdx.y])) {
+        case 1: idqn_forward_body<1>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        case 2: idqn_forward_body<2>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        case 3: idqn_forward_body<3>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        case 4: idqn_forward_body<4>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        case 5: idqn_forward_body<5>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        case 6: idqn_forward_body<6>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        case 7: idqn_forward_body<7>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        default: idqn_forward_body<8>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
     }
 }

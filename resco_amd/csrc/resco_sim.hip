@@ -100,6 +100,12 @@ struct DevExec {
     }
     // tid / 64 as a wave-uniform value: what is derived from it (the roles of the waves inside a phase) stays in scalar registers
     __device__ __forceinline__ int wave_of(int tid) const { return __builtin_amdgcn_readfirstlane(tid >> 6); }
+    // the next work chunk of this wave: one LDS atomic per wave (called with the wave converged), broadcast from its first lane
+    __device__ __forceinline__ int next_chunk(int32_t *ctr, int, int, int) const {
+        int c = 0;
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(ctr, 1);
+        return __builtin_amdgcn_readfirstlane(c);
+    }
     // time a wave spends in one role of a phase: sum of the 100 MHz ticks in the low 40 bits, number of waves above
     __device__ __forceinline__ unsigned long long role_begin() const { return prof ? wall_clock64() : 0ull; }
     __device__ __forceinline__ void role_end(int id, unsigned long long start) const {
@@ -783,11 +789,7 @@ extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, 
                            const void *dyn, int32_t *actions, float *q, void *stream) {
     if (!p || !obs || !actions || n_envs <= 0 || mode < 0 || mode > 1) return RS_EINVAL;
     if (hipSetDevice(p->device) != hipSuccess) return RS_EHIP;
-    typedef void (*pol_fn)(PolicyTab, const __half *, int, int, float, uint32_t, uint32_t, const uint32_t *, int32_t *, float *);
-    static const pol_fn kernels[9] = {nullptr, rs_idqn_forward_kernel<1>, rs_idqn_forward_kernel<2>, rs_idqn_forward_kernel<3>,
-                                      rs_idqn_forward_kernel<4>, rs_idqn_forward_kernel<5>, rs_idqn_forward_kernel<6>,
-                                      rs_idqn_forward_kernel<7>, rs_idqn_forward_kernel<8>};
-    hipLaunchKernelGGL(kernels[p->W.hp], dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(128), 0, (hipStream_t)stream,
                        p->W, (const __half *)obs, (int)n_envs, (int)mode, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_EHIP;
 }

@@ -7,6 +7,9 @@
 //   ex.role_begin/role_end  optional timers of what one WAVE does inside a phase (ids 3, 7-10, 15)
 //   ex.B                    threads per workgroup (a multiple of 64)
 //   ex.wave_of(tid)         tid / 64, known to be the same for the 64 threads of a wave (a scalar on the GPU)
+//   ex.next_chunk(c, w, i, n)  the next work chunk of wave w (its i-th call in this phase, n waves): on the GPU ONE atomic on the LDS
+//                           counter c per wave (dynamic: whichever wave is free takes the next chunk), on the host i * n + w --
+//                           any assignment of chunks to waves gives the same result, a phase being order independent
 // On the GPU (resco_sim.hip) one workgroup = one environment; the state lives in LDS for the whole env-step and phase() is
 // `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same source for the host (tests/hostemu), where
 // phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never reads what another thread writes in the same
@@ -203,7 +206,16 @@ struct Lds {
 #define SC_NH 7         // entries of ls_h (may exceed lcap: overflow)
 #define SC_NLC 8
 #define SC_NMH 9        // two counters, by tick parity (the plan of tick t + 1 queues while nothing separates it from the move of t)
-#define SC_STATS 11
+#define SC_CHUNK_P 11    // next work chunk of the plan phase / of the move phase (wave-level tickets, reset in C)
+#define SC_CHUNK_M 12
+#define SC_STATS 13
+// entries of a long-path work list one wave takes at a time.  Measured on the MI355X (profiles/r04_ab_chunks.txt, ingolstadt21 x 4096):
+// 64 entries 1.665 ms per launch -- exactly what the fixed roles of round 3 took --, 48: 1.674, 32: 1.784, 16: 2.109.  Handing the
+// chunks out dynamically does not shorten the phases: they are not bound by the slowest role but by what all waves of the CU
+// issue together.
+#ifndef RS_LIST_CHUNK
+#define RS_LIST_CHUNK 64
+#endif
 
 RS_CARVE size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // Layout of the working memory: a table of offsets computed once by the host (read from the constant argument block, so an
@@ -1062,32 +1074,48 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
         ex.phase(4, [&](int tid) {
             const int wv = ex.wave_of(tid), ln = tid & 63;          // (the wave index is wave-uniform: the role variables stay scalar)
             const int nh = L.sc[SC_NH], nlc = L.sc[SC_NLC];
-            int hwv = (nh + 63) >> 6, lwv = (nlc + 63) >> 6;            // waves for the look-ahead list, the lane-change list
-            // a list overflowed, or the lists leave no wave for the slots: every thread handles its slots in full, in two passes
-            const bool all = nh > lcap || nlc > lcap || hwv + lwv >= nwv;
             const unsigned long long r0 = ex.role_begin();
             int role = 0;
-            for (int pass = 0; pass < (all ? 2 : 1); ++pass) {
-                int kind, w0, stride, lim;                              // kind 0: plan of a slot, 1: plan from the list, 2: lane change
-                if (all) { kind = pass ? 2 : 0; w0 = tid; stride = B; lim = hw; }
-                else if (wv < hwv) { kind = 1; w0 = wv * 64 + ln; stride = hwv * 64; lim = nh; }
-                else if (wv < hwv + lwv) { kind = 2; w0 = (wv - hwv) * 64 + ln; stride = lwv * 64; lim = nlc; }
-                else { kind = 0; w0 = (wv - hwv - lwv) * 64 + ln; stride = (nwv - hwv - lwv) * 64; lim = hw; }
-                role = kind;
-                for (int w = w0; w < lim; w += stride) {
-                    int s = w;
-                    if (kind == 1) s = L.ls_h[w];
-                    else if (kind == 2 && !all) s = L.ls_lc[w];
-                    else {
-                        const int f = L.node[w].fl;
-                        if (kind == 0 ? (!all && (f & FL_H)) : !(f & FL_LC)) continue;
+            if (nh > lcap || nlc > lcap) {
+                // a list overflowed: every thread handles its slots in full (the flags, not the lists, carry the meaning), in two passes
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int w = tid; w < hw; w += B) {
+                        if (pass && !(L.node[w].fl & FL_LC)) continue;
+                        if (pass) {
+                            const Aux ax = L.aux[w];
+                            if (ax.lane == LANE_NONE) continue;
+                            const int code = phase_lc_decide(T, L, gold, G, eo, t, w, ax, L.node[w]);
+                            if (code) flag_mover(L, w, t, code);
+                        } else phase_plan(T, L, gold, G, eo, P, genv, t, w);
                     }
-                    if (kind == 2) {
-                        const Aux ax = L.aux[s];
-                        if (ax.lane == LANE_NONE) continue;
-                        const int code = phase_lc_decide(T, L, gold, G, eo, t, s, ax, L.node[s]);
-                        if (code) flag_mover(L, s, t, code);
-                    } else phase_plan(T, L, gold, G, eo, P, genv, t, s);
+            } else {
+                // The work of the phase in chunks, longest code path first: the look-ahead list (RS_LIST_CHUNK entries per chunk), the
+                // lane-change list, then the slots on the short path (64 per chunk).  A wave takes the next chunk when it is done
+                // with its last one, so the phase ends when the work is done, not when the slowest of three fixed roles is.
+                const int hch = (nh + RS_LIST_CHUNK - 1) / RS_LIST_CHUNK, lch = (nlc + RS_LIST_CHUNK - 1) / RS_LIST_CHUNK;
+                const int total = hch + lch + ((hw + 63) >> 6);
+                for (int it = 0;; ++it) {
+                    const int c = ex.next_chunk(&L.sc[SC_CHUNK_P], wv, it, nwv);
+                    if (c >= total) break;
+                    if (c < hch) {                                  // plan of a vehicle that looks beyond its lane
+                        role = 1;
+                        const int w = c * RS_LIST_CHUNK + ln;
+                        if (ln < RS_LIST_CHUNK && w < nh) phase_plan(T, L, gold, G, eo, P, genv, t, L.ls_h[w]);
+                    } else if (c < hch + lch) {                     // lane-change decision
+                        role = 2;
+                        const int w = (c - hch) * RS_LIST_CHUNK + ln;
+                        if (ln < RS_LIST_CHUNK && w < nlc) {
+                            const int s = L.ls_lc[w];
+                            const Aux ax = L.aux[s];
+                            if (ax.lane != LANE_NONE) {
+                                const int code = phase_lc_decide(T, L, gold, G, eo, t, s, ax, L.node[s]);
+                                if (code) flag_mover(L, s, t, code);
+                            }
+                        }
+                    } else {                                        // plan on the short path
+                        const int w = (c - hch - lch) * 64 + ln;
+                        if (w < hw && !(L.node[w].fl & FL_H)) phase_plan(T, L, gold, G, eo, P, genv, t, w);
+                    }
                 }
             }
             ex.role_end(role == 1 ? 7 : (role == 2 ? 8 : 9), r0);
@@ -1106,67 +1134,76 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 L.sc[SC_ROOM] = C - L.sc[SC_NACT];
                 L.sc[SC_NH] = 0; L.sc[SC_NLC] = 0;              // the move phase queues the next tick's lists
                 L.sc[SC_NMH + ((t + 1) & 1)] = 0;               // the next plan phase queues the next tick's movers
+                L.sc[SC_CHUNK_P] = 0; L.sc[SC_CHUNK_M] = 0;     // (nobody takes tickets during C)
             }
         });
         ex.phase(6, [&](int tid) {
             int active = 0, halted = 0, top = 0;
-            // the first waves take the list of the vehicles that leave their lane, the last one the insertions (when there are
-            // any), the others share the slots
+            // chunks again, longest first: the vehicles that leave their lane (list), the insertions (one chunk, when there are
+            // any), then the slots
             const int wv = ex.wave_of(tid), ln = tid & 63;
             const int nmh = L.sc[SC_NMH + (t & 1)];
-            int mwv = (nmh + 63) >> 6, iwv = 0;
-            for (int i = 0; i < (T.n_dep + 31) / 32; ++i) if (L.insm[i]) iwv = 1;
-            const bool all = nmh > lcap || mwv + iwv >= nwv;
-            if (all) { mwv = 0; iwv = 0; }
-            const bool list = wv < mwv, ins = all || wv >= nwv - iwv;
-            const int nsw = nwv - mwv - iwv;                // waves that share the slots
-            const int w0 = (list ? wv : wv - mwv) * 64 + ln, stride = (list ? mwv : nsw) * 64, lim = list ? nmh : ((ins && !all) ? 0 : hw);
+            int ich = 0;
+            for (int i = 0; i < (T.n_dep + 31) / 32; ++i) if (L.insm[i]) ich = 1;
+            const bool all = nmh > lcap;
+            const int mch = all ? 0 : (nmh + RS_LIST_CHUNK - 1) / RS_LIST_CHUNK;
+            const int total = mch + ich + ((hw + 63) >> 6);
             const unsigned long long r0 = ex.role_begin();
-            for (int w = w0; w < lim; w += stride) {
-                int s = w;
-                if (list) s = L.ls_mh[w];
-                else if (!(L.alive0[w >> 5] & (1u << (w & 31))) || (!all && (L.node[w].fl & fl_mh(t)))) continue;
-                phase_move(T, L, gold, gnew, G, P, env, eo, t, !more, more, s, active, halted, top);
+            bool list = false;
+            for (int it = 0;; ++it) {
+                const int c = ex.next_chunk(&L.sc[SC_CHUNK_M], wv, it, nwv);
+                if (c >= total) break;
+                if (c < mch) {
+                    list = true;
+                    const int w = c * RS_LIST_CHUNK + ln;
+                    if (ln < RS_LIST_CHUNK && w < nmh) phase_move(T, L, gold, gnew, G, P, env, eo, t, !more, more, L.ls_mh[w], active, halted, top);
+                } else if (c < mch + ich) {
+                    // the winners of the departure lanes take the slots that were free at the beginning of the tick, lower lane first
+                    for (int d = 63 - ln; d < T.n_dep; d += 64) {
+                        if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
+                        int rank = rs_popc(L.insm[d >> 5] & ((1u << (d & 31)) - 1u));
+                        for (int w = 0; w < (d >> 5); ++w) rank += rs_popc(L.insm[w]);
+                        if (rank >= L.sc[SC_ROOM]) continue;            // the network is full
+                        const int s = nth_free_slot(L, C, rank);
+                        if (s < 0) continue;
+                        const int k = L.dep[d];
+                        const int v = T.trip_vtype()[k];
+                        const float *vt = L.vtp + v * VT_COLS;
+                        const RouteRec RR = T.routes()[T.trip_route()[k]];
+                        const LaneRec LRd = T.lanes()[RR.depart_lane];
+                        const int sfq = speed_factor_q(P, genv, k, vt);
+                        const float sfn = sf_of(sfq);
+                        Node nn; nn.pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
+                        nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.sfq = (uint16_t)sfq;
+                        nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(nn.pos, lane_cells(LRd)), s, false);
+                        if (more) nn.fl = (uint8_t)classify(L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, cont_row(T, (int)RR.start), k, sfn, t + 1);
+                        L.node[s] = nn;
+                        Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.swait = 0;
+                        na.nlink = cache_link(T, LRd, RR.depart_lane, (int)RR.start, k);
+                        L.aux[s] = na;
+                        G.sf()[eo + s] = sfn; G.tloss()[eo + s] = 0.0f; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE; G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE;
+                        G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
+                        {
+                            const int k2 = T.cold.trip_next[k];
+                            L.dep[d] = (uint16_t)k2;
+                            L.dep_t[d] = k2 == (int)TRIP_NONE ? (uint16_t)0xFFFF : (uint16_t)T.cold.trip_depart[k2];
+                        }
+                        rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
+                        rs_atomic_add(&L.sc[SC_NACT], 1);
+                        rs_atomic_add(&L.sc[SC_NINS], 1);
+                        rs_atomic_add(&L.sc[SC_STATS + ST_INSERTED], 1);
+                        rs_atomic_add(&L.sc[SC_STATS + ST_DEPDELAY], t - T.cold.trip_depart[k]);
+                        if (s + 1 > top) top = s + 1;
+                        // (a standing vehicle does not register an approach)
+                    }
+                } else {
+                    const int w = (c - mch - ich) * 64 + ln;
+                    // (the vehicles of the list have FL_MH of this tick's parity set: their chunk moves them)
+                    if (w < hw && (L.alive0[w >> 5] & (1u << (w & 31))) && (all || !(L.node[w].fl & fl_mh(t))))
+                        phase_move(T, L, gold, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
+                }
             }
             ex.role_end(list ? 10 : 3, r0);
-            // the winners of the departure lanes take the slots that were free at the beginning of the tick, lower lane first
-            for (int d = all ? B - 1 - tid : 63 - ln; ins && d < T.n_dep; d += all ? B : 64) {
-                if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
-                int rank = rs_popc(L.insm[d >> 5] & ((1u << (d & 31)) - 1u));
-                for (int w = 0; w < (d >> 5); ++w) rank += rs_popc(L.insm[w]);
-                if (rank >= L.sc[SC_ROOM]) continue;            // the network is full
-                const int s = nth_free_slot(L, C, rank);
-                if (s < 0) continue;
-                const int k = L.dep[d];
-                const int v = T.trip_vtype()[k];
-                const float *vt = L.vtp + v * VT_COLS;
-                const RouteRec RR = T.routes()[T.trip_route()[k]];
-                const LaneRec LRd = T.lanes()[RR.depart_lane];
-                const int sfq = speed_factor_q(P, genv, k, vt);
-                const float sfn = sf_of(sfq);
-                Node nn; nn.pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
-                nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.sfq = (uint16_t)sfq;
-                nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(nn.pos, lane_cells(LRd)), s, false);
-                if (more) nn.fl = (uint8_t)classify(L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, cont_row(T, (int)RR.start), k, sfn, t + 1);
-                L.node[s] = nn;
-                Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.swait = 0;
-                na.nlink = cache_link(T, LRd, RR.depart_lane, (int)RR.start, k);
-                L.aux[s] = na;
-                G.sf()[eo + s] = sfn; G.tloss()[eo + s] = 0.0f; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE; G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE;
-                G.rwait()[eo + s] = 0; G.owner()[eo + s] = OWNER_NONE; G.depart()[eo + s] = (uint16_t)(t + 1); G.accel()[eo + s] = 0.0f; G.wtot()[eo + s] = 0;
-                {
-                    const int k2 = T.cold.trip_next[k];
-                    L.dep[d] = (uint16_t)k2;
-                    L.dep_t[d] = k2 == (int)TRIP_NONE ? (uint16_t)0xFFFF : (uint16_t)T.cold.trip_depart[k2];
-                }
-                rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
-                rs_atomic_add(&L.sc[SC_NACT], 1);
-                rs_atomic_add(&L.sc[SC_NINS], 1);
-                rs_atomic_add(&L.sc[SC_STATS + ST_INSERTED], 1);
-                rs_atomic_add(&L.sc[SC_STATS + ST_DEPDELAY], t - T.cold.trip_depart[k]);
-                if (s + 1 > top) top = s + 1;
-                // (a standing vehicle does not register an approach)
-            }
             rs_wave_add(&L.sc[SC_STATS + ST_ACTIVE_TICKS], active);
             rs_wave_add(&L.sc[SC_STATS + ST_WAITING], halted);
             rs_wave_max(&L.sc[cur ? SC_HW : SC_HWNEW], top);

@@ -74,6 +74,9 @@ struct HostExec {
     unsigned long long role_begin() const { return 0ull; }
     void role_end(int, unsigned long long) const {}
     int wave_of(int tid) const { return tid >> 6; }
+    // chunk of work for wave w on its i-th call in a phase (n waves): the GPU hands chunks out dynamically; here a fixed
+    // assignment that depends on the thread order under test -- every chunk goes to exactly one wave either way
+    int next_chunk(int32_t *, int w, int i, int n) const { return i * n + (order == 0 ? w : (order == 1 ? n - 1 - w : (w + n / 2 + 1) % n)); }
     int B;
     int order;          // 0 ascending, 1 descending, 2 shuffled (a different permutation in every phase)
     uint32_t rng = 12345u;

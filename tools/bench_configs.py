@@ -19,31 +19,46 @@ from resco_amd.scenario import Scenario      # noqa: E402
 from resco_amd.sim import BatchedSim         # noqa: E402
 
 
-def run(name, n, policy, steps=360, warm=0, fixed=0):
+def run(name, n, policy, steps=360, warm=0, fixed=0, pipes=1):
+    """`pipes` handles of n / pipes environments each, every one stepping on its own HIP stream (bench.py --pipes)"""
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
-    sim = BatchedSim(sc, n, seed=0, fixed_program=fixed)
+    per = n // pipes
+    sims = [BatchedSim(sc, per, seed=0, fixed_program=fixed, env_base=i * per) for i in range(pipes)]
 
     def one(k):
-        if policy == 'maxpressure':
-            sim.act_maxwave(1)
-        elif policy == 'random':
-            sim.act_random(k)
-        sim.step(None)
+        for sim in sims:
+            if policy == 'maxpressure':
+                sim.act_maxwave(1)
+            elif policy == 'random':
+                sim.act_random(k)
+            sim.step(None)
+
+    def sync():
+        for sim in sims:
+            sim.sync()
 
     for k in range(warm):
         one(k)
-    sim.sync()
-    sim.timing(True)
+    sync()
+    for sim in sims:
+        sim.timing(True)
     t0 = time.perf_counter()
     for k in range(warm, warm + steps):
         one(k)
-    sim.sync()
+    sync()
     dt = time.perf_counter() - t0
-    kms, nl = sim.timing_read()
-    st = sim.stats()
-    out = dict(map=name, envs=n, policy=policy, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3,
-               kernel_ms=kms / max(1, nl), mean_active=float((st['active_ticks'] / st['ticks']).mean()), **sim.info())
-    sim.close()
+    kms, nl = 0.0, 0
+    for sim in sims:
+        a, b = sim.timing_read()
+        kms += a
+        nl += b
+    act = sum(float((sim.stats()['active_ticks'] / sim.stats()['ticks']).sum()) for sim in sims) / n
+    info = sims[0].info()
+    info['n_envs'] = n
+    out = dict(map=name, envs=n, pipes=pipes, policy=policy, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3,
+               kernel_ms=kms / max(1, nl), mean_active=act, **info)
+    for sim in sims:
+        sim.close()
     return out
 
 
@@ -68,11 +83,12 @@ def config1():
 
 if __name__ == '__main__':
     print(json.dumps(dict(config=1, **config1())), flush=True)
-    print(json.dumps(dict(config=2, **run('cologne1', 1024, 'maxpressure'))), flush=True)
-    print(json.dumps(dict(config=3, **run('ingolstadt21', 4096, 'random'))), flush=True)
-    print(json.dumps(dict(config=4, **run('cologne8', 2048, 'maxpressure'))), flush=True)
-    print(json.dumps(dict(config=5, **run('ingolstadt21', 1024, 'random'))), flush=True)
+    for pipes in (1, 2):
+        print(json.dumps(dict(config=2, **run('cologne1', 1024, 'maxpressure', pipes=pipes))), flush=True)
+        print(json.dumps(dict(config=3, **run('ingolstadt21', 4096, 'random', pipes=pipes))), flush=True)
+        print(json.dumps(dict(config=4, **run('cologne8', 2048, 'maxpressure', pipes=pipes))), flush=True)
+        print(json.dumps(dict(config=5, **run('ingolstadt21', 1024, 'random', pipes=pipes))), flush=True)
     for n in (16384, 65536):
-        print(json.dumps(dict(config='2x', **run('cologne1', n, 'maxpressure'))), flush=True)
-    print(json.dumps(dict(config='4x', **run('cologne8', 16384, 'maxpressure'))), flush=True)
-    print(json.dumps(dict(config='3x', **run('ingolstadt21', 16384, 'random', steps=120))), flush=True)
+        print(json.dumps(dict(config='2x', **run('cologne1', n, 'maxpressure', pipes=2))), flush=True)
+    print(json.dumps(dict(config='4x', **run('cologne8', 16384, 'maxpressure', pipes=2))), flush=True)
+    print(json.dumps(dict(config='3x', **run('ingolstadt21', 16384, 'random', steps=120, pipes=2))), flush=True)

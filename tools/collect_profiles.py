@@ -10,7 +10,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+PIPES = 2          # bench.py's default: launches per step
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')
 
@@ -24,7 +25,7 @@ def cp(a, b):
 for a, b in (('bench_default.json', 'bench_default.json'), ('bench_driver_window.json', 'bench_driver_window.json'),
              ('bench_under_rocprof.json', 'bench_under_rocprof.json'), ('phase_profile.txt', 'phase_profile.txt'),
              ('phase_profile_one_workgroup_per_cu.txt', 'phase_profile_one_workgroup_per_cu.txt'),
-             ('graph_ab.jsonl', 'graph_ab.jsonl'), ('bench_configs.jsonl', 'bench_configs.jsonl'),
+             ('pipes_ab.jsonl', 'pipes_ab.jsonl'), ('heldout_idqn.txt', 'heldout_idqn.txt'), ('bench_configs.jsonl', 'bench_configs.jsonl'),
              ('reference_bands.txt', 'reference_bands.txt'), ('idqn_rollout.jsonl', 'idqn_rollout.jsonl'), ('prof/%s_kernel_stats.csv' % tag, 'kernel_stats.csv'),
              ('prof_dw/%s_dw_kernel_stats.csv' % tag, 'driver_window_kernel_stats.csv'),
              ('pmc_s300_w60/pmc_summary.json', 'pmc_s300_w60.json'), ('pmc_s20_w5/pmc_summary.json', 'pmc_s20_w5.json'),
@@ -36,13 +37,18 @@ for name, out in (('prof/%s_kernel_trace.csv' % tag, 'kernel_trace_summary.txt')
     if not os.path.exists(p):
         continue
     rows = [r for r in csv.DictReader(open(p)) if 'rs_step_kernel' in r.get('Kernel_Name', '')]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
     dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
+    steps = 20 if '_dw' in name else 300
+    tail = PIPES * min(steps, 20)           # the all-outputs leg bench.py runs after the timed window
+    timed = rows[-(tail + PIPES * steps):-tail]
+    d = dur[-(tail + PIPES * steps):-tail]
+    span = (max(int(r['End_Timestamp']) for r in timed) - min(int(r['Start_Timestamp']) for r in timed)) / 1e6
     with open(os.path.join(dst, '%s_%s' % (tag, out)), 'w') as f:
         f.write('rocprofv3 --kernel-trace of `%s`\n' % ('python bench.py --no-cpu-baseline' + (' --steps 20 --warmup 5' if '_dw' in name else '')))
-        f.write('rs_step_kernel launches: %d (fast-forward + warm-up + timed; the first is the reset observe)\n' % len(dur))
-        for k in ((300, 'last 300 = the timed launches') if '_dw' not in name else (20, 'last 20 = the timed launches'),):
-            d = dur[-k[0]:]
-            f.write('%s: mean %.4f ms, min %.4f, max %.4f\n' % (k[1], sum(d) / len(d), min(d), max(d)))
+        f.write('rs_step_kernel launches: %d (%d per step, one per pipe: fast-forward + warm-up + timed + the %d all-outputs steps after the window; the first %d are the reset observes)\n' % (len(dur), PIPES, tail // PIPES, PIPES))
+        f.write('the %d timed launches (%d steps x %d pipes of 2048 environments): mean %.4f ms, min %.4f, max %.4f\n' % (len(d), steps, PIPES, sum(d) / len(d), min(d), max(d)))
+        f.write('first start to last end of the timed launches: %.3f ms = %.4f ms per step (the launches of the two pipes overlap)\n' % (span, span / steps))
         f.write('all launches: mean %.4f ms\n' % (sum(dur) / len(dur)))
     print('profiles/%s_%s' % (tag, out))
 res = subprocess.run(['bash', os.path.join(ROOT, 'tools', 'kernel_resources.sh')], capture_output=True, text=True).stdout

@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--out', default=None)
     ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--rollout-only', action='store_true')
+    ap.add_argument('--no-rollout', action='store_true')
     a = ap.parse_args()
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', a.map + '.npz'))
     rows = []
@@ -111,10 +113,11 @@ def main():
     shapes = [(4096, 1), (4096, 2), (4096, 4), (3840, 1), (4608, 1), (4608, 2), (3072, 1), (8192, 1), (8192, 2)]
     if a.quick:
         shapes = shapes[:3]
-    for n, k in shapes:
+    for n, k in ([] if a.rollout_only else shapes):
         emit(sim_only(sc, n, k, a.steps))
-    for n in (1024, 4096):
-        emit(sim_only(sc, n, 1, a.steps))
+    for n in (() if a.no_rollout else (1024, 4096)):
+        for k in (1, 2, 4):
+            emit(sim_only(sc, n, k, a.steps))
         for k in (1, 2, 4):
             emit(rollout(sc, n, k, a.steps, 'eps1'))
         for k in (1, 2):

@@ -15,20 +15,27 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IN
   echo "pass $i rc=$? : $set"
 done
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json, sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
+from bench import kernel_source_hash, DEFAULT_PIPES
+STEPS, PIPES = ${2:-30}, DEFAULT_PIPES
+TAIL = PIPES * min(STEPS, 20)           # the all-outputs leg bench.py runs after the timed window
 summary = {}
 for f in sorted(glob.glob('$OUT/p*/*counter_collection.csv')):
-    acc = collections.defaultdict(lambda: [0.0, 0])
+    per = collections.defaultdict(list)                 # counter -> [(dispatch id, value)]
     for r in csv.DictReader(open(f)):
         if 'rs_step_kernel' not in r.get('Kernel_Name', ''): continue
-        a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
-    for k, (v, n) in sorted(acc.items()):
-        print(f.split('/')[-2], k, 'per-launch avg', v / max(1, n), 'launches', n)
-        summary[k] = dict(per_launch_avg=v / max(1, n), launches=n)
-import json, sys
-sys.path.insert(0, '$GRAFT_REPO_ROOT')
-from bench import kernel_source_hash
-json.dump(dict(command='$CMD', kernel='rs_step_kernel', source_hash=kernel_source_hash(), counters=summary,
-               note='FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)'),
+        per[r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
+    for k, rows in sorted(per.items()):
+        # a counter may be reported in several rows per dispatch (one per XCD / instance): add them up per dispatch first
+        by = collections.OrderedDict()
+        for d, v in sorted(rows):
+            by[d] = by.get(d, 0.0) + v
+        vals = list(by.values())
+        timed = vals[-(TAIL + PIPES * STEPS):-TAIL] if len(vals) >= TAIL + PIPES * STEPS else vals
+        print(f.split('/')[-2], k, 'per-launch avg over the %d timed launches' % len(timed), sum(timed) / max(1, len(timed)), '(all %d launches: %s)' % (len(vals), sum(vals) / max(1, len(vals))))
+        summary[k] = dict(per_launch_avg=sum(timed) / max(1, len(timed)), launches=len(timed), all_launches=len(vals), all_launches_avg=sum(vals) / max(1, len(vals)))
+json.dump(dict(command='$CMD', kernel='rs_step_kernel', source_hash=kernel_source_hash(), pipes=PIPES, counters=summary,
+               note='per_launch_avg: over the timed launches of the command (steps x pipes launches of 4096 / pipes environments each; the fast-forward, warm-up and all-outputs launches are left out).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)'),
           open('$OUT/pmc_summary.json', 'w'), indent=1)
 PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the measured evidence of the current build on the MI355X box (run through gpurun); outputs land in
 # gpurun_out/$TAG/ and are copied into profiles/ (named per round) afterwards (tools/collect_profiles.py).
-#   gpurun --timeout 1500 -- 'TAG=r03 bash tools/refresh_profiles.sh'
+#   gpurun --timeout 1500 -- 'TAG=r04 bash tools/refresh_profiles.sh'
 set -u
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-final}
@@ -14,10 +14,12 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_window.log 2>/dev/null
 tail -1 $OUT/bench_driver_window.log > $OUT/bench_driver_window.json
 python tools/phase_profile.py ingolstadt21 4096 0 > $OUT/phase_profile.txt 2>/dev/null
 python tools/phase_profile.py ingolstadt21 256 0 > $OUT/phase_profile_one_workgroup_per_cu.txt 2>/dev/null
-python tools/graph_ab.py > $OUT/graph_ab.jsonl 2>/dev/null
 python tools/bench_configs.py > $OUT/bench_configs.jsonl 2>/dev/null
-(python tools/idqn_rollout.py 1024; python tools/idqn_rollout.py 4096) 2>/dev/null | grep '^{' > $OUT/idqn_rollout.jsonl
-python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_reference_result_bands -s 2>&1 | grep -o "band .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/reference_bands.txt
+rm -f $OUT/pipes_ab.jsonl $OUT/idqn_rollout.jsonl
+python tools/pipes_ab.py --no-rollout --out $OUT/pipes_ab.jsonl > /dev/null 2>&1
+python tools/pipes_ab.py --rollout-only --out $OUT/idqn_rollout.jsonl > /dev/null 2>&1
+python -m pytest tests/test_gpu_parity.py -m gpu -q -k "test_reference_result_bands or test_reference_result_known_gaps" -s 2>&1 | grep -o "band .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/reference_bands.txt
+python -m pytest tests/test_gpu_heldout.py -m gpu -q -s 2>&1 | grep -o "heldout .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/heldout_idqn.txt
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the contract line (default --steps / --warmup), CPU baseline off: per-kernel time by rocprofv3
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
