@@ -40,13 +40,12 @@ for name, out in (('prof/%s_kernel_trace.csv' % tag, 'kernel_trace_summary.txt')
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
     steps = 20 if '_dw' in name else 300
-    tail = PIPES * min(steps, 20)           # the all-outputs leg bench.py runs after the timed window
-    timed = rows[-(tail + PIPES * steps):-tail]
-    d = dur[-(tail + PIPES * steps):-tail]
+    timed = rows[-PIPES * steps:]           # the timed window is the end of the run
+    d = dur[-PIPES * steps:]
     span = (max(int(r['End_Timestamp']) for r in timed) - min(int(r['Start_Timestamp']) for r in timed)) / 1e6
     with open(os.path.join(dst, '%s_%s' % (tag, out)), 'w') as f:
         f.write('rocprofv3 --kernel-trace of `%s`\n' % ('python bench.py --no-cpu-baseline' + (' --steps 20 --warmup 5' if '_dw' in name else '')))
-        f.write('rs_step_kernel launches: %d (%d per step, one per pipe: fast-forward + warm-up + timed + the %d all-outputs steps after the window; the first %d are the reset observes)\n' % (len(dur), PIPES, tail // PIPES, PIPES))
+        f.write('rs_step_kernel launches: %d (%d per step, one per pipe: fast-forward + warm-up + timed; the first %d are the reset observes)\n' % (len(dur), PIPES, PIPES))
         f.write('the %d timed launches (%d steps x %d pipes of 2048 environments): mean %.4f ms, min %.4f, max %.4f\n' % (len(d), steps, PIPES, sum(d) / len(d), min(d), max(d)))
         f.write('first start to last end of the timed launches: %.3f ms = %.4f ms per step (the launches of the two pipes overlap)\n' % (span, span / steps))
         f.write('all launches: mean %.4f ms\n' % (sum(dur) / len(dur)))

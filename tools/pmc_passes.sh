@@ -19,7 +19,6 @@ import csv, glob, collections, json, sys
 sys.path.insert(0, '$GRAFT_REPO_ROOT')
 from bench import kernel_source_hash, DEFAULT_PIPES
 STEPS, PIPES = ${2:-30}, DEFAULT_PIPES
-TAIL = PIPES * min(STEPS, 20)           # the all-outputs leg bench.py runs after the timed window
 summary = {}
 for f in sorted(glob.glob('$OUT/p*/*counter_collection.csv')):
     per = collections.defaultdict(list)                 # counter -> [(dispatch id, value)]
@@ -32,10 +31,10 @@ for f in sorted(glob.glob('$OUT/p*/*counter_collection.csv')):
         for d, v in sorted(rows):
             by[d] = by.get(d, 0.0) + v
         vals = list(by.values())
-        timed = vals[-(TAIL + PIPES * STEPS):-TAIL] if len(vals) >= TAIL + PIPES * STEPS else vals
+        timed = vals[-PIPES * STEPS:]         # the timed window is the end of the run
         print(f.split('/')[-2], k, 'per-launch avg over the %d timed launches' % len(timed), sum(timed) / max(1, len(timed)), '(all %d launches: %s)' % (len(vals), sum(vals) / max(1, len(vals))))
         summary[k] = dict(per_launch_avg=sum(timed) / max(1, len(timed)), launches=len(timed), all_launches=len(vals), all_launches_avg=sum(vals) / max(1, len(vals)))
 json.dump(dict(command='$CMD', kernel='rs_step_kernel', source_hash=kernel_source_hash(), pipes=PIPES, counters=summary,
-               note='per_launch_avg: over the timed launches of the command (steps x pipes launches of 4096 / pipes environments each; the fast-forward, warm-up and all-outputs launches are left out).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)'),
+               note='per_launch_avg: over the timed launches of the command (steps x pipes launches of 4096 / pipes environments each; the fast-forward and warm-up launches are left out).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)'),
           open('$OUT/pmc_summary.json', 'w'), indent=1)
 PY
