@@ -84,6 +84,9 @@ typedef struct rs_params {
     int32_t speed_dev;        /* 1: per-vehicle speedFactor ~ clip(N(mean, dev), 0.2, 2) */
     int32_t fixed_program;    /* 1: run the net's own tlLogic and ignore actions */
     int32_t trip_log;         /* 1: keep a per-trip record (RS_BUF_TRIP_LOG) for tripinfo output; costs N x n_trips x 16 B */
+    int32_t step_ratio;       /* simulation steps per step_sim() call (MultiSignal(step_ratio=...), multi_signal.py:102-105): an env-step runs
+                               * yellow_length x step_ratio ticks before Signal.set_phase and step_length x step_ratio ticks in all; the
+                               * RESCO waiting rule still adds step_length per observe (traffic_signal.py:196).  0 or 1: one */
 } rs_params;
 
 typedef struct rs_sim *rs_handle;

@@ -891,10 +891,11 @@ void orc_step(orc_env *e, const int32_t *actions) {
             }
         }
     }
-    for (int32_t i = 0; i < sc->yellow_length; ++i) orc_tick(e);
+    const int32_t ratio = e->p.step_ratio > 1 ? e->p.step_ratio : 1;      /* step_sim() = step_ratio x simulationStep() (multi_signal.py:102-105) */
+    for (int32_t i = 0; i < sc->yellow_length * ratio; ++i) orc_tick(e);
     if (!e->p.fixed_program)
         for (int32_t s = 0; s < S; ++s) orc_set_phase(e, s, e->next_phase[s]);   /* Signal.set_phase (:186-187) */
-    for (int32_t i = 0; i < sc->step_length - sc->yellow_length; ++i) orc_tick(e);
+    for (int32_t i = 0; i < (sc->step_length - sc->yellow_length) * ratio; ++i) orc_tick(e);
     orc_observe(e);
 }
 

@@ -219,6 +219,7 @@ __global__ void rs_act_maxwave_kernel(KTab T, KParams P, const int32_t *pairs, i
 struct rs_sim {
     int device = 0;
     int n_envs = 0, env_base = 0, block = 256;
+    int ratio = 1;                  // rs_params.step_ratio: simulation ticks per step_sim() call
     size_t lds = 0;
     KTab K{};
     StepArgs *args = nullptr;      // device copy of {K, G, O}
@@ -358,7 +359,10 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         K.maxlen = PT.maxlen; K.occ_unit = PT.occ_unit;
         K.n_trips = sc->n_trips; K.tls_maxl = PT.tls_maxl; K.kmax = sc->kmax;
         K.n_lanes = sc->n_lanes; K.n_cells = PT.n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes;
-        K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = PT.lmax;
+        h->ratio = p->step_ratio > 1 ? p->step_ratio : 1;
+        // the kernel counts ticks: Signal.set_phase comes after yellow_length x step_ratio of them (multi_signal.py:102-105, 175-180);
+        // step_length stays what Signal.observe adds to a waiting time (traffic_signal.py:196)
+        K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length * h->ratio; K.lmax = PT.lmax;
         K.n_arr = PT.n_arr; K.n_dep = PT.n_dep;
     }
     const int lmax = PT.lmax;
@@ -540,7 +544,7 @@ extern "C" int rs_step(rs_handle h, const int32_t *actions, int32_t actions_on_d
         // a pageable host source may be read after the call returns: make the caller's buffer reusable
         if (!actions_on_device) HIPCHK(h, hipStreamSynchronize(st));
     }
-    return launch_step(h, st, h->K.step_length, 1);
+    return launch_step(h, st, h->K.step_length * h->ratio, 1);
 }
 
 extern "C" int rs_ticks(rs_handle h, int32_t n_ticks, void *stream) {

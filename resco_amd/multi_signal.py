@@ -19,7 +19,7 @@ from . import rewards as _rewards
 from . import states as _states
 from .config.map_config import map_configs
 from .config.signal_config import signal_configs
-from .scenario import Scenario, compile_from_sumocfg
+from .scenario import Scenario, compile_from_sumocfg, compile_scenario, parse_net, parse_routes
 from .sim import BatchedSim, speed_factor, torch_stream
 from .traffic_signal import Phase, Signal
 
@@ -101,8 +101,8 @@ class MultiSignal(_EnvBase):
                  step_length=10, yellow_length=4, step_ratio=1, max_distance=200, lights=(), log_dir='/',
                  libsumo=False, warmup=0, gymma=False, *, device=0, seed=None, sigma=-1.0, speed_dev=1,
                  fixed_program=False, scenario=None, use_fast_path=True, tripinfo=True):
-        if step_ratio != 1:
-            raise NotImplementedError('step_ratio != 1 (sub-second SUMO steps) is not supported')
+        if int(step_ratio) < 1:
+            raise ValueError('step_ratio must be a positive integer')
         self.libsumo, self.gymma, self.gui = libsumo, gymma, gui
         self.log_dir, self.net, self.route = log_dir, net, route
         self.state_fn, self.reward_fn = state_fn, reward_fn
@@ -113,14 +113,26 @@ class MultiSignal(_EnvBase):
         self.use_fast_path = use_fast_path
         self.connection_name = run_name + '-' + map_name + '---' + state_fn.__name__ + '-' + reward_fn.__name__
 
+        # multi_signal.py:33-38, 123-124: with `route` the demand comes from one route file PER RUN, `<route>_<run>.rou.xml` next to
+        # the net file `net` (the two grid maps; their archives unpack into a directory of the map's name)
+        self._lights, self._net_parsed, self._sc_run = tuple(lights), None, None
+        if route is not None and scenario is None:
+            for grid in ('grid4x4', 'arterial4x4'):
+                if grid in self.route:
+                    self.route += '/' + grid
+                    break
+            scenario = self._compile_run(1)
+            self._sc_run = 1
         self.scenario = scenario if scenario is not None else load_scenario(map_name, net, lights, yellow_length)
         sc = self.scenario
         if sc.yellow_length != yellow_length:       # the yellow phases are compiled into the scenario's programmes
             raise EnvironmentError('scenario %s was compiled with yellow_length=%d (asked %d)' % (map_name, sc.yellow_length, yellow_length))
         self._base_seed = int.from_bytes(os.urandom(4), 'little') if seed is None else int(seed)
-        self.sim = BatchedSim(sc, 1, device=device, seed=self._base_seed, max_distance=max_distance, sigma=sigma,
-                              speed_dev=speed_dev, fixed_program=1 if fixed_program else 0,
-                              step_length=step_length, yellow_length=yellow_length, trip_log=1 if tripinfo else 0)
+        self._sim_kw = dict(device=device, max_distance=max_distance, sigma=sigma, speed_dev=speed_dev,
+                            fixed_program=1 if fixed_program else 0, step_length=step_length, yellow_length=yellow_length,
+                            trip_log=1 if tripinfo else 0,
+                            step_ratio=step_ratio)      # multi_signal.py:102-105: step_sim() = step_ratio simulation steps
+        self.sim = BatchedSim(sc, 1, seed=self._base_seed, **self._sim_kw)
         self.tripinfo = tripinfo
         self.view_env = 0
         self._version = 0
@@ -159,6 +171,18 @@ class MultiSignal(_EnvBase):
             os.makedirs(log_dir + self.connection_name, exist_ok=True)
         except OSError:
             pass
+
+    def _compile_run(self, run):
+        """scenario tables for the demand of episode `run`: `<route>_<run>.rou.xml` over the net file (SUMO's `-n net -r routes`,
+        begin 0: multi_signal.py:123-124)"""
+        path = self.route + '_' + str(run) + '.rou.xml'
+        if not os.path.isfile(path) or not (self.net and os.path.isfile(self.net)):
+            raise EnvironmentError('route file %s (or net file %s) does not exist' % (path, self.net))
+        if self._net_parsed is None:
+            self._net_parsed = parse_net(self.net)
+        vtypes, trips = parse_routes(path)
+        return compile_scenario(self.map_name, self._net_parsed, vtypes, trips, 0, int(self.end_time), signal_configs[self.map_name],
+                                lights=self._lights, yellow_length=self.yellow_length)
 
     # ------------------------------------------------------------------ device buffer access
     def _host(self, name):
@@ -215,9 +239,9 @@ class MultiSignal(_EnvBase):
 
     # ------------------------------------------------------------------ gym API
     def step_sim(self):
-        """one sumo.simulationStep() (multi_signal.py:102-105) and nothing else -- the Signal objects are not observed, their
-        waiting times and arrival / departure sets stay as they are; MultiSignal.step() fuses its ticks into one launch"""
-        self.sim.step_sim(1)
+        """step_ratio x sumo.simulationStep() (multi_signal.py:102-105) and nothing else -- the Signal objects are not observed,
+        their waiting times and arrival / departure sets stay as they are; MultiSignal.step() fuses its ticks into one launch"""
+        self.sim.step_sim(int(self.step_ratio))
         self._version += 1
 
     def reinit_signals(self):
@@ -236,11 +260,18 @@ class MultiSignal(_EnvBase):
             self.save_tripinfo()
         self.metrics = []
         self.run += 1
+        if self.route is not None and self._sc_run is not None and self._sc_run != self.run:
+            # a new SUMO with this run's route file (multi_signal.py:123-124): the tables are compiled from it, the net stays
+            self.sim.close()
+            self.scenario = self._compile_run(self.run)
+            self._sc_run = self.run
+            self.sim = BatchedSim(self.scenario, 1, seed=self._base_seed, **self._sim_kw)
+            self._cache = {}
         # the reference restarts SUMO with --random (multi_signal.py:127): a new seed per episode
         self.sim.set_seed((self._base_seed + 0x9E3779B1 * self.run) & 0xFFFFFFFF)
         self.sim.reset()
         if self.warmup > 0:             # multi_signal.py:139-140: warm-up ticks before the Signal objects exist
-            self.sim.ticks(self.warmup)
+            self.sim.ticks(self.warmup * int(self.step_ratio))      # `warmup` x step_sim() (multi_signal.py:139-140)
             self.sim.reinit_signals()
         self._version += 1
         self.signal_ids = [self.all_ts_ids[i] for i in range(self.ts_starter)]
@@ -337,18 +368,18 @@ class VecMultiSignal:
 
     def __init__(self, map_name, n_envs, states=('drq_norm',), rewards=('wait',), net=None, device=0, seed=0,
                  max_distance=200, step_length=10, yellow_length=3, sigma=-1.0, speed_dev=1, fixed_program=False,
-                 env_base=0, block_threads=0, scenario=None, outputs=None):
+                 env_base=0, block_threads=0, scenario=None, outputs=None, step_ratio=1):
         mc = map_configs.get(map_name, {})
         self.scenario = scenario if scenario is not None else load_scenario(map_name, net, mc.get('lights', ()),
                                                                             yellow_length)
         self.sim = BatchedSim(self.scenario, n_envs, device=device, seed=seed, max_distance=max_distance,
                               sigma=sigma, speed_dev=speed_dev, fixed_program=1 if fixed_program else 0,
                               env_base=env_base, step_length=step_length, yellow_length=yellow_length,
-                              block_threads=block_threads)
+                              block_threads=block_threads, step_ratio=step_ratio)
         self.n_envs, self.n_signals = n_envs, self.scenario.n_signals
         self.state_names, self.reward_names = tuple(states), tuple(rewards)
         self.step_length = step_length
-        self.horizon_steps = self.scenario.horizon // step_length
+        self.horizon_steps = self.scenario.horizon // (step_length * max(1, int(step_ratio)))
         self.steps = 0
         self.all_ts_ids = list(self.scenario.signal_ids)
         self.n_actions = [int(g) for g in self.scenario.tls_ngreen]

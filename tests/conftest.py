@@ -14,7 +14,9 @@ HOT_CASES = ['cologne1_d200', 'cologne8_d200', 'cologne8_d50', 'ingolstadt21_d20
 # whole 360-step episode (tests/golden/make_golden.py)
 WARM_CASES = ['ingolstadt21_d200_warm180', 'cologne8_d200_warm180']
 FULL_CASES = ['cologne1_d50_full']
-ALL_CASES = HOT_CASES + WARM_CASES + FULL_CASES
+# MultiSignal(step_ratio=2): two simulation steps per step_sim() (multi_signal.py:102-105), driven by the reference's own loop
+RATIO_CASES = ['cologne8_d200_sr2']
+ALL_CASES = HOT_CASES + WARM_CASES + FULL_CASES + RATIO_CASES
 
 
 def pytest_configure(config):

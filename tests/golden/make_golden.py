@@ -31,6 +31,9 @@ CASES = [  # (map, steps, max_distance, pre-roll steps)
     # reference's MultiSignal.reset() builds its Signal objects on it and is driven for `steps` (long waiting_times,
     # departures under congestion, the purge of traffic_signal.py:230-232)
     ('ingolstadt21', 30, 200, 180), ('cologne8', 30, 200, 180),
+    # step_ratio = 2 (multi_signal.py:102-105: two simulationStep() per step_sim(): 6 yellow + 14 green ticks per env-step, the
+    # 6 s greens of cologne8 run out twice inside one step)
+    ('cologne8', 24, 200, 0, 2),
 ]
 STATE_FNS = ['drq', 'drq_norm', 'mplight', 'mplight_full', 'wave']
 REWARD_FNS = ['wait', 'wait_norm', 'pressure']
@@ -47,7 +50,7 @@ def preroll_actions(sc, seed, k):
     return np.array([L.orc_hash((seed ^ 0xA5A5A5A5) & 0xFFFFFFFF, 0, s, k, 7) % int(sc.tls_ngreen[s]) for s in range(sc.n_signals)], np.int32)
 
 
-def run_case(map_name, steps, max_distance, preroll=0):
+def run_case(map_name, steps, max_distance, preroll=0, step_ratio=1):
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', map_name + '.npz'))
     mc = map_configs[map_name]
     state = {'n': 0}
@@ -92,7 +95,7 @@ def run_case(map_name, steps, max_distance, preroll=0):
     tmp = tempfile.mkdtemp() + os.sep
     env = ref['MultiSignal']('golden', map_name, 'x.sumocfg', states.mplight, rewards.wait, step_length=mc['step_length'],
                              yellow_length=mc['yellow_length'], end_time=mc['end_time'], max_distance=max_distance,
-                             lights=mc['lights'], log_dir=tmp)
+                             lights=mc['lights'], log_dir=tmp, step_ratio=step_ratio)
     ids = list(env.all_ts_ids)
     S = len(ids)
     mp = ref['MAXPRESSURE']({}, None, map_name, 0)
@@ -163,8 +166,9 @@ def run_case(map_name, steps, max_distance, preroll=0):
     with open(os.path.join(tmp, env.connection_name, 'metrics_1.csv')) as f:
         csv_text = f.read()
 
-    tag = '%s_d%d' % (map_name, max_distance) + ('_full' if steps >= 360 else '') + ('_warm%d' % preroll if preroll else '')
-    meta = dict(map=map_name, steps=steps, max_distance=max_distance, preroll=preroll, base_seed=BASE_SEED, seed=episode_seed(1),
+    tag = '%s_d%d' % (map_name, max_distance) + ('_full' if steps >= 360 else '') + ('_warm%d' % preroll if preroll else '') + \
+        ('_sr%d' % step_ratio if step_ratio != 1 else '')
+    meta = dict(map=map_name, steps=steps, max_distance=max_distance, preroll=preroll, step_ratio=step_ratio, base_seed=BASE_SEED, seed=episode_seed(1),
                 all_ts_ids=ids, ts_order=list(env.ts_order), obs_shape={ts: list(env.obs_shape[ts]) for ts in ids},
                 n_green=n_green, connection_name=env.connection_name, metrics_csv=csv_text,
                 oracle_stats=orc_stats, signals={}, fma2c_keys=fma_keys, fma2c_shapes=fma_shapes)
@@ -187,5 +191,10 @@ def run_case(map_name, steps, max_distance, preroll=0):
 
 
 if __name__ == '__main__':
+    only = sys.argv[1:]             # tags to (re)generate; none = all
     for case in CASES:
+        tag = '%s_d%d' % (case[0], case[2]) + ('_full' if case[1] >= 360 else '') + ('_warm%d' % case[3] if case[3] else '') + \
+            ('_sr%d' % case[4] if len(case) > 4 and case[4] != 1 else '')
+        if only and tag not in only:
+            continue
         run_case(*case)

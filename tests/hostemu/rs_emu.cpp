@@ -103,7 +103,7 @@ struct rs_sim {
     Out O{};
     KParams P{};
     Lds L{};
-    int n_envs = 0, block = 0, order = 0;
+    int n_envs = 0, block = 0, order = 0, ratio = 1;
     size_t lds = 0;
     std::vector<char> slab, outb, smem;
     std::vector<int32_t> env, tls, actions, trip_log, pairs, valid, ordr;
@@ -181,7 +181,8 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     c.trips_cum = keep_i32(h, sc->trips_cum, sc->horizon + 2);
     K.maxlen = PT.maxlen; K.occ_unit = PT.occ_unit; K.n_trips = sc->n_trips; K.tls_maxl = PT.tls_maxl; K.kmax = sc->kmax;
     K.n_lanes = sc->n_lanes; K.n_cells = PT.n_cells; K.n_signals = sc->n_signals; K.n_obs = sc->n_obs; K.n_vtypes = sc->n_vtypes;
-    K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length; K.lmax = PT.lmax;
+    h->ratio = p->step_ratio > 1 ? p->step_ratio : 1;
+    K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length * h->ratio; K.lmax = PT.lmax;
     K.n_arr = PT.n_arr; K.n_dep = PT.n_dep;
     h->P.seed = p->seed; h->P.env_base = env_base; h->P.max_distance = p->max_distance; h->P.sigma = p->sigma;
     h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.n_envs = n_envs;
@@ -252,7 +253,7 @@ int rs_reset(rs_handle h, void *) {
 }
 int rs_step(rs_handle h, const int32_t *actions, int32_t, void *) {
     if (actions) memcpy(h->actions.data(), actions, h->actions.size() * 4);
-    run_step(h, h->K.step_length, 1);
+    run_step(h, h->K.step_length * h->ratio, 1);
     return RS_OK;
 }
 int rs_ticks(rs_handle h, int32_t n, void *) { run_step(h, n, 0); return RS_OK; }

@@ -157,7 +157,7 @@ def test_multisignal_matches_reference_python(tag, fast):
     tmp = tempfile.mkdtemp() + os.sep
     env = MultiSignal('golden', meta['map'], mc['net'], states.mplight, rewards.wait, step_length=mc['step_length'],
                       yellow_length=mc['yellow_length'], end_time=mc['end_time'], max_distance=meta['max_distance'],
-                      lights=mc['lights'], log_dir=tmp, seed=meta['base_seed'], use_fast_path=fast)
+                      lights=mc['lights'], log_dir=tmp, seed=meta['base_seed'], use_fast_path=fast, step_ratio=meta.get('step_ratio', 1))
     ids = meta['all_ts_ids']
     assert env.all_ts_ids == ids and env.ts_order == meta['ts_order']
     assert {k: list(v) for k, v in env.obs_shape.items()} == meta['obs_shape']

@@ -3,6 +3,8 @@
 
 This pins the kernel's logic, and its independence of the order in which the threads of a workgroup run inside a
 phase, without a GPU.  The -m gpu tests pin the real thing (the same source compiled by hipcc) against the same oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,6 +105,29 @@ def test_half_the_threads_two_slots_each():
         sim.step(a[None, :])
         o.step(a)
     assert_equal(sim, [o], 59)
+    sim.close()
+
+
+def test_step_ratio_two_against_the_reference_s_own_loop():
+    """MultiSignal(step_ratio=2): step_sim() = two simulation steps (multi_signal.py:102-105), i.e. 6 yellow + 14 further ticks per
+    env-step with step_length 10 / yellow_length 3, while Signal.observe still adds step_length to a waiting time.  The golden
+    case was produced by the REFERENCE's unmodified step loop (tests/golden/make_golden.py); the kernel source (host emulation) and
+    the oracle's orc_step must both reproduce it."""
+    meta, g = load_golden('cologne8_d200_sr2')
+    assert meta['step_ratio'] == 2
+    sc = load_scenario('cologne8')
+    sim = EmuSim(sc, 1, order=2, seed=meta['seed'], max_distance=meta['max_distance'], step_ratio=2)
+    o = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1, step_ratio=2)
+    o.observe()
+    for k in range(meta['steps']):
+        sim.step(g['actions'][k][None, :])
+        o.step(g['actions'][k])
+        assert int(sim.time()[0]) == 20 * (k + 1) == g['time'][k + 1] - sc.begin
+        np.testing.assert_array_equal(sim.read('phase')[0], g['phase'][k + 1])
+        np.testing.assert_array_equal(sim.read('mplight')[0].reshape(-1), g['mplight'][k + 1])
+        np.testing.assert_array_equal(sim.read('lane_agg')[0][:, :4], g['agg'][k + 1][:, :4])
+        np.testing.assert_array_equal(sim.read('wait')[0], g['wait'][k + 1].astype(np.float32))
+    assert_equal(sim, [o], meta['steps'] - 1)
     sim.close()
 
 
@@ -271,3 +296,47 @@ def test_out_of_range_actions_keep_the_current_phase():
         o.step(a)
         assert_equal(sim, [o], step)
     sim.close()
+
+
+REF_ENV = '/root/reference/resco_benchmark/environments'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ENV), reason='needs the reference net / route files (build container only)')
+def test_route_kwarg_one_route_file_per_run(tmp_path, monkeypatch):
+    """MultiSignal(route=prefix): the demand of episode k comes from `<prefix>_<k>.rou.xml` over the net file, SUMO begins at 0
+    (multi_signal.py:33-38, 123-124 -- how the reference runs the two grid maps).  Two route files cut from cologne1's demand (even /
+    odd trips, departures shifted to begin 0); the host emulation stands in for the HIP library."""
+    import xml.etree.ElementTree as ET
+    import resco_amd.multi_signal as ms
+    from resco_amd import rewards, states
+    root = ET.parse(os.path.join(REF_ENV, 'cologne1', 'cologne1.rou.xml')).getroot()
+    vtypes = [el for el in root if el.tag == 'vType']
+    trips = [el for el in root if el.tag == 'trip']
+    for run, part in ((1, trips[0::2]), (2, trips[1::2])):
+        r = ET.Element('routes')
+        for el in vtypes:
+            r.append(el)
+        for el in part:
+            t = ET.SubElement(r, 'trip', dict(el.attrib))
+            t.set('depart', '%.2f' % (float(el.get('depart')) - 25200.0))
+        ET.ElementTree(r).write(str(tmp_path / ('demand_%d.rou.xml' % run)))
+    monkeypatch.setattr(ms, 'BatchedSim', lambda sc, n, **kw: EmuSim(sc, n, **{k: v for k, v in kw.items() if k != 'device'}))
+    env = ms.MultiSignal('t', 'cologne1', os.path.join(REF_ENV, 'cologne1', 'cologne1.net.xml'), states.mplight, rewards.wait,
+                         route=str(tmp_path / 'demand'), end_time=3600, yellow_length=3, log_dir=str(tmp_path) + os.sep, seed=3,
+                         tripinfo=False)
+    assert env.scenario.n_trips == len(trips[0::2]) and env.scenario.begin == 0
+    n = {}
+    for run in (1, 2):
+        env.reset()
+        assert env.run == run and env.scenario.n_trips == len(trips[run - 1::2])
+        for k in range(40):
+            obs, rew, done, info = env.step({ts: k % 4 for ts in env.all_ts_ids})
+        assert info == {'eps': run} and not done and env.sim_time() == 400.0
+        n[run] = int(env.sim.stats()['inserted'][0])
+        # the demand of this run, and no other: every trip scheduled in the first 400 s of ITS file is on the network or waiting
+        due = int((env.scenario.trip_depart < 400).sum())
+        assert 0 < n[run] <= due and n[run] + int(env.sim.backlog()[0][0]) == due
+        assert list(env.scenario.trip_ids) == [el.get('id') for el in trips[run - 1::2]]
+    with pytest.raises(EnvironmentError):
+        env.reset()                                     # there is no demand_3.rou.xml
+    env.close()
