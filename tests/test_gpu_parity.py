@@ -85,6 +85,59 @@ def test_gpu_equals_oracle_bit_exact(name, n_envs, steps, sigma, speed_dev, fixe
     sim.close()
 
 
+def _random_configs(n, seed):
+    """seeded draws over what a handle can be created with (the same generator as tests/test_hostemu.py uses for the host emulation)"""
+    rng = np.random.default_rng(seed)
+    maps = ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21']
+    out = []
+    for i in range(n):
+        out.append(dict(name=maps[int(rng.integers(0, len(maps)))], sigma=float(rng.choice([-1.0, 0.0, 0.3, 0.9])),
+                        speed_dev=int(rng.integers(0, 2)), max_distance=float(rng.choice([1.0, 50.0, 200.0, 9999.0])),
+                        fixed=int(rng.random() < 0.25), step_ratio=int(rng.choice([1, 1, 2, 3])), seed=int(rng.integers(0, 2 ** 31)),
+                        env_base=int(rng.integers(0, 5000)), warm=int(rng.choice([0, 40, 90, 150])), n_envs=int(rng.integers(1, 4)),
+                        steps=int(rng.integers(12, 28)), case=i))
+    return out
+
+
+@pytest.mark.parametrize('cfg', _random_configs(10, 4096), ids=lambda c: '%d-%s' % (c['case'], c['name']))
+def test_randomised_parameter_sweep_bit_exact(cfg):
+    """HIP path == oracle on every output and every vehicle field for random combinations of the handle's parameters (driver
+    imperfection, speed factors, detector range, programme, step_ratio, seed, first environment), after a warm start under the
+    on-device random policy, under random, repeated and out-of-range actions"""
+    from oracle.pyoracle import OracleEnv
+    from resco_amd.sim import BatchedSim
+    sc = load_scenario(cfg['name'])
+    kw = dict(seed=cfg['seed'], sigma=cfg['sigma'], speed_dev=cfg['speed_dev'], max_distance=cfg['max_distance'],
+              fixed_program=cfg['fixed'], step_ratio=cfg['step_ratio'])
+    n = cfg['n_envs']
+    sim = BatchedSim(sc, n, env_base=cfg['env_base'], **kw)
+    orcs = [OracleEnv(sc, env_index=cfg['env_base'] + e, **kw) for e in range(n)]
+    for o in orcs:
+        o.observe()
+    for k in range(cfg['warm'] // cfg['step_ratio']):
+        sim.act_random(k)
+        sim.sync()
+        a = sim.read('actions')
+        sim.step(None)
+        for e, o in enumerate(orcs):
+            o.step(a[e])
+    rng = np.random.default_rng(cfg['case'])
+    prev = np.zeros((n, sc.n_signals), np.int32)
+    for step in range(cfg['steps']):
+        a = np.stack([rng.integers(0, sc.tls_ngreen) for _ in range(n)]).astype(np.int32)
+        keep = rng.random((n, sc.n_signals)) < 0.3
+        a[keep] = prev[keep]
+        if step % 9 == 4:
+            a[int(rng.integers(0, n)), int(rng.integers(0, sc.n_signals))] = int(rng.choice([-1, 97]))
+        prev = a.copy()
+        sim.step(a)
+        for e, o in enumerate(orcs):
+            o.step(a[e])
+        if step % 6 == 5 or step == cfg['steps'] - 1:
+            assert_env_equal(sim, orcs, step)
+    sim.close()
+
+
 @pytest.mark.parametrize('name,block,steps', [
     ('ingolstadt7', 64, 120),           # one wave for 256 slots: no wave roles, every thread handles its slots in full
     ('ingolstadt7', 256, 120),          # one thread per slot

@@ -75,6 +75,58 @@ def test_kernel_source_equals_oracle(name, steps, order, sigma, speed_dev, fixed
     sim.close()
 
 
+def _random_configs(n, seed):
+    """seeded draws over everything a handle can be created with: map, thread order, driver imperfection, speed factors, detector
+    range, programme, step_ratio, block shape, RNG seed, first environment, a warm start"""
+    rng = np.random.default_rng(seed)
+    maps = ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21']
+    out = []
+    for i in range(n):
+        name = maps[int(rng.integers(0, len(maps)))]
+        out.append(dict(name=name, order=int(rng.integers(0, 3)), sigma=float(rng.choice([-1.0, 0.0, 0.3, 0.9])),
+                        speed_dev=int(rng.integers(0, 2)), max_distance=float(rng.choice([1.0, 50.0, 200.0, 9999.0])),
+                        fixed=int(rng.random() < 0.25), step_ratio=int(rng.choice([1, 1, 2, 3])), seed=int(rng.integers(0, 2 ** 31)),
+                        env_base=int(rng.integers(0, 5000)), warm=int(rng.choice([0, 0, 40, 90])),
+                        threads=int(rng.choice([0, 64, 128])), steps=int(rng.integers(12, 28)), case=i))
+    return out
+
+
+@pytest.mark.parametrize('cfg', _random_configs(14, 2024), ids=lambda c: '%d-%s' % (c['case'], c['name']))
+def test_randomised_parameter_sweep_equals_oracle(cfg):
+    """kernel source (host emulation) == oracle on every output and every vehicle field for random combinations of the handle's
+    parameters, after an optional warm start under the on-device random policy, under random, repeated and out-of-range actions"""
+    sc = load_scenario(cfg['name'])
+    kw = dict(seed=cfg['seed'], sigma=cfg['sigma'], speed_dev=cfg['speed_dev'], max_distance=cfg['max_distance'],
+              fixed_program=cfg['fixed'], step_ratio=cfg['step_ratio'])
+    bt = cfg['threads'] if cfg['threads'] and cfg['threads'] <= sc.capacity else 0
+    sim = EmuSim(sc, 1, order=cfg['order'], env_base=cfg['env_base'], block_threads=bt, **kw)
+    o = OracleEnv(sc, env_index=cfg['env_base'], **kw)
+    o.observe()
+    ratio = cfg['step_ratio']
+    for k in range(cfg['warm'] // ratio):
+        sim.act_random(k)
+        sim.step(None)
+        sim.sync()
+        o.step(sim.read('actions')[0])
+    rng = np.random.default_rng(cfg['case'])
+    prev = np.zeros(sc.n_signals, np.int32)
+    for step in range(cfg['steps']):
+        a = rng.integers(0, sc.tls_ngreen).astype(np.int32)
+        keep = rng.random(sc.n_signals) < 0.3
+        a[keep] = prev[keep]                                # the no-change branch of prep_phase
+        if step % 9 == 4:
+            a[int(rng.integers(0, sc.n_signals))] = int(rng.choice([-1, 97]))      # not a phase index: the signal is left alone
+        prev = a.copy()
+        sim.step(a[None, :])
+        o.step(a)
+        if step % 6 == 5 or step == cfg['steps'] - 1:
+            assert_equal(sim, [o], step)
+    st, so = sim.stats(), o.stats()
+    for k in st:
+        assert st[k][0] == so[k], k
+    sim.close()
+
+
 @pytest.mark.parametrize('name,steps,order', [('cologne8', 60, 2), ('ingolstadt7', 80, 1)])
 def test_work_lists_overflow(name, steps, order):
     """the work lists of the phases (look-ahead, lane change, lane leavers) are scheduling only: with lists of 8 entries they
