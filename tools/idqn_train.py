@@ -2,7 +2,7 @@
 """IDQN training loop entirely on the GPU: HIP simulator -> fp16 observations -> fused HIP policy kernel
 (rs_idqn_act) -> device replay ring -> batched DQN update (PyTorch) -> weights re-packed on the device.  Nothing crosses PCIe per step except the launch calls.
 
-    python tools/idqn_train.py [map] [n_envs] [episodes] [batch] [updates_per_step] [graph|nograph] [replay_steps] [eps_end]
+    python tools/idqn_train.py [map] [n_envs] [episodes] [batch] [updates_per_step] [graph|nograph] [replay_steps] [eps_end] [seed]
 
 Prints one JSON line per episode (mean episode return of rewards.wait_norm per signal, average trip delay as
 utils/readXML.py computes it, epsilon, env-steps/s including learning) and a final line comparing with the
@@ -27,20 +27,20 @@ def delay(env):
     return float(env.sim.trip_delay().mean()), float(env.sim.stats()['arrived'].mean())
 
 
-def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1, use_graph=True, replay_steps=0, eps_end=0.0, evaluate=True, quiet=False):
+def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1, use_graph=True, replay_steps=0, eps_end=0.0, evaluate=True, quiet=False, seed=0):
     rows = []
     env = VecMultiSignal(map_name, n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=0)
     S, steps = env.n_signals, env.horizon_steps
     net = BatchedIDQN.from_scenario(env.scenario, dtype=torch.float32, device='cuda')
-    net.init_like_reference(seed=0)
+    net.init_like_reference(seed=seed)
     learner = BatchedDQNLearner(net, gamma=0.99, lr=1e-3, target_update=500, batch_size=batch)
-    policy = FusedIDQN(net, seed=7)             # acting: one HIP kernel; weights re-packed on the device after each update
+    policy = FusedIDQN(net, seed=7 + seed)             # acting: one HIP kernel; weights re-packed on the device after each update
     actions = env.tensor('actions')
     # the reference keeps the last 10 000 transitions of its ONE environment = 27.8 episodes of history (pfrl_dqn.py:55); a ring of
     # `replay_steps` env-steps over all N environments (0: the last four episodes -- a small ring forgets exploratory data within
     # four episodes of epsilon reaching 0)
     replay = DeviceReplay(replay_steps if replay_steps > 0 else min(2048, 4 * steps), n, S, net.lmax, device='cuda')
-    gen = torch.Generator(device='cuda').manual_seed(0)
+    gen = torch.Generator(device='cuda').manual_seed(seed)
     decay = int(0.8 * episodes * steps)                 # the reference decays over config['steps'] agent steps
 
     env.sim.set_seed(12345)                             # baseline: random policy on an evaluation demand seed
@@ -51,7 +51,7 @@ def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1, use_grap
     rnd_delay, _ = delay(env)
 
     for ep in range(episodes):
-        env.sim.set_seed(1000 + ep)
+        env.sim.set_seed(1000 + ep + 7919 * seed)
         obs = env.reset()['drq_norm_f16']
         ret = torch.zeros(n, S, device='cuda')
         torch.cuda.synchronize()
@@ -104,4 +104,4 @@ if __name__ == '__main__':
     a = sys.argv[1:]
     main(a[0] if len(a) > 0 else 'cologne1', int(a[1]) if len(a) > 1 else 256, int(a[2]) if len(a) > 2 else 12,
          int(a[3]) if len(a) > 3 else 256, int(a[4]) if len(a) > 4 else 1, (a[5] != 'nograph') if len(a) > 5 else True,
-         int(a[6]) if len(a) > 6 else 0, float(a[7]) if len(a) > 7 else 0.0)
+         int(a[6]) if len(a) > 6 else 0, float(a[7]) if len(a) > 7 else 0.0, seed=int(a[8]) if len(a) > 8 else 0)
