@@ -61,7 +61,7 @@ def sim_only(sc, n, k, steps, start=170):
     return dict(mode='sim_only', envs=n, pipes=k, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3, mean_active=act)
 
 
-def rollout(sc, n, k, steps, eps_mode, start=170):
+def rollout(sc, n, k, steps, eps_mode, start=170, prio=False):
     from resco_amd.agents.idqn_fused import FusedIDQN
     from resco_amd.agents.idqn_rollout import BatchedIDQN
     sims, streams = make_pipes(sc, n, k, ('drq_norm_f16',))
@@ -73,10 +73,25 @@ def rollout(sc, n, k, steps, eps_mode, start=170):
     act = [s.tensor('actions') for s in sims]
     sync_all(sims)
 
+    if prio:        # the policy kernels on high-priority streams of their own, ordered with the pipe's step by events
+        hi = [torch.cuda.Stream(priority=-1) for _ in range(k)]
+        ev_act = [torch.cuda.Event() for _ in range(k)]
+        ev_step = [torch.cuda.Event() for _ in range(k)]
+        for i in range(k):
+            ev_step[i].record(streams[i])
+
     def one(j, eps):
         for i, s in enumerate(sims):
-            pol[i].act(obs[i], epsilon=eps, step_key=j, stream=ptr[i], out=act[i])
-            s.step(None, ptr[i])
+            if prio:
+                hi[i].wait_event(ev_step[i])
+                pol[i].act(obs[i], epsilon=eps, step_key=j, stream=hi[i].cuda_stream, out=act[i])
+                ev_act[i].record(hi[i])
+                streams[i].wait_event(ev_act[i])
+                s.step(None, ptr[i])
+                ev_step[i].record(streams[i])
+            else:
+                pol[i].act(obs[i], epsilon=eps, step_key=j, stream=ptr[i], out=act[i])
+                s.step(None, ptr[i])
 
     for j in range(start):
         one(j, 1.0)
@@ -88,7 +103,7 @@ def rollout(sc, n, k, steps, eps_mode, start=170):
     dt = time.perf_counter() - t0
     for s in sims:
         s.close()
-    return dict(mode='sim_plus_fused_policy_' + eps_mode, envs=n, pipes=k, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3)
+    return dict(mode='sim_plus_fused_policy_' + eps_mode + ('_prio' if prio else ''), envs=n, pipes=k, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3)
 
 
 def main():
@@ -99,6 +114,7 @@ def main():
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--rollout-only', action='store_true')
     ap.add_argument('--no-rollout', action='store_true')
+    ap.add_argument('--prio', action='store_true', help='rollout: policy kernels on high-priority streams')
     a = ap.parse_args()
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', a.map + '.npz'))
     rows = []
@@ -120,6 +136,8 @@ def main():
             emit(sim_only(sc, n, k, a.steps))
         for k in (1, 2, 4):
             emit(rollout(sc, n, k, a.steps, 'eps1'))
+            if a.prio:
+                emit(rollout(sc, n, k, a.steps, 'eps1', prio=True))
         for k in (1, 2):
             emit(rollout(sc, n, k, a.steps, 'sched'))
 
