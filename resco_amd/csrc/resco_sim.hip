@@ -338,15 +338,15 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         UP(K.trip_route_, uint16_t, PT.trip_route.data(), PT.trip_route.size()) UP(K.trip_vtype_, uint8_t, PT.trip_vtype.data(), PT.trip_vtype.size())
         UP(K.route_cont_, float, sc->route_cont, (size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1) * sc->kmax)
         UP(cold.trip_depart, int32_t, sc->trip_depart, sc->n_trips) UP(cold.trip_next, uint16_t, PT.trip_next.data(), PT.trip_next.size())
-        UP(cold.dep_lane, uint16_t, PT.dep_lane.data(), PT.dep_lane.size()) UP(cold.dep_first, uint16_t, PT.dep_first.data(), PT.dep_first.size())
+        UP(cold.dep_lane, uint16_t, PT.dep_lane.data(), PT.dep_lane.size()) UP(cold.dep_info, DepInfo, PT.dep_info.data(), PT.dep_info.size()) UP(cold.dep_first, uint16_t, PT.dep_first.data(), PT.dep_first.size())
         UP(cold.vtype_params, float, sc->vtype_params, sc->n_vtypes * VT_COLS)
         UP(cold.tls8, uint8_t, PT.tls8.data(), PT.tls8.size()) UP(cold.fix8, uint8_t, PT.fix8.data(), PT.fix8.size())
         UP(cold.tls_nphase, int32_t, sc->tls_nphase, sc->n_signals) UP(cold.tls_ngreen, int32_t, sc->tls_ngreen, sc->n_signals)
-        UP(cold.tls_nlinks, int32_t, sc->tls_nlinks, sc->n_signals) UP(cold.tls_state_off, int32_t, sc->tls_state_off, sc->n_signals)
+        UP(cold.tls_nlinks, int32_t, sc->tls_nlinks, sc->n_signals) UP(cold.tls_state_off, int32_t, PT.tls_off_p.data(), sc->n_signals)
         UP(cold.tls_dur_off, int32_t, sc->tls_dur_off, sc->n_signals) UP(cold.tls_yel_off, int32_t, sc->tls_yel_off, sc->n_signals)
         UP(cold.tls_dur, int32_t, sc->tls_dur, sc->n_tls_dur) UP(cold.tls_yellow, int32_t, sc->tls_yellow, sc->n_tls_yellow)
         UP(cold.tls_init_phase, int32_t, sc->tls_init_phase, sc->n_signals)
-        UP(cold.fix_nphase, int32_t, sc->fix_nphase, sc->n_signals) UP(cold.fix_state_off, int32_t, sc->fix_state_off, sc->n_signals)
+        UP(cold.fix_nphase, int32_t, sc->fix_nphase, sc->n_signals) UP(cold.fix_state_off, int32_t, PT.fix_off_p.data(), sc->n_signals)
         UP(cold.fix_dur_off, int32_t, sc->fix_dur_off, sc->n_signals) UP(cold.fix_dur, int32_t, sc->fix_dur, sc->n_fix_dur)
         UP(cold.fix_init_phase, int32_t, sc->fix_init_phase, sc->n_signals) UP(cold.fix_init_left, int32_t, sc->fix_init_left, sc->n_signals)
         UP(cold.lane_obs, int16_t, PT.lane_obs16.data(), PT.lane_obs16.size()) UP(cold.obs_sig, int32_t, PT.obs_sig.data(), PT.obs_sig.size())

@@ -452,10 +452,19 @@ RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const uint16_t *grid, const
 }
 // copy the link states of signal s in phase ph into the working memory (called by the thread that owns the signal)
 RS_DEV void tls_refresh(const KTab &T, const Lds &L, const KParams &P, int s, int ph) {
-    const uint8_t *src = (P.fixed_program ? T.cold.fix8 + T.cold.fix_state_off[s] : T.cold.tls8 + T.cold.tls_state_off[s]) + ph * T.cold.tls_nlinks[s];
-    const int n = T.cold.tls_nlinks[s];
+    // rows of the state tables are tls_maxl bytes (a multiple of 4, zero padded) and 4-byte aligned: the row is copied with
+    // independent 32-bit loads (up to 8 of them in flight) -- all signals change phase in the same ticks, and this copy is on the
+    // critical path of those ticks' C phase
+    const int w = T.tls_maxl >> 2;
+    const uint32_t *src = (const uint32_t *)((P.fixed_program ? T.cold.fix8 + T.cold.fix_state_off[s] : T.cold.tls8 + T.cold.tls_state_off[s]) + ph * T.tls_maxl);
+    uint32_t *dst = (uint32_t *)((uint8_t *)L.tstate + s * T.tls_maxl);
+    uint32_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src[i < w ? i : 0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < w) dst[i] = v[i];
 #pragma unroll 1
-    for (int i = 0; i < n; ++i) L.tstate[s * T.tls_maxl + i] = src[i];
+    for (int i = 8; i < w; ++i) dst[i] = src[i];
 }
 RS_DEV void set_phase(const KTab &T, const Lds &L, const KParams &P, int s, int ph) {
     if (ph < 0 || ph >= T.cold.tls_nphase[s]) return;
@@ -749,7 +758,8 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     const float vn = L.vnx[s];
     gold[LR.cell0 + cell_of(me.pos, lane_cells(LR))] = NIL;         // every vehicle of a cell stores the same: the old grid empties
     int rq = ax.rq;
-    int link = (int)(ax.nlink & 0x7FFF);
+    uint16_t nlink = ax.nlink;              // the link after the lane the vehicle ends up on, as cache_link() returns it
+    int link = (int)(nlink & 0x7FFF);
     bool relink = false;
     int side = 0;
     if (me.fl & (LCT_LEFT | LCT_RIGHT | LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) {
@@ -759,7 +769,8 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     if (side) {
         lane += side;
         LR = T.lanes()[lane];
-        link = (int)(cache_link(T, LR, lane, rq, k) & 0x7FFF);
+        nlink = cache_link(T, LR, lane, rq, k);
+        link = (int)(nlink & 0x7FFF);
         relink = true;
     }
     const float vref = LR.vmax * sfv;
@@ -786,7 +797,8 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
             lane = Km.to_lane;
             LR = Km.dest;
         }
-        link = (int)(cache_link(T, LR, lane, rq, k) & 0x7FFF);
+        nlink = cache_link(T, LR, lane, rq, k);
+        link = (int)(nlink & 0x7FFF);
         relink = true;
     }
     if (arrived) {
@@ -814,7 +826,7 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     if (s + 1 > top) top = s + 1;
     Aux na = ax;
     na.lane = (uint16_t)lane; na.rq = (uint16_t)rq; na.swait = (uint16_t)swn;
-    if (relink) na.nlink = cache_link(T, LR, lane, rq, k);
+    if (relink) na.nlink = nlink;           // (looked up when the lane was entered: not loaded twice)
     L.aux[s] = na;
     Node nn = me;
     nn.pos = x; nn.speed = vn; nn.fl = (uint8_t)(me.fl & fl_mh(t));
@@ -939,12 +951,12 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
 RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, const uint16_t *grid, int t, int d) {
     if ((int)L.dep_t[d] > t) return false;           // nothing due on this lane (the common case: no global access)
     const int k = L.dep[d];
-    const int dl = T.cold.dep_lane[d];
-    const LaneRec LR = T.lanes()[dl];
+    // (one 8-byte record per departure lane instead of lane id -> lane record: the two loads of this check are independent)
+    const DepInfo LR = T.cold.dep_info[d];
     const float *vt = L.vtp + T.trip_vtype()[k] * VT_COLS;
     const float mypos = vt[VT_LENGTH] < LR.len ? vt[VT_LENGTH] : LR.len;
     // only vehicles with pos - length < mypos + minGap can be in the way
-    const int nc = lane_cells(LR);
+    const int nc = (int)(LR.len * CELL_INV) + 1;      // lane_cells()
     const int c1 = LR.cell0 + cell_of(mypos + vt[VT_MINGAP] + T.maxlen, nc);
     for (int c = scan_up(grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(grid, c + 1, c1) : -1))
         for (int o = grid[c] & NIL; o != NIL;) { RS_CHAIN_GUARD

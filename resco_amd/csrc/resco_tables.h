@@ -75,11 +75,13 @@ struct __attribute__((aligned(16))) RouteRec {
 #define NLINK_NONE 0x7FFF       // L.nlink value: link index (0x7FFF none), bit 15 = the link owns an approach register
 #define NLINK_ARR 0x8000
 
+struct DepInfo { float len; uint16_t cell0, lane; };
 // tables used rarely (per signal, per departure lane, at load / observe): reached through one pointer
 struct KCold {
     const int32_t *trip_depart;
     const uint16_t *trip_next;          // next trip with the same departure lane (TRIP_NONE: last)
     const uint16_t *dep_lane;           // [n_dep] lane of each departure lane, ascending
+    const struct DepInfo *dep_info;     // [n_dep] what the insertion check needs to know about that lane: one 8-byte load
     const uint16_t *dep_first;          // [n_dep] its first trip
     const float *vtype_params;
     const uint8_t *tls8, *fix8;
@@ -158,6 +160,8 @@ struct PackedTables {
     std::vector<RouteRec> routes;
     std::vector<uint16_t> next_link, trip_route, trip_next, dep_lane, dep_first;
     std::vector<uint8_t> trip_vtype, tls8, fix8;
+    std::vector<DepInfo> dep_info;
+    std::vector<int32_t> tls_off_p, fix_off_p;      // byte offset of signal s's first row in tls8 / fix8 (rows padded to tls_maxl bytes)
     std::vector<int16_t> lane_obs16;
     std::vector<int32_t> obs_sig;
     int n_cells = 0, n_arr = 1, n_dep = 1, kmax = 1, lmax = 1, tls_maxl = 1;
@@ -323,9 +327,23 @@ struct PackedTables {
             trip_next[k] = dep_first[d];
             dep_first[d] = (uint16_t)k;
         }
-        tls8.resize((size_t)(sc->n_tls_states > 0 ? sc->n_tls_states : 1)); fix8.resize((size_t)(sc->n_fix_states > 0 ? sc->n_fix_states : 1));
-        for (int i = 0; i < sc->n_tls_states; ++i) tls8[i] = (uint8_t)sc->tls_states[i];
-        for (int i = 0; i < sc->n_fix_states; ++i) fix8[i] = (uint8_t)sc->fix_states[i];
+        // link states per (signal, phase): one row of tls_maxl bytes (a multiple of 4, zero padded) per phase, so that a phase
+        // change copies a row into the working memory with a handful of independent 32-bit loads instead of one byte at a time
+        tls_maxl = (tls_maxl + 3) & ~3;
+        dep_info.clear();
+        for (size_t d = 0; d < dep_lane.size(); ++d) dep_info.push_back(DepInfo{lanes[dep_lane[d]].len, lanes[dep_lane[d]].cell0, dep_lane[d]});
+        tls_off_p.assign((size_t)sc->n_signals, 0); fix_off_p.assign((size_t)sc->n_signals, 0);
+        tls8.clear(); fix8.clear();
+        for (int s = 0; s < sc->n_signals; ++s) {
+            const int n = sc->tls_nlinks[s];
+            tls_off_p[(size_t)s] = (int32_t)tls8.size();
+            for (int ph = 0; ph < sc->tls_nphase[s]; ++ph)
+                for (int i = 0; i < tls_maxl; ++i) tls8.push_back(i < n ? (uint8_t)sc->tls_states[sc->tls_state_off[s] + ph * n + i] : (uint8_t)0);
+            fix_off_p[(size_t)s] = (int32_t)fix8.size();
+            for (int ph = 0; ph < sc->fix_nphase[s]; ++ph)
+                for (int i = 0; i < tls_maxl; ++i) fix8.push_back(i < n ? (uint8_t)sc->fix_states[sc->fix_state_off[s] + ph * n + i] : (uint8_t)0);
+        }
+        tls8.resize(tls8.size() + 64, 0); fix8.resize(fix8.size() + 64, 0);       // (a row copy reads whole dwords up to 32 bytes)
         return true;
     }
 };

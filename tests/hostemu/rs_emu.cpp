@@ -164,14 +164,14 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     K.lanes_ = PT.lanes.data(); K.links_ = PT.links.data(); K.foes_ = PT.foes.data(); K.rsteps_ = PT.rsteps.data();
     K.route_cont_ = h->route_cont.data(); K.next_link_ = PT.next_link.data(); K.routes_ = PT.routes.data();
     K.trip_route_ = PT.trip_route.data(); K.trip_vtype_ = PT.trip_vtype.data();
-    c.trip_depart = keep_i32(h, sc->trip_depart, sc->n_trips); c.trip_next = PT.trip_next.data(); c.dep_lane = PT.dep_lane.data(); c.dep_first = PT.dep_first.data();
+    c.trip_depart = keep_i32(h, sc->trip_depart, sc->n_trips); c.trip_next = PT.trip_next.data(); c.dep_lane = PT.dep_lane.data(); c.dep_info = PT.dep_info.data(); c.dep_first = PT.dep_first.data();
     c.vtype_params = h->vtype_params.data(); c.tls8 = PT.tls8.data(); c.fix8 = PT.fix8.data();
     c.tls_nphase = keep_i32(h, sc->tls_nphase, sc->n_signals); c.tls_ngreen = keep_i32(h, sc->tls_ngreen, sc->n_signals);
-    c.tls_nlinks = keep_i32(h, sc->tls_nlinks, sc->n_signals); c.tls_state_off = keep_i32(h, sc->tls_state_off, sc->n_signals);
+    c.tls_nlinks = keep_i32(h, sc->tls_nlinks, sc->n_signals); c.tls_state_off = PT.tls_off_p.data();
     c.tls_dur_off = keep_i32(h, sc->tls_dur_off, sc->n_signals); c.tls_yel_off = keep_i32(h, sc->tls_yel_off, sc->n_signals);
     c.tls_dur = keep_i32(h, sc->tls_dur, sc->n_tls_dur); c.tls_yellow = keep_i32(h, sc->tls_yellow, sc->n_tls_yellow);
     c.tls_init_phase = keep_i32(h, sc->tls_init_phase, sc->n_signals);
-    c.fix_nphase = keep_i32(h, sc->fix_nphase, sc->n_signals); c.fix_state_off = keep_i32(h, sc->fix_state_off, sc->n_signals);
+    c.fix_nphase = keep_i32(h, sc->fix_nphase, sc->n_signals); c.fix_state_off = PT.fix_off_p.data();
     c.fix_dur_off = keep_i32(h, sc->fix_dur_off, sc->n_signals); c.fix_dur = keep_i32(h, sc->fix_dur, sc->n_fix_dur);
     c.fix_init_phase = keep_i32(h, sc->fix_init_phase, sc->n_signals); c.fix_init_left = keep_i32(h, sc->fix_init_left, sc->n_signals);
     c.lane_obs = PT.lane_obs16.data(); c.obs_sig = PT.obs_sig.data(); c.sig_obs_start = keep_i32(h, sc->sig_obs_start, sc->n_signals + 1);
