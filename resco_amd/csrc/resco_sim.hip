@@ -75,6 +75,11 @@ __device__ __forceinline__ uint16_t rs_f2h(float x) { return __half_as_ushort(__
 extern __shared__ __attribute__((aligned(16))) char rs_smem[];      // THE working memory of a workgroup (dynamic LDS)
 #define RS_SMEM rs_smem
 
+#ifdef RS_STUDY_SECTIONS       // study build: where inside the long path of the plan a wave's time goes (tools/phase_profile.py --sections)
+__device__ unsigned long long *g_sec_prof;
+#define RS_SEC_BEGIN unsigned long long sec_t = wall_clock64();
+#define RS_SEC(id) { const unsigned long long sec_1 = wall_clock64(); if (g_sec_prof && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicAdd(&g_sec_prof[id], (sec_1 - sec_t) + (1ull << 40)); sec_t = wall_clock64(); }
+#endif
 #include "resco_step.h"
 #include "resco_policy.h"
 
@@ -109,6 +114,9 @@ struct DevExec {
     // time a wave spends in one role of a phase: sum of the 100 MHz ticks in the low 40 bits, number of waves above
     __device__ __forceinline__ unsigned long long role_begin() const { return prof ? wall_clock64() : 0ull; }
     __device__ __forceinline__ void role_end(int id, unsigned long long start) const {
+#ifdef RS_STUDY_SECTIONS
+        return;
+#endif
         if (prof && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicAdd(&prof[id], (wall_clock64() - start) + (1ull << 40));   // (every 16th environment: the sum stays below 2^40)
     }
 };
@@ -126,6 +134,9 @@ __global__ void __launch_bounds__(1024, 8)
 rs_step_kernel_v64(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
     if ((int)blockIdx.x >= P.n_envs) return;
     const StepArgs *A = (const StepArgs *)Ac;
+#ifdef RS_STUDY_SECTIONS
+    if (threadIdx.x == 0) g_sec_prof = P.prof;
+#endif
     DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
     rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
 }
@@ -134,6 +145,9 @@ __global__ void __launch_bounds__(768, 6)
 rs_step_kernel_v80(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
     if ((int)blockIdx.x >= P.n_envs) return;
     const StepArgs *A = (const StepArgs *)Ac;
+#ifdef RS_STUDY_SECTIONS
+    if (threadIdx.x == 0) g_sec_prof = P.prof;
+#endif
     DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
     rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
 }
@@ -142,6 +156,9 @@ __global__ void __launch_bounds__(512, 4)
 rs_step_kernel_v128(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
     if ((int)blockIdx.x >= P.n_envs) return;
     const StepArgs *A = (const StepArgs *)Ac;
+#ifdef RS_STUDY_SECTIONS
+    if (threadIdx.x == 0) g_sec_prof = P.prof;
+#endif
     DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
     rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
 }

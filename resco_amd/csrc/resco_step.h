@@ -216,6 +216,9 @@ struct Lds {
 #ifndef RS_LIST_CHUNK
 #define RS_LIST_CHUNK 64
 #endif
+#ifndef RS_H_CHUNK
+#define RS_H_CHUNK RS_LIST_CHUNK     // entries of the look-ahead list per chunk
+#endif
 
 RS_CARVE size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 // Layout of the working memory: a table of offsets computed once by the host (read from the constant argument block, so an
@@ -263,6 +266,13 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
 #define RS_CHAIN_GUARD if (++rs_dbg_chain > 50000000L) { printf("endless chain walk\n"); fflush(stdout); abort(); }
 #else
 #define RS_CHAIN_GUARD
+#endif
+#ifndef RS_ASSERT
+#define RS_ASSERT(c)
+#endif
+#ifndef RS_SEC             // section timers of a study build (resco_sim.hip)
+#define RS_SEC_BEGIN
+#define RS_SEC(id) {}
 #endif
 RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
 RS_DEV int lane_cells(const LaneRec &LR) { return (int)(LR.len * CELL_INV) + 1; }
@@ -614,8 +624,11 @@ RS_DEV int classify(const Lds &L, int s, const float *vt, float v, float x, cons
 }
 
 // ------------------------------------------------------------------------------------------------ the phases
-// P: plan (Krauss car-following + links) for slot s
-RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
+// P: plan (Krauss car-following + links) for slot s.  LONG = false: the short path, for a vehicle WITHOUT FL_H -- nothing beyond
+// the end of its lane is inside its look-ahead (classify() decided that on the very state this plan sees; the host emulation
+// checks it) --, so the walk over the links is not compiled into what the waves on the short path run.
+template <bool LONG> RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
+    RS_SEC_BEGIN
     const Aux ax = L.aux[s];
     const int lane = ax.lane;
     if (lane == (int)LANE_NONE) return;
@@ -635,7 +648,9 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const 
     float tgap = 0.0f, tvl = 0.0f, tbl = b;
     bool have = false;
     const float look = plan_look(vt, vfree);
+    if (LONG) RS_SEC(7)
     const int lead = leader_within(L, grid, LR.cell0, lane_cells(LR), x, k, s, look + T.maxlen);
+    if (LONG) RS_SEC(8)
     bool found = false;
     if (lead != NIL) {
         const Node ld = L.node[lead];
@@ -649,8 +664,10 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const 
         if (c1 != COOP_NONE) { G.coop((t + 1) & 1)[eo + s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
         if (c2 != COOP_NONE) { G.cooplead((t + 1) & 1)[eo + s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
     }
+    if (LONG) RS_SEC(9)
     float seen = LR.len - x;
-    if (!found && seen < look) {
+    RS_ASSERT(LONG || found || !(seen < look))
+    if (LONG && !found && seen < look) {
         int rq = ax.rq;
         int link = (int)(ax.nlink & 0x7FFF);
         int cur_lane = lane;
@@ -703,6 +720,7 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const 
             if (!(seen < look)) break;
         }
     }
+    if (LONG) RS_SEC(10)
     if (have) {
         const float vs = d_follow_speed(tgap, tvl, b, tbl, tau);
         if (vs < vsafe) vsafe = vs;
@@ -727,13 +745,15 @@ RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const 
         printf("plan t %d slot %d lane %d x %.3f v %.3f lead %d have %d tgap %.3f tvl %.3f vsafe %.3f vfree %.3f vnext %.3f nlink %x\n", t, s, lane, x, v, lead,
                (int)have, tgap, tvl, vsafe, vfree, vnext, ax.nlink);
 #endif
+    if (LONG) RS_SEC(3)
     if (x + vnext > LR0.len) flag_mover(L, s, t);
+    if (LONG) RS_SEC(15)
     (void)LR;
 }
 
 // M: move slot s -- sideways first (the lane change decided in the plan phase), then forward, over to the next lanes, or
 // out of the network; leave the old grid, enter the new one; register the approach of the coming tick
-RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gnew, const State &G, const KParams &P, int env, size_t eo,
+template <bool LONG> RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gnew, const State &G, const KParams &P, int env, size_t eo,
                        int t, bool last_tick, bool more, int s, int &active, int &halted, int &top) {
     const Aux ax = L.aux[s];
     const Node me = L.node[s];
@@ -762,11 +782,14 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     int link = (int)(nlink & 0x7FFF);
     bool relink = false;
     int side = 0;
-    if (me.fl & (LCT_LEFT | LCT_RIGHT | LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) {
+    // LONG = false: a vehicle WITHOUT this tick's FL_MH -- its plan found that it stays on its lane and no lane change was decided --:
+    // the hand-over, the arrival and the sideways move are not compiled into the code the waves on the short path run
+    RS_ASSERT(LONG || (!(me.fl & (LCT_LEFT | LCT_RIGHT | LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) && !(me.pos + vn > LR.len)))
+    if (LONG && (me.fl & (LCT_LEFT | LCT_RIGHT | LCT_SWAP_LEFT | LCT_SWAP_RIGHT))) {
         if ((me.fl & (LCT_LEFT | LCT_RIGHT)) && !(me.pos + vn > LR.len)) side = (me.fl & LCT_LEFT) ? +1 : -1;
         else if (me.fl & (LCT_SWAP_LEFT | LCT_SWAP_RIGHT)) side = (me.fl & LCT_SWAP_LEFT) ? +1 : -1;
     }
-    if (side) {
+    if (LONG && side) {
         lane += side;
         LR = T.lanes()[lane];
         nlink = cache_link(T, LR, lane, rq, k);
@@ -783,7 +806,7 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss()[eo + s] = tl; }
     float x = me.pos + vn;
     bool arrived = false;
-    for (int it = 0; it < 16; ++it) {
+    if (LONG) for (int it = 0; it < 16; ++it) {
         if (!(x > LR.len)) break;
         const bool li = (LR.flags & LF_INTERNAL) != 0;
         if (link == NLINK_NONE) {
@@ -801,7 +824,7 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
         link = (int)(nlink & 0x7FFF);
         relink = true;
     }
-    if (arrived) {
+    if (LONG && arrived) {
         Aux na = ax; na.lane = LANE_NONE; na.swait = 0;
         L.aux[s] = na;
         L.node[s].trip = TRIP_NONE; L.node[s].fl = (uint8_t)(me.fl & fl_mh(t));
@@ -826,13 +849,13 @@ RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gn
     if (s + 1 > top) top = s + 1;
     Aux na = ax;
     na.lane = (uint16_t)lane; na.rq = (uint16_t)rq; na.swait = (uint16_t)swn;
-    if (relink) na.nlink = nlink;           // (looked up when the lane was entered: not loaded twice)
+    if (LONG && relink) na.nlink = nlink;           // (looked up when the lane was entered: not loaded twice)
     L.aux[s] = na;
     Node nn = me;
     nn.pos = x; nn.speed = vn; nn.fl = (uint8_t)(me.fl & fl_mh(t));
     nn.nxt = grid_push(gnew, LR.cell0 + cell_of(x, lane_cells(LR)), s, vn > RM_HALT_SPEED);
     if (more) {
-        if (relink) { R = cont_row(T, rq); if (na.nlink & NLINK_ARR) kw = link_reg_word(T, na.nlink); }
+        if (LONG && relink) { R = cont_row(T, rq); if (na.nlink & NLINK_ARR) kw = link_reg_word(T, na.nlink); }
         nn.fl |= classify(L, s, L.vtp + me.vt * VT_COLS, vn, x, LR, lane, R, k, sfv, t + 1);
         L.node[s] = nn;
         if ((na.nlink & NLINK_ARR) && vn > RM_HALT_SPEED) register_approach_w(T, L, kw, vn, x, LR.len, me.vt);
@@ -862,7 +885,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
     if ((LR.flags & LF_INTERNAL) || n < 2) return 0;
     const int dir_allowed = (t & 1) ? -1 : +1;
     const int l0 = LR.edge_lane0, kk = lane - l0;
-    const int k = me.trip, rq = ax.rq;
+    const int k = me.trip;
     const float *vt = L.vtp + me.vt * VT_COLS;
     const float x = me.pos, v = me.speed;
     const int nc = lane_cells(LR);
@@ -1098,21 +1121,21 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                             if (ax.lane == LANE_NONE) continue;
                             const int code = phase_lc_decide(T, L, gold, G, eo, t, w, ax, L.node[w]);
                             if (code) flag_mover(L, w, t, code);
-                        } else phase_plan(T, L, gold, G, eo, P, genv, t, w);
+                        } else phase_plan<true>(T, L, gold, G, eo, P, genv, t, w);
                     }
             } else {
                 // The work of the phase in chunks, longest code path first: the look-ahead list (RS_LIST_CHUNK entries per chunk), the
                 // lane-change list, then the slots on the short path (64 per chunk).  A wave takes the next chunk when it is done
                 // with its last one, so the phase ends when the work is done, not when the slowest of three fixed roles is.
-                const int hch = (nh + RS_LIST_CHUNK - 1) / RS_LIST_CHUNK, lch = (nlc + RS_LIST_CHUNK - 1) / RS_LIST_CHUNK;
+                const int hch = (nh + RS_H_CHUNK - 1) / RS_H_CHUNK, lch = (nlc + RS_LIST_CHUNK - 1) / RS_LIST_CHUNK;
                 const int total = hch + lch + ((hw + 63) >> 6);
                 for (int it = 0;; ++it) {
                     const int c = ex.next_chunk(&L.sc[SC_CHUNK_P], wv, it, nwv);
                     if (c >= total) break;
                     if (c < hch) {                                  // plan of a vehicle that looks beyond its lane
                         role = 1;
-                        const int w = c * RS_LIST_CHUNK + ln;
-                        if (ln < RS_LIST_CHUNK && w < nh) phase_plan(T, L, gold, G, eo, P, genv, t, L.ls_h[w]);
+                        const int w = c * RS_H_CHUNK + ln;
+                        if (ln < RS_H_CHUNK && w < nh) phase_plan<true>(T, L, gold, G, eo, P, genv, t, L.ls_h[w]);
                     } else if (c < hch + lch) {                     // lane-change decision
                         role = 2;
                         const int w = (c - hch) * RS_LIST_CHUNK + ln;
@@ -1126,7 +1149,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                         }
                     } else {                                        // plan on the short path
                         const int w = (c - hch - lch) * 64 + ln;
-                        if (w < hw && !(L.node[w].fl & FL_H)) phase_plan(T, L, gold, G, eo, P, genv, t, w);
+                        if (w < hw && !(L.node[w].fl & FL_H)) phase_plan<false>(T, L, gold, G, eo, P, genv, t, w);
                     }
                 }
             }
@@ -1168,7 +1191,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 if (c < mch) {
                     list = true;
                     const int w = c * RS_LIST_CHUNK + ln;
-                    if (ln < RS_LIST_CHUNK && w < nmh) phase_move(T, L, gold, gnew, G, P, env, eo, t, !more, more, L.ls_mh[w], active, halted, top);
+                    if (ln < RS_LIST_CHUNK && w < nmh) phase_move<true>(T, L, gold, gnew, G, P, env, eo, t, !more, more, L.ls_mh[w], active, halted, top);
                 } else if (c < mch + ich) {
                     // the winners of the departure lanes take the slots that were free at the beginning of the tick, lower lane first
                     for (int d = 63 - ln; d < T.n_dep; d += 64) {
@@ -1211,8 +1234,10 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                 } else {
                     const int w = (c - mch - ich) * 64 + ln;
                     // (the vehicles of the list have FL_MH of this tick's parity set: their chunk moves them)
-                    if (w < hw && (L.alive0[w >> 5] & (1u << (w & 31))) && (all || !(L.node[w].fl & fl_mh(t))))
-                        phase_move(T, L, gold, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
+                    if (w < hw && (L.alive0[w >> 5] & (1u << (w & 31)))) {
+                        if (all) phase_move<true>(T, L, gold, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
+                        else if (!(L.node[w].fl & fl_mh(t))) phase_move<false>(T, L, gold, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
+                    }
                 }
             }
             ex.role_end(list ? 10 : 3, r0);

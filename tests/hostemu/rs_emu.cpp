@@ -21,6 +21,8 @@
 #define RS_CARVE static inline
 static char *g_smem = nullptr;
 #define RS_SMEM g_smem
+// an invariant of the kernel source the emulation checks (the device build compiles it out)
+#define RS_ASSERT(c) if (!(c)) { fprintf(stderr, "rs_emu: invariant violated: %s (resco_step.h:%d)\n", #c, __LINE__); abort(); }
 static inline void rs_atomic_min(int32_t *p, int32_t v) { if (v < *p) *p = v; }
 static inline void rs_atomic_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
 static inline void rs_atomic_max(int32_t *p, int32_t v) { if (v > *p) *p = v; }

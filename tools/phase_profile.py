@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """In-kernel phase timers of the step kernel (rs_phase_profile): share of every phase in a workgroup's wall time.
-python tools/phase_profile.py [map] [envs] [block]"""
+python tools/phase_profile.py [map] [envs] [block] [--sections]
+--sections: the library in RESCO_SIM_LIB is a study build (tools/ab.py build "sec:-DRS_STUDY_SECTIONS"): the role counters hold
+the time a wave spends in the sections of the long path of the plan (one look-ahead chunk) instead."""
 import os, sys
+SECTIONS = '--sections' in sys.argv
+if SECTIONS:
+    sys.argv.remove('--sections')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from resco_amd.scenario import Scenario
@@ -19,7 +24,10 @@ for k in range(100, 160):
     sim.act_random(k); sim.step(None)
 acc = sim.phase_profile(False)
 names = ['L0 init', 'L1 load+prep', 'L2 register', '-', 'P plan+lc', 'C insert?+tls', 'M move+insert', '-', '-', '-', '-', 'O0', 'O1 observe', 'O2 outputs', 'O3', '-']
-roles = {7: 'P look-ahead list', 8: 'P lane-change list', 9: 'P slots', 10: 'M leavers list', 3: 'M slots', 15: 'M whole body'}
+if SECTIONS:
+    roles = {7: 'H plan: own records', 8: 'H plan: leader on the lane', 9: 'H plan: leader found + cooperation', 10: 'H plan: walk over the links', 3: 'H plan: safe speed + dawdling', 15: 'H plan: mover flag'}
+else:
+    roles = {7: 'P look-ahead list', 8: 'P lane-change list', 9: 'P slots', 10: 'M leavers list', 3: 'M slots', 15: 'M whole body'}
 tot = float(sum(a for i, a in enumerate(acc) if i not in roles)) or 1.0
 for i, (nm, a) in enumerate(zip(names, acc)):
     if i not in roles and nm != '-':
