@@ -390,9 +390,10 @@ def main():
         'mean_active_vehicles_per_env': mean_active,
         'sim_ticks_per_s': value * 10, 'vehicle_ticks_per_s': value * 10 * mean_active,
         'all_outputs': {'value': world * n_local * all_out_rate if all_out_rate else None, 'unit': 'env-steps/s', 'steps': min(args.steps, 20, args.warmup),
-                        'note': 'rank 0, the last warm-up steps (right before the timed window) with EVERY derived buffer written (lane_agg, drq_norm, '
-                                'wave, mplight, mplight_full, drq_norm_f16, lane_arrivals): rounds 1-2 measured this workload, rounds 3-4 write what '
-                                'config 3 consumes'},
+                        'episode_window': [w0 - min(args.steps, 20, args.warmup), w0],
+                        'note': 'rank 0, the last warm-up steps (right before the timed window: the network is as loaded as at its first step, '
+                                'not as on its average) with EVERY derived buffer written (lane_agg, drq_norm, wave, mplight, mplight_full, '
+                                'drq_norm_f16, lane_arrivals): rounds 1-2 measured this workload, rounds 3-4 write what config 3 consumes'},
     }
     if args.digest:
         out['state_digest'] = state_digest(sims, dist, rank, world)
