@@ -435,8 +435,13 @@ def _dijkstra(succ, cost, src, dst):
 
 
 def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_map, lights=(),
-                     yellow_length=3, capacity=None) -> Scenario:
+                     yellow_length=3, capacity=None, minor_penalty=0.0, turnaround_penalty=0.0) -> Scenario:
     """Build the flat tables for one map.
+
+    minor_penalty / turnaround_penalty (seconds, both 0 in the shipped scenarios): router cost terms of SUMO that the shipped
+    cost model (edge length / speed + junction-lane time) leaves out [SUMO-K: --weights.minor-penalty, 1.5 s per junction lane
+    entered over a link that is neither traffic-light controlled nor has priority; --weights.turnaround-penalty].  They exist for
+    tools/route_sensitivity.py, which re-routes the demand with them and reports what moves (profiles/r05_route_sensitivity.txt).
 
     sig_cfg_map = signal_configs[map] (the reference's per-map dict: phase_pairs, valid_acts, per-signal
     lane_sets/downstream; resco_benchmark/config/signal_config.py).
@@ -494,8 +499,22 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
             cost[eid] = edge_len(eid) / edge_speed(eid)
     succ = {}
     pair_w = {}
+    def via_penalty(c):
+        """[SUMO-K MSEdge::recalcCache] every junction lane whose incoming link is uncontrolled and minor costs `minor_penalty`"""
+        pen = turnaround_penalty if c.dir == 't' else 0.0
+        cc, guard = c, 0
+        while cc is not None and cc.via is not None and guard < 4:
+            if cc.tl is None and not ('A' <= cc.state[:1] <= 'Z'):
+                pen += minor_penalty
+            vl = L[cc.via]
+            cc = next(iter(conn_by_from.get((vl.edge, vl.index), ())), None)
+            guard += 1
+        return pen
+
     for c in nconns:
         w = sum(L[v].length / max(L[v].speed, 0.1) for v in via_chain(c))
+        if minor_penalty or turnaround_penalty:
+            w += via_penalty(c)
         key = (c.frm, c.to)
         if key not in pair_w or w < pair_w[key]:
             pair_w[key] = w
@@ -863,12 +882,13 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
                   valid_acts=sig_cfg_map.get('valid_acts'),
                   demand_tag='vehicle' if any(t[5] is not None for t in trips_xml) else 'trip')
     sc.dropped_trips = dropped
+    sc.router = dict(cost=cost, succ=succ, od_route=od_route)      # host-side only (not saved): tools/route_sensitivity.py
     return sc
 
 
-def compile_from_sumocfg(name, sumocfg_path, sig_cfg_map, lights=(), yellow_length=3, capacity=None):
+def compile_from_sumocfg(name, sumocfg_path, sig_cfg_map, lights=(), yellow_length=3, capacity=None, **router):
     net_path, rou_path, begin, end = parse_sumocfg(sumocfg_path)
     net = parse_net(net_path)
     vtypes, trips = parse_routes(rou_path)
     return compile_scenario(name, net, vtypes, trips, begin, end, sig_cfg_map, lights=lights,
-                            yellow_length=yellow_length, capacity=capacity)
+                            yellow_length=yellow_length, capacity=capacity, **router)
