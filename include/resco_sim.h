@@ -87,6 +87,13 @@ typedef struct rs_params {
     int32_t step_ratio;       /* simulation steps per step_sim() call (MultiSignal(step_ratio=...), multi_signal.py:102-105): an env-step runs
                                * yellow_length x step_ratio ticks before Signal.set_phase and step_length x step_ratio ticks in all; the
                                * RESCO waiting rule still adds step_length per observe (traffic_signal.py:196).  0 or 1: one */
+    int32_t tls_expiry;       /* what trafficlight.setPhase (Signal.prep_phase / set_phase, traffic_signal.py:176-187) leaves behind:
+                               * 0 (default) the phase stays until the next setPhase; 1 it expires after its programme duration and the
+                               * programme continues with the next index, i -> i + 1 (mod P) -- what SUMO's setPhase is documented to do
+                               * [SUMO-K], under which a 6 s green chosen for a 10 s step hands its 7th second to the next phase of the list.
+                               * Neither is pinned against a SUMO binary; 0 is the default because it reproduces the reference-held
+                               * random-policy figures of five maps and 1 does not (profiles/r05_tls_expiry_bands.txt).
+                               * The net's own programme (fixed_program) and the phase installed at reset always run on their durations */
 } rs_params;
 
 typedef struct rs_sim *rs_handle;

@@ -479,7 +479,7 @@ RS_DEV void tls_refresh(const KTab &T, const Lds &L, const KParams &P, int s, in
 RS_DEV void set_phase(const KTab &T, const Lds &L, const KParams &P, int s, int ph) {
     if (ph < 0 || ph >= T.cold.tls_nphase[s]) return;
     L.phase[s] = ph;
-    L.left[s] = T.cold.tls_dur[T.cold.tls_dur_off[s] + ph];
+    L.left[s] = P.tls_expiry ? T.cold.tls_dur[T.cold.tls_dur_off[s] + ph] : RM_TLS_HOLD_TICKS;      // rs_params.tls_expiry
     tls_refresh(T, L, P, s, ph);
 }
 // TLS switch events at the beginning of tick `tick` of this launch, preceded by Signal.set_phase when the yellow

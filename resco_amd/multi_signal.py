@@ -100,7 +100,7 @@ class MultiSignal(_EnvBase):
     def __init__(self, run_name, map_name, net, state_fn, reward_fn, route=None, gui=False, end_time=3600,
                  step_length=10, yellow_length=4, step_ratio=1, max_distance=200, lights=(), log_dir='/',
                  libsumo=False, warmup=0, gymma=False, *, device=0, seed=None, sigma=-1.0, speed_dev=1,
-                 fixed_program=False, scenario=None, use_fast_path=True, tripinfo=True):
+                 fixed_program=False, scenario=None, use_fast_path=True, tripinfo=True, tls_expiry=False):
         if int(step_ratio) < 1:
             raise ValueError('step_ratio must be a positive integer')
         self.libsumo, self.gymma, self.gui = libsumo, gymma, gui
@@ -131,7 +131,8 @@ class MultiSignal(_EnvBase):
         self._sim_kw = dict(device=device, max_distance=max_distance, sigma=sigma, speed_dev=speed_dev,
                             fixed_program=1 if fixed_program else 0, step_length=step_length, yellow_length=yellow_length,
                             trip_log=1 if tripinfo else 0,
-                            step_ratio=step_ratio)      # multi_signal.py:102-105: step_sim() = step_ratio simulation steps
+                            step_ratio=step_ratio,      # multi_signal.py:102-105: step_sim() = step_ratio simulation steps
+                            tls_expiry=1 if tls_expiry else 0)       # include/resco_sim.h: what setPhase leaves behind
         self.sim = BatchedSim(sc, 1, seed=self._base_seed, **self._sim_kw)
         self.tripinfo = tripinfo
         self.view_env = 0
@@ -368,14 +369,14 @@ class VecMultiSignal:
 
     def __init__(self, map_name, n_envs, states=('drq_norm',), rewards=('wait',), net=None, device=0, seed=0,
                  max_distance=200, step_length=10, yellow_length=3, sigma=-1.0, speed_dev=1, fixed_program=False,
-                 env_base=0, block_threads=0, scenario=None, outputs=None, step_ratio=1):
+                 env_base=0, block_threads=0, scenario=None, outputs=None, step_ratio=1, tls_expiry=False):
         mc = map_configs.get(map_name, {})
         self.scenario = scenario if scenario is not None else load_scenario(map_name, net, mc.get('lights', ()),
                                                                             yellow_length)
         self.sim = BatchedSim(self.scenario, n_envs, device=device, seed=seed, max_distance=max_distance,
                               sigma=sigma, speed_dev=speed_dev, fixed_program=1 if fixed_program else 0,
                               env_base=env_base, step_length=step_length, yellow_length=yellow_length,
-                              block_threads=block_threads, step_ratio=step_ratio)
+                              block_threads=block_threads, step_ratio=step_ratio, tls_expiry=1 if tls_expiry else 0)
         self.n_envs, self.n_signals = n_envs, self.scenario.n_signals
         self.state_names, self.reward_names = tuple(states), tuple(rewards)
         self.step_length = step_length

@@ -435,13 +435,15 @@ def _dijkstra(succ, cost, src, dst):
 
 
 def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_map, lights=(),
-                     yellow_length=3, capacity=None, minor_penalty=0.0, turnaround_penalty=0.0) -> Scenario:
+                     yellow_length=3, capacity=None, minor_penalty=1.5, turnaround_penalty=0.0) -> Scenario:
     """Build the flat tables for one map.
 
-    minor_penalty / turnaround_penalty (seconds, both 0 in the shipped scenarios): router cost terms of SUMO that the shipped
-    cost model (edge length / speed + junction-lane time) leaves out [SUMO-K: --weights.minor-penalty, 1.5 s per junction lane
-    entered over a link that is neither traffic-light controlled nor has priority; --weights.turnaround-penalty].  They exist for
-    tools/route_sensitivity.py, which re-routes the demand with them and reports what moves (profiles/r05_route_sensitivity.txt).
+    minor_penalty / turnaround_penalty (seconds): router cost terms next to edge length / speed + junction-lane time.  [SUMO-K]
+    `--weights.minor-penalty` (default 1.5 s): every junction lane entered over a link that is neither traffic-light controlled nor
+    has priority costs that much more (MSEdge::recalcCache) -- part of the shipped cost model since round 5: it re-routes 583 of
+    ingolstadt21's 4283 trips and moves that map's FIXED / random-policy delays from 2.07 x / 1.27 x to 1.72 x / 1.05 x of the
+    reference's (profiles/r05_route_sensitivity.txt, tools/route_sensitivity.py).  `--weights.turnaround-penalty` (later SUMO
+    versions) moves 6 trips and nothing else: left at 0.
 
     sig_cfg_map = signal_configs[map] (the reference's per-map dict: phase_pairs, valid_acts, per-signal
     lane_sets/downstream; resco_benchmark/config/signal_config.py).

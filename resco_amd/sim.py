@@ -145,7 +145,8 @@ class BatchedSim:
     """N lock-step environments of one scenario on one GPU (one rs_handle)."""
 
     def __init__(self, scenario, n_envs, device=0, seed=0, max_distance=200.0, sigma=-1.0, speed_dev=1,
-                 fixed_program=0, env_base=0, step_length=10, yellow_length=None, block_threads=0, trip_log=0, step_ratio=1):
+                 fixed_program=0, env_base=0, step_length=10, yellow_length=None, block_threads=0, trip_log=0, step_ratio=1,
+                 tls_expiry=0):
         self.sc = scenario
         self.n_envs = int(n_envs)
         self.device = int(device)
@@ -156,7 +157,7 @@ class BatchedSim:
             raise ValueError('scenario %s was compiled with yellow_length=%d (asked %d)' % (scenario.name, scenario.yellow_length, yellow_length))
         self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
         self._p = ParamsStruct(int(seed) & 0xFFFFFFFF, float(max_distance), float(sigma), int(speed_dev),
-                               int(fixed_program), int(trip_log), int(step_ratio))
+                               int(fixed_program), int(trip_log), int(step_ratio), 1 if tls_expiry else 0)
         self.step_ratio = max(1, int(step_ratio))
         self._h = C.c_void_p()
         rc = self._lib.rs_create(C.byref(self._st), C.byref(self._p), self.n_envs, int(env_base), self.device,

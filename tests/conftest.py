@@ -16,7 +16,9 @@ WARM_CASES = ['ingolstadt21_d200_warm180', 'cologne8_d200_warm180']
 FULL_CASES = ['cologne1_d50_full']
 # MultiSignal(step_ratio=2): two simulation steps per step_sim() (multi_signal.py:102-105), driven by the reference's own loop
 RATIO_CASES = ['cologne8_d200_sr2']
-ALL_CASES = HOT_CASES + WARM_CASES + FULL_CASES + RATIO_CASES
+# rs_params.tls_expiry = 1 (a phase set through setPhase runs out after its programme duration; not the default)
+EXPIRY_CASES = ['cologne1_d200_exp', 'ingolstadt21_d200_exp', 'cologne8_d200_sr2_exp']
+ALL_CASES = HOT_CASES + WARM_CASES + FULL_CASES + RATIO_CASES + EXPIRY_CASES
 
 
 def pytest_configure(config):

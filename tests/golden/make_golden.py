@@ -34,6 +34,10 @@ CASES = [  # (map, steps, max_distance, pre-roll steps)
     # step_ratio = 2 (multi_signal.py:102-105: two simulationStep() per step_sim(): 6 yellow + 14 green ticks per env-step, the
     # 6 s greens of cologne8 run out twice inside one step)
     ('cologne8', 24, 200, 0, 2),
+    # rs_params.tls_expiry = 1: a phase entered through setPhase expires after its programme duration and the programme continues
+    # ([SUMO-K], what SUMO documents for setPhase; not the default, include/resco_sim.h): the 6 s greens run out inside a step, the
+    # reference's prep_phase sees the NEXT index (possibly a yellow) -- on one signal, on a corridor, with two ticks per step_sim()
+    ('cologne1', 48, 200, 0, 1, 1), ('ingolstadt21', 30, 200, 0, 1, 1), ('cologne8', 24, 200, 0, 2, 1),
 ]
 STATE_FNS = ['drq', 'drq_norm', 'mplight', 'mplight_full', 'wave']
 REWARD_FNS = ['wait', 'wait_norm', 'pressure']
@@ -50,7 +54,12 @@ def preroll_actions(sc, seed, k):
     return np.array([L.orc_hash((seed ^ 0xA5A5A5A5) & 0xFFFFFFFF, 0, s, k, 7) % int(sc.tls_ngreen[s]) for s in range(sc.n_signals)], np.int32)
 
 
-def run_case(map_name, steps, max_distance, preroll=0, step_ratio=1):
+def case_tag(map_name, steps, max_distance, preroll=0, step_ratio=1, tls_expiry=0):
+    return '%s_d%d' % (map_name, max_distance) + ('_full' if steps >= 360 else '') + ('_warm%d' % preroll if preroll else '') + \
+        ('_sr%d' % step_ratio if step_ratio != 1 else '') + ('_exp' if tls_expiry else '')
+
+
+def run_case(map_name, steps, max_distance, preroll=0, step_ratio=1, tls_expiry=0):
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', map_name + '.npz'))
     mc = map_configs[map_name]
     state = {'n': 0}
@@ -58,7 +67,7 @@ def run_case(map_name, steps, max_distance, preroll=0, step_ratio=1):
     def factory(cmd):
         # every traci.start is a fresh SUMO: the probe run of __init__ is start #0, episode k is start #k
         orc = OracleEnv(sc, env_index=0, seed=episode_seed(state['n']), max_distance=max_distance, sigma=-1.0,
-                        speed_dev=1)
+                        speed_dev=1, tls_expiry=tls_expiry)
         fresh = state['n'] == 0 or preroll == 0
         state['n'] += 1
         state['orc'] = orc
@@ -166,9 +175,9 @@ def run_case(map_name, steps, max_distance, preroll=0, step_ratio=1):
     with open(os.path.join(tmp, env.connection_name, 'metrics_1.csv')) as f:
         csv_text = f.read()
 
-    tag = '%s_d%d' % (map_name, max_distance) + ('_full' if steps >= 360 else '') + ('_warm%d' % preroll if preroll else '') + \
-        ('_sr%d' % step_ratio if step_ratio != 1 else '')
-    meta = dict(map=map_name, steps=steps, max_distance=max_distance, preroll=preroll, step_ratio=step_ratio, base_seed=BASE_SEED, seed=episode_seed(1),
+    tag = case_tag(map_name, steps, max_distance, preroll, step_ratio, tls_expiry)
+    meta = dict(map=map_name, steps=steps, max_distance=max_distance, preroll=preroll, step_ratio=step_ratio, tls_expiry=tls_expiry,
+                base_seed=BASE_SEED, seed=episode_seed(1),
                 all_ts_ids=ids, ts_order=list(env.ts_order), obs_shape={ts: list(env.obs_shape[ts]) for ts in ids},
                 n_green=n_green, connection_name=env.connection_name, metrics_csv=csv_text,
                 oracle_stats=orc_stats, signals={}, fma2c_keys=fma_keys, fma2c_shapes=fma_shapes)
@@ -193,8 +202,7 @@ def run_case(map_name, steps, max_distance, preroll=0, step_ratio=1):
 if __name__ == '__main__':
     only = sys.argv[1:]             # tags to (re)generate; none = all
     for case in CASES:
-        tag = '%s_d%d' % (case[0], case[2]) + ('_full' if case[1] >= 360 else '') + ('_warm%d' % case[3] if case[3] else '') + \
-            ('_sr%d' % case[4] if len(case) > 4 and case[4] != 1 else '')
+        tag = case_tag(*case)
         if only and tag not in only:
             continue
         run_case(*case)

@@ -95,7 +95,8 @@ def _random_configs(n, seed):
                         speed_dev=int(rng.integers(0, 2)), max_distance=float(rng.choice([1.0, 50.0, 200.0, 9999.0])),
                         fixed=int(rng.random() < 0.25), step_ratio=int(rng.choice([1, 1, 2, 3])), seed=int(rng.integers(0, 2 ** 31)),
                         env_base=int(rng.integers(0, 5000)), warm=int(rng.choice([0, 40, 90, 150])), n_envs=int(rng.integers(1, 4)),
-                        steps=int(rng.integers(12, 28)), case=i))
+                        steps=int(rng.integers(12, 28)), case=i,
+                        tls_expiry=i % 2))       # both answers to what setPhase leaves behind (rs_params.tls_expiry)
     return out
 
 
@@ -108,7 +109,7 @@ def test_randomised_parameter_sweep_bit_exact(cfg):
     from resco_amd.sim import BatchedSim
     sc = load_scenario(cfg['name'])
     kw = dict(seed=cfg['seed'], sigma=cfg['sigma'], speed_dev=cfg['speed_dev'], max_distance=cfg['max_distance'],
-              fixed_program=cfg['fixed'], step_ratio=cfg['step_ratio'])
+              fixed_program=cfg['fixed'], step_ratio=cfg['step_ratio'], tls_expiry=cfg['tls_expiry'])
     n = cfg['n_envs']
     sim = BatchedSim(sc, n, env_base=cfg['env_base'], **kw)
     orcs = [OracleEnv(sc, env_index=cfg['env_base'] + e, **kw) for e in range(n)]
@@ -210,7 +211,8 @@ def test_multisignal_matches_reference_python(tag, fast):
     tmp = tempfile.mkdtemp() + os.sep
     env = MultiSignal('golden', meta['map'], mc['net'], states.mplight, rewards.wait, step_length=mc['step_length'],
                       yellow_length=mc['yellow_length'], end_time=mc['end_time'], max_distance=meta['max_distance'],
-                      lights=mc['lights'], log_dir=tmp, seed=meta['base_seed'], use_fast_path=fast, step_ratio=meta.get('step_ratio', 1))
+                      lights=mc['lights'], log_dir=tmp, seed=meta['base_seed'], use_fast_path=fast, step_ratio=meta.get('step_ratio', 1),
+                      tls_expiry=meta.get('tls_expiry', 0))
     ids = meta['all_ts_ids']
     assert env.all_ts_ids == ids and env.ts_order == meta['ts_order']
     assert {k: list(v) for k, v in env.obs_shape.items()} == meta['obs_shape']
@@ -882,38 +884,41 @@ def test_fused_policy_sampling_mode_follows_the_softmax():
 # The dynamics are this build's own model (PARITY-UNPINNED vs SUMO); these are the only reference-held
 # numbers that depend on them.  ONE band: +-35 % of the reference figure.  What is known to lie outside it is listed in KNOWN_GAPS
 # and tested as an expected failure -- not banded around:
-#  * ingolstadt21 FIXED (2.1 x): profiles/r04_ingolstadt21_approaches.txt.  40 % of the delay sits on ONE movement -- 490 veh/h on
-#    one lane of -201201945#0.78 with 20 s of green per 86 s, turning left 12 m later through gneJ257's permissive internal
-#    junction (90 s cycle: the offset drifts through every value; 8 vehicles per cycle in phase, 4 out of phase, 211 veh/h served)
-#    -- and 22 % on the S approach (right-turn lane at 515 veh/h against a measured discharge of 12 per cycle = 504 veh/h).  Both
-#    are at or beyond their physical capacity under the net's own programme in any Krauss simulation; near saturation a few per
-#    cent of capacity are a factor of two in delay.  With half the demand the map runs at 96 s.
-#  * ingolstadt21 MAXWAVE / MAXPRESSURE as configured (6.4 x / 4.4 x): the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2}
+#  * ingolstadt21 FIXED (1.73 x; 2.1 x before the router's minor-link penalty, round 5): profiles/r04_ingolstadt21_approaches.txt,
+#    profiles/r05_route_sensitivity.txt.  40 % of the delay sits on ONE movement -- 490 veh/h on one lane of -201201945#0.78 with
+#    20 s of green per 86 s, turning left 12 m later through gneJ257's permissive internal junction -- and 22 % on the S approach.
+#    Both are at or beyond their physical capacity under the net's own programme in any Krauss simulation; none of the 535 trips of
+#    that movement has an alternative route within 2 % of its best (371 within 10 %), so the assignment does not relieve it.
+#  * ingolstadt21 MAXWAVE / MAXPRESSURE as configured (5.4 x / 3.9 x): the reference's valid_acts['243641585'] = {2: 0, 4: 1, 7: 2}
 #    maps the wave of the S approach (841 trips/h) to green 0 = 'rGgG', in which that approach is red (phase order = the tlLogic's
 #    file order exactly as multi_signal.py:52-59 extracts it): 0 of its 841 trips arrive in the hour.  No simulator reaches the
 #    published 69.6 s with that mapping (the vehicles stored on the approach alone are worth 59 s per tripinfo entry); with the
-#    entry rotated to {4: 0, 7: 1, 2: 2} MAXWAVE gives 1.15 x (default band), MAXPRESSURE 1.58 x.
-#  * STOCHASTIC on cologne1 / cologne3: the random policy saturates these maps in SUMO (delay > duration: most of it is insertion
-#    backlog; the reference's own early episodes spread over 216-379 s on cologne1 and 132-323 s on cologne3).  This model
-#    discharges more per green second under 7 s greens.
+#    entry rotated to {4: 0, 7: 1, 2: 2} MAXWAVE gives 1.11 x (default band), MAXPRESSURE 1.55 x.
+#  * STOCHASTIC on cologne3 (0.35 x): two pairs of junctions 10 m and 13 m apart; whether a lane change is possible on those two
+#    edges decides the cell (RM_MIN_LC_LEN 5 m: 0.35 x, 12.5 m: 2.9 x); the reference's own figure is the mean of trials of which one
+#    gridlocked (279 s +- 202 s over the trials; IPPO's and MPLight's first episodes: 185 s and 132 s).
 #  * cologne3 / cologne8 MAXPRESSURE and cologne3 MAXWAVE are bimodal in the reference itself (means 162 / 48 / 91 s against
 #    medians 28 / 30 / 22 s): medians are compared.
+# Round 5 closed the random-policy gaps of cologne1 (0.68 / 0.58 / 0.46 / 0.51 -> 0.94 / 0.78 / 0.76 / 0.75) and moved cologne8,
+# ingolstadt1 and ingolstadt7 towards the reference with ONE rule: a phase entered through setPhase no longer expires
+# (rs_params.tls_expiry = 0; with expiry a 6 s green hands its 7th second to the next phase of the list -- cologne1's W-E greens
+# gained 40 % of capacity that way).  test_tls_expiry_evidence holds the two answers against the reference's figures.
 # The held-out counterpart (figures no model constant was tuned on) is tests/test_gpu_heldout.py.
 BAND = (0.65, 1.35)
 # Cells that are KNOWN to be outside the default band.  They are NOT part of the pass criterion of test_reference_result_bands (the
 # default band is the only one); test_reference_result_known_gaps asserts the default band for each of them as an expected
-# failure (xfail, non-strict: a model that closes a gap turns it into an XPASS), and the value is an UPPER bound on the ratio --
-# a regression guard only, never a lower bound above 1.
+# failure (xfail, non-strict: a model that closes a gap turns it into an XPASS).  The value is the ratio this build measures
+# (64 environments, seed 0: the simulation is deterministic, every box gives the same figure): test_reference_result_bands holds
+# each of them within +-15 % of it -- a TWO-SIDED drift guard, so that a model change that moves a gap either way is seen.
 KNOWN_GAPS = {
-    ('ingolstadt21', 'FIXED', 'delay'): 2.4,            # 2.1 x: profiles/r04_ingolstadt21_approaches.txt, DESIGN.md section 2
-    ('ingolstadt21', 'MAXWAVE', 'delay'): 8.0,          # 6.4 x / 4.4 x as configured: the S approach of TLS 243641585 is never served
-    ('ingolstadt21', 'MAXPRESSURE', 'delay'): 5.5,      #   (valid_acts maps its wave to a phase in which it is red); unreachable on SUMO too
-    ('ingolstadt21', 'MAXPRESSURE*', 'delay'): 1.9,     # 1.58 x with the entry rotated (MAXWAVE*: 1.15 x, inside the default band)
-    ('cologne1', 'STOCHASTIC', 'delay'): None,          # 0.68 x: at the edge of the band
-    ('cologne1', 'STOCHASTIC', 'duration'): None, ('cologne1', 'STOCHASTIC', 'waiting'): None, ('cologne1', 'STOCHASTIC', 'queue'): None,
-    ('cologne3', 'STOCHASTIC', 'delay'): None, ('cologne3', 'STOCHASTIC', 'duration'): None,
-    ('cologne3', 'STOCHASTIC', 'waiting'): None, ('cologne3', 'STOCHASTIC', 'queue'): None,
+    ('ingolstadt21', 'FIXED', 'delay'): 1.73,
+    ('ingolstadt21', 'MAXWAVE', 'delay'): 5.42,         # as configured: the S approach of TLS 243641585 is never served
+    ('ingolstadt21', 'MAXPRESSURE', 'delay'): 3.85,     #   (valid_acts maps its wave to a phase in which it is red); unreachable on SUMO too
+    ('ingolstadt21', 'MAXPRESSURE*', 'delay'): 1.55,    # with the entry rotated (MAXWAVE*: 1.11 x, inside the default band)
+    ('cologne3', 'STOCHASTIC', 'delay'): 0.35, ('cologne3', 'STOCHASTIC', 'duration'): 0.39,
+    ('cologne3', 'STOCHASTIC', 'waiting'): 0.24,
 }
+DRIFT = 0.15
 MAXD = {'FIXED': 200, 'MAXWAVE': 50, 'MAXPRESSURE': 200, 'STOCHASTIC': 200}
 
 
@@ -922,10 +927,11 @@ def _ref_bands():
         return json.load(f)
 
 
-def _episode_metrics(sc, policy, n_envs=64, seed=0):
+def _episode_metrics(sc, policy, n_envs=64, seed=0, tls_expiry=0):
     """one whole episode of `policy` on the device for n_envs environments: the reference's four per-episode figures"""
     from resco_amd.sim import BatchedSim
-    sim = BatchedSim(sc, n_envs, seed=seed, max_distance=MAXD[policy.rstrip('*')], fixed_program=1 if policy == 'FIXED' else 0)
+    sim = BatchedSim(sc, n_envs, seed=seed, max_distance=MAXD[policy.rstrip('*')], fixed_program=1 if policy == 'FIXED' else 0,
+                     tls_expiry=tls_expiry)
     q = np.zeros(n_envs)
     for k in range(360):
         if policy.startswith('MAX'):
@@ -992,18 +998,18 @@ def test_reference_result_bands(name):
     """64 environments x one whole episode of FIXED / MAXWAVE / MAXPRESSURE / STOCHASTIC on the device against every figure the
     reference holds for them (delay for all four, duration / waitingTime / queue for the random policy, the free-flow residual
     for the routes).  ONE pass criterion: the default band (+-35 %; +-10 % for the free-flow residual).  The cells listed in
-    KNOWN_GAPS are reported and only guarded from above here; test_reference_result_known_gaps holds them to the default band as
-    expected failures."""
+    KNOWN_GAPS are reported and held within +-15 % of their recorded ratio here (a two-sided drift guard);
+    test_reference_result_known_gaps holds them to the default band as expected failures."""
     failures, lines = [], []
     for policy, metric, value, target in _band_cells(name):
         ratio = value / target
         key = (name, policy, metric)
         band = (0.9, 1.1) if metric == 'free_flow' else BAND
         if key in KNOWN_GAPS:
-            ub = KNOWN_GAPS[key]
-            lines.append('band %-12s %-12s %-9s %8.2f / %8.2f = %.2f  KNOWN GAP (default band [%.2f, %.2f]%s)' % (
-                name, policy, metric, value, target, ratio, band[0], band[1], '; guard: ratio <= %.1f' % ub if ub else ''))
-            if ub is not None and ratio > ub:
+            rec = KNOWN_GAPS[key]
+            lines.append('band %-12s %-12s %-9s %8.2f / %8.2f = %.2f  KNOWN GAP (default band [%.2f, %.2f]; drift guard: %.2f +-%d %%)' % (
+                name, policy, metric, value, target, ratio, band[0], band[1], rec, round(100 * DRIFT)))
+            if not rec * (1 - DRIFT) <= ratio <= rec * (1 + DRIFT):
                 failures.append(lines[-1])
             continue
         lines.append('band %-12s %-12s %-9s %8.2f / %8.2f = %.2f  [%.2f, %.2f]' % (name, policy, metric, value, target, ratio, band[0], band[1]))
@@ -1022,6 +1028,32 @@ def test_reference_result_known_gaps(cell):
             assert BAND[0] <= value / target <= BAND[1], (cell, value, target, value / target)
             return
     raise AssertionError('no such cell: %r' % (cell,))
+
+
+def test_tls_expiry_evidence():
+    """What does trafficlight.setPhase leave behind (rs_params.tls_expiry)?  SUMO documents that the phase runs for its programme
+    duration and the programme then continues [SUMO-K]; the reference never resets a duration (traffic_signal.py:176-187), so a 6 s
+    green chosen for a 10 s step would hand its 7th second to the next phase of the list.  No SUMO binary is at hand, but the
+    reference holds 20 figures that depend on it: delay / duration / waitingTime / queue of a uniformly random policy on five maps
+    with 6 s greens (episode 1 of its IDQN runs, epsilon >= 0.9875).  Both answers on the device, 64 environments x one episode
+    each; the table goes to profiles/r05_tls_expiry_bands.txt.  Asserted: WITHOUT expiry (the default) at least 15 of the 20 figures
+    are closer to the reference's than with it, and |log ratio| summed over the 20 is at most 70 % of what expiry gives."""
+    ref = _ref_bands()
+    lines, closer, err = [], 0, [0.0, 0.0]
+    for name in ('cologne1', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'):
+        sc = load_scenario(name)
+        m = [{k: float(np.median(v)) for k, v in _episode_metrics(sc, 'STOCHASTIC', tls_expiry=x).items()} for x in (0, 1)]
+        for metric in ('delay', 'duration', 'waiting', 'queue'):
+            t = ref[name]['STOCHASTIC'][metric]
+            r = [m[0][metric] / t, m[1][metric] / t]
+            closer += abs(np.log(r[0])) < abs(np.log(r[1]))
+            err[0] += abs(np.log(r[0]))
+            err[1] += abs(np.log(r[1]))
+            lines.append('expiry %-12s STOCHASTIC %-9s reference %8.2f   phase stays %8.2f (%.2f)   phase expires %8.2f (%.2f)' % (
+                name, metric, t, m[0][metric], r[0], m[1][metric], r[1]))
+    lines.append('expiry closer to the reference without expiry: %d of 20; sum |log ratio|: %.2f without, %.2f with' % (closer, err[0], err[1]))
+    print('\n'.join(lines))
+    assert closer >= 15 and err[0] <= 0.7 * err[1]
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs 4 and 5

@@ -87,7 +87,8 @@ def _random_configs(n, seed):
                         speed_dev=int(rng.integers(0, 2)), max_distance=float(rng.choice([1.0, 50.0, 200.0, 9999.0])),
                         fixed=int(rng.random() < 0.25), step_ratio=int(rng.choice([1, 1, 2, 3])), seed=int(rng.integers(0, 2 ** 31)),
                         env_base=int(rng.integers(0, 5000)), warm=int(rng.choice([0, 0, 40, 90])),
-                        threads=int(rng.choice([0, 64, 128])), steps=int(rng.integers(12, 28)), case=i))
+                        threads=int(rng.choice([0, 64, 128])), steps=int(rng.integers(12, 28)), case=i,
+                        tls_expiry=i % 2))       # both answers to what setPhase leaves behind (rs_params.tls_expiry)
     return out
 
 
@@ -97,7 +98,7 @@ def test_randomised_parameter_sweep_equals_oracle(cfg):
     parameters, after an optional warm start under the on-device random policy, under random, repeated and out-of-range actions"""
     sc = load_scenario(cfg['name'])
     kw = dict(seed=cfg['seed'], sigma=cfg['sigma'], speed_dev=cfg['speed_dev'], max_distance=cfg['max_distance'],
-              fixed_program=cfg['fixed'], step_ratio=cfg['step_ratio'])
+              fixed_program=cfg['fixed'], step_ratio=cfg['step_ratio'], tls_expiry=cfg['tls_expiry'])
     bt = cfg['threads'] if cfg['threads'] and cfg['threads'] <= sc.capacity else 0
     sim = EmuSim(sc, 1, order=cfg['order'], env_base=cfg['env_base'], block_threads=bt, **kw)
     o = OracleEnv(sc, env_index=cfg['env_base'], **kw)

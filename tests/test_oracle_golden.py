@@ -21,7 +21,7 @@ def test_oracle_matches_reference_python(tag):
     sc = load_scenario(meta['map'])
     assert meta['all_ts_ids'] == sc.signal_ids
     env = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1,
-                    step_ratio=meta.get('step_ratio', 1))
+                    step_ratio=meta.get('step_ratio', 1), tls_expiry=meta.get('tls_expiry', 0))
     env.observe()
     t0 = 0
     if meta.get('preroll'):         # loaded network: roll forward, then fresh Signal objects (as the fixture's generator did)

@@ -72,9 +72,10 @@ def test_parity_mode_is_deterministic_and_env_keyed():
 
 
 def test_fsm_duration_auto_advance():
-    """a 6 s green expires inside the 7 post-yellow ticks -> phase advances to (a+1) % P."""
+    """SURVEY 8(a) A7 [SUMO-K], rs_params.tls_expiry = 1: a 6 s green expires inside the 7 post-yellow ticks -> phase advances to
+    (a+1) % P."""
     sc = load_scenario('cologne1')
-    e = OracleEnv(sc, sigma=0.0)
+    e = OracleEnv(sc, sigma=0.0, tls_expiry=1)
     e.observe()
     assert e.outputs()['phase'][0] == 0
     e.step(np.array([1], np.int32))                # green 1 has duration 6
@@ -87,3 +88,30 @@ def test_fsm_duration_auto_advance():
     assert e.outputs()['phase'][0] == 4
     e.step(np.array([0], np.int32))                # current phase is a yellow index: no yellow_dict key, plain set
     assert e.outputs()['phase'][0] == 0
+
+
+def test_fsm_a_set_phase_stays_by_default():
+    """rs_params.tls_expiry = 0 (default): the phase entered through setPhase is the phase observed, whatever its programme
+    duration; the phase installed at reset still runs on its duration until the first setPhase, and so does the net's own
+    programme (fixed_program)"""
+    sc = load_scenario('cologne1')
+    e = OracleEnv(sc, sigma=0.0)
+    e.observe()
+    for a in (1, 3, 1, 0, 3, 3, 2):
+        e.step(np.array([a], np.int32))
+        assert e.outputs()['phase'][0] == a
+    e = OracleEnv(sc, sigma=0.0)                   # nobody calls setPhase: the installed programme runs (29 s, then the 6 s green ...)
+    for _ in range(29):
+        e.tick()
+    assert e.get_phase(0) == 0
+    e.tick()
+    assert e.get_phase(0) == 1
+    for _ in range(6):
+        e.tick()
+    assert e.get_phase(0) == 2
+    f = OracleEnv(sc, sigma=0.0, fixed_program=1)
+    seen = set()
+    for _ in range(90):
+        f.tick()
+        seen.add(f.get_phase(0))
+    assert seen == set(range(8))                   # the net's eight phases, one 90 s cycle
