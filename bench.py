@@ -84,7 +84,7 @@ def pmc_traffic(args, n_local, world):
     (tools/pmc_passes.sh <tag> K W -> profiles/r03_pmc_s<K>_w<W>.json), so a figure is reported only when a committed
     summary exists for this run's --steps / --warmup on the default workload AND was measured on the kernel sources that are
     running now (source hash); otherwise None, with the reason."""
-    path = os.path.join(ROOT, 'profiles', 'r04_pmc_s%d_w%d.json' % (args.steps, args.warmup))
+    path = os.path.join(ROOT, 'profiles', 'r05_pmc_s%d_w%d.json' % (args.steps, args.warmup))
     default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0 and args.pipes == DEFAULT_PIPES
     if not default_workload or not os.path.exists(path):
         return None, ('HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_passes.sh); '
@@ -120,28 +120,35 @@ def window_start(steps, warmup):
 def run_timed(sims, steps, warmup, barrier, sync, reduce_max, all_outputs_steps=0):
     """W untimed steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks.  `sims`: the pipes of
     this rank -- every step launches [agent, step] on each pipe's own stream, one host thread issuing them in turn."""
+    from resco_amd.sim import SimGroup
+    group = SimGroup(sims)
     k = 0
 
     def one():
+        # ONE call through the C ABI per env-step for all pipes (rs_group_step): per pipe the random policy's kernel and the step
+        # kernel on the pipe's own stream
         nonlocal k
-        for sim in sims:
-            if k > 0 and k % EPISODE_STEPS == 0:
+        if k > 0 and k % EPISODE_STEPS == 0:
+            for sim in sims:
                 sim.reset()
-            sim.act_random(k)
-            sim.step(None)
+        group.step('random', step_key=k)
         k += 1
 
     def stats():
         st = [sim.stats() for sim in sims]
         return {key: __import__('numpy').concatenate([x[key] for x in st]) for key in st[0]}
 
-    for _ in range(window_start(steps, warmup) - warmup):      # untimed fast-forward into the bulk of the episode
+    # The LAST steps before the warm-up -- the end of the untimed fast-forward into the bulk of the episode, or, when there is
+    # none, of the warm-up itself -- run with EVERY derived output buffer switched on (lane_agg, wave, mplight_full, the fp16
+    # tensor, lane_arrivals next to drq_norm + mplight) and are timed on their own: what the output mask saves, reported next to
+    # the headline figure.  Untimed as far as the contract's K steps go; `all_outputs_steps` of them whatever --warmup is.
+    ff = window_start(steps, warmup) - warmup
+    n_all = min(all_outputs_steps, ff + warmup)
+    n_all_ff = min(n_all, ff)                   # ... of which inside the fast-forward
+    all_outputs_rate = None
+    for _ in range(ff - n_all_ff):
         one()
-    # The LAST warm-up steps (right before the timed window) run with EVERY derived output buffer switched on (lane_agg, wave,
-    # mplight_full, the fp16 tensor, lane_arrivals next to drq_norm + mplight) and are timed on their own: what the output mask
-    # saves, reported next to the headline figure.  They are warm-up steps all the same: untimed as far as the contract's K steps go.
-    all_outputs_rate, n_all = None, min(all_outputs_steps, warmup)
-    for _ in range(warmup - n_all):
+    for _ in range(0 if n_all_ff else warmup - n_all):
         one()
     if n_all > 0:
         for sim in sims:
@@ -154,6 +161,8 @@ def run_timed(sims, steps, warmup, barrier, sync, reduce_max, all_outputs_steps=
         all_outputs_rate = n_all / (time.perf_counter() - t2)       # steps per second of this rank
         for sim in sims:
             sim.set_outputs(OUTPUTS)
+    for _ in range(warmup if n_all_ff else 0):
+        one()
     sync()
     st0 = stats()
     for sim in sims:
@@ -174,7 +183,7 @@ def run_timed(sims, steps, warmup, barrier, sync, reduce_max, all_outputs_steps=
         sim.timing(False)
     st1 = stats()
     elapsed = reduce_max(t1 - t0)
-    return elapsed, kernel_ms, launches, st0, st1, all_outputs_rate
+    return elapsed, kernel_ms, launches, st0, st1, all_outputs_rate, n_all, t1 - t0
 
 
 def state_digest(sims, dist, rank, world):
@@ -344,8 +353,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed, kernel_ms, launches, st0, st1, all_out_rate = run_timed(sims, args.steps, args.warmup, barrier, sync, reduce_max,
-                                                                     all_outputs_steps=min(args.steps, 20))
+    elapsed, kernel_ms, launches, st0, st1, all_out_rate, n_all, elapsed_local = run_timed(sims, args.steps, args.warmup, barrier, sync, reduce_max,
+                                                                                             all_outputs_steps=20)
     ticks = (st1['ticks'] - st0['ticks']).astype('float64')
     mean_active = float(((st1['active_ticks'] - st0['active_ticks']) / ticks.clip(min=1)).mean()) if ticks.min() > 0 \
         else float(st1['active'].mean())
@@ -358,7 +367,9 @@ def main():
     # one step = `pipes` launches of n_local / pipes environments that overlap on their streams: the bytes of all of them over
     # the average duration of one of them (= pipes x the per-launch figure)
     achieved_per_launch = b_alg * per / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-    achieved = args.pipes * achieved_per_launch
+    # `achieved`: the algorithmic bytes of everything this rank stepped over ITS wall clock of the timed region -- no assumption
+    # about how well the launches of the pipes overlap (pipes x the per-launch figure is the upper bound, reported next to it)
+    achieved = b_alg * n_local * args.steps / elapsed_local / 1e9
     w0 = window_start(args.steps, args.warmup)
     traffic, traffic_note = pmc_traffic(args, n_local, world)
     out = {
@@ -379,20 +390,23 @@ def main():
                      'traffic': traffic, 'traffic_note': traffic_note,
                      'kernel': 'rs_step_kernel', 'kernel_avg_ms': k_avg_s * 1e3, 'launches': launches,
                      'concurrent_launches': args.pipes, 'achieved_per_launch': achieved_per_launch,
-                     'achieved_note': 'a step is %d launches of %d environments each on %d HIP streams; they overlap, so `achieved` = %d x '
-                                      '(algorithmic bytes of one launch / its average duration by HIP events on its own stream); '
-                                      '`traffic` likewise = %d x the per-launch counter figure' % (args.pipes, per, args.pipes, args.pipes, args.pipes),
+                     'achieved_upper_bound': args.pipes * achieved_per_launch,
+                     'achieved_note': 'a step is %d launches of %d environments each on %d HIP streams.  `achieved` = algorithmic bytes of the '
+                                      '%d env-steps of the timed region / its wall clock on this rank; `achieved_per_launch` = algorithmic bytes of '
+                                      'one launch / its average duration by HIP events on its own stream, `achieved_upper_bound` = %d x that (what '
+                                      'perfectly overlapping launches would give); `traffic` = %d x the per-launch counter figure'
+                                      % (args.pipes, per, args.pipes, n_local * args.steps, args.pipes, args.pipes),
                      'algorithmic_bytes_per_env_step': b_alg, 'env_steps_per_launch': per,
                      'formula': 'SURVEY 8(d): 60*V + 12*S + 20*SL + 8*S', 'designed_bytes_per_env_step': b_wide,
-                     'achieved_designed_bytes': args.pipes * b_wide * per / k_avg_s / 1e9 if k_avg_s > 0 else 0.0,
+                     'achieved_designed_bytes': b_wide * n_local * args.steps / elapsed_local / 1e9,
                      'note': 'state is Infinity-Cache resident and the kernel is issue/latency bound: the HBM '
                              'fraction is small by construction (SURVEY.md 8d)'},
         'mean_active_vehicles_per_env': mean_active,
         'sim_ticks_per_s': value * 10, 'vehicle_ticks_per_s': value * 10 * mean_active,
-        'all_outputs': {'value': world * n_local * all_out_rate if all_out_rate else None, 'unit': 'env-steps/s', 'steps': min(args.steps, 20, args.warmup),
-                        'episode_window': [w0 - min(args.steps, 20, args.warmup), w0],
-                        'note': 'rank 0, the last warm-up steps (right before the timed window: the network is as loaded as at its first step, '
-                                'not as on its average) with EVERY derived buffer written (lane_agg, drq_norm, wave, mplight, mplight_full, '
+        'all_outputs': {'value': world * n_local * all_out_rate if all_out_rate else None, 'unit': 'env-steps/s', 'steps': n_all,
+                        'episode_window': [max(0, w0 - args.warmup - n_all), max(0, w0 - args.warmup - n_all) + n_all] if w0 - args.warmup >= n_all else [w0 - n_all, w0],
+                        'note': 'rank 0, the last untimed steps before the warm-up (the network is nearly as loaded as in the timed window) '
+                                'with EVERY derived buffer written (lane_agg, drq_norm, wave, mplight, mplight_full, '
                                 'drq_norm_f16, lane_arrivals): rounds 1-2 measured this workload, rounds 3-4 write what config 3 consumes'},
     }
     if args.digest:

@@ -259,6 +259,31 @@ int rs_idqn_set_device_weights(rs_policy_handle p, const float *conv_w, const fl
 int rs_idqn_set_lanes(rs_policy_handle p, const int32_t *lanes_per_signal);
 void rs_idqn_destroy(rs_policy_handle p);
 
+/* ---- a whole group of handles stepped by ONE call --------------------------------------------------------------
+ * The environments of one GPU are split over several handles ("pipes") whose kernels overlap on their own
+ * streams; driven from Python that costs two calls through ctypes per pipe and step (agent + rs_step, ~37 us each), which is the
+ * limit beyond four pipes and at the small batches of BASELINE config 5.  rs_group_step runs the reference's loop body
+ *     act = agent.act(obs); obs, rew, done, info = env.step(act)          (resco_benchmark/main.py:104-108)
+ * n_steps times for every handle of the group: per step and handle the agent's kernel and the step kernel, on the handle's own
+ * stream, asynchronously.  The agent reads the buffers the handle's LAST observe wrote and writes its RS_BUF_ACTIONS:
+ *   RS_AGENT_NONE         rs_step(h, NULL, ...): RS_BUF_ACTIONS as it is
+ *   RS_AGENT_RANDOM       rs_act_random(h, step_key + k)                   agents/stochastic.py:17-18
+ *   RS_AGENT_MAXWAVE / RS_AGENT_MAXPRESSURE   rs_act_maxwave with the tables a first rs_act_maxwave call installed
+ *   RS_AGENT_IDQN         rs_idqn_act(policy, h's RS_BUF_DRQ_NORM_F16, mode, epsilon + k * epsilon_step (>= 0), seed, step_key + k);
+ *                         the epsilon-greedy draws are keyed by the GLOBAL environment index (env_base + e), so that a batch
+ *                         split over pipes or GPUs draws what the single batch draws
+ * Returns the first error (codes as everywhere; rs_last_error of the handle it occurred on). */
+enum rs_agent { RS_AGENT_NONE = 0, RS_AGENT_RANDOM = 1, RS_AGENT_MAXWAVE = 2, RS_AGENT_MAXPRESSURE = 3, RS_AGENT_IDQN = 4 };
+typedef struct rs_group_agent {
+    int32_t kind;               /* enum rs_agent */
+    uint32_t step_key;          /* RANDOM, IDQN: key of the call's first step */
+    rs_policy_handle policy;    /* IDQN */
+    int32_t mode;               /* IDQN: 0 epsilon-greedy, 1 softmax sampling (rs_idqn_act) */
+    float epsilon, epsilon_step;
+    uint32_t seed;
+} rs_group_agent;
+int rs_group_step(const rs_handle *handles, int32_t n_handles, const rs_group_agent *agent, int32_t n_steps);
+
 /* static facts */
 int rs_info(rs_handle h, int32_t *n_envs, int32_t *block_threads, int32_t *lds_bytes, int32_t *max_lanes_per_signal);
 

@@ -11,8 +11,15 @@
 // One workgroup = 2 waves = 64 environments of ONE signal (grid: ceil(N/64) x S); a wave owns 32 rows (envs) x 64
 // fc1 outputs = two 32x32 accumulator tiles.  fc2 / fc3 reuse the same MFMA shape after an LDS round trip that
 // turns accumulator layout into A-fragment layout; the epilogue does the masked argmax and the epsilon-greedy draw
-// (counter hash over (seed; env, signal, step)) - or, in mode 1, samples from softmax(outputs), which is the IPPO
+// (counter hash over (seed; env_base + env, signal, step): rs_group_step passes the handle's first global environment index, so
+// that a batch split over pipes draws what the single batch draws) - or, in mode 1, samples from softmax(outputs), which is the IPPO
 // policy head on the same trunk - and writes int32 actions the step kernel consumes.
+//
+// Round 5 measured the 64-channel loop split over two wave pairs (4 waves, channels 0-31 / 32-63, partial sums through LDS): 62 KB
+// of LDS instead of 46 KB per workgroup.  The policy of one pipe runs under the step kernels of the others, whose workgroups hold
+// 53 KB each, three to a CU: a 46 KB workgroup starts as soon as ONE of them retires, a 62 KB one needs two.  A/B on one box,
+// ingolstadt21, sim + policy / sim-only (tools/pipes_ab.py --group, profiles/r05_pipes_group.txt): 1024 envs x 4 pipes 0.76 instead
+// of 0.83, x 8 pipes 0.74 instead of 0.85, 4096 envs x 2 pipes 0.86 instead of 0.91.  Not adopted.
 //
 // MFMA 32x32x8 f16 fragment layout (lane l, g = l >> 5, i = l & 31):
 //     A: row i, k = 4 g + j (j = 0..3);   B: column i, k = 4 g + j;   C/D reg r: column i, row (r & 3) + 8 (r >> 2) + 4 g.
@@ -57,7 +64,7 @@ struct PolicySmem {
 // others belong to padded lanes, whose fc1 rows are zero: skipping them changes no result.
 template <int HP>
 __device__ __forceinline__ void
-idqn_forward_body(PolicySmem &sm, const PolicyTab &W, const __half *__restrict__ obs, int n_envs, int mode, float eps, uint32_t seed,
+idqn_forward_body(PolicySmem &sm, const PolicyTab &W, const __half *__restrict__ obs, int n_envs, int env_base, int mode, float eps, uint32_t seed,
                   uint32_t step_key, int32_t *__restrict__ actions, float *__restrict__ q_out) {
     auto &xs = sm.xs; auto &ys = sm.ys; auto &qs = sm.qs; auto &wbuf = sm.wbuf;
     const int s = blockIdx.y;
@@ -210,13 +217,13 @@ idqn_forward_body(PolicySmem &sm, const PolicyTab &W, const __half *__restrict__
                 // categorical policy (the IPPO head, pfrl_ppo.py:57-60): the outputs are logits, a ~ softmax(logits)
                 float z = 0.0f;
                 for (int a = 0; a < na; ++a) z += __expf(qs[wave][lane][a] - bq);
-                const float u = d_u01(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 2u)) * z;
+                const float u = d_u01(pol_hash(seed ^ 0x1D0A17u, (uint32_t)(env_base + m), (uint32_t)s, step_key, 2u)) * z;
                 float cum = 0.0f;
                 act = na - 1;
                 for (int a = 0; a < na; ++a) { cum += __expf(qs[wave][lane][a] - bq); if (u < cum) { act = a; break; } }
             } else if (eps > 0.0f) {
-                const float u = d_u01(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 0u));
-                if (u < eps) act = (int)(pol_hash(seed ^ 0x1D0A17u, (uint32_t)m, (uint32_t)s, step_key, 1u) % (uint32_t)na);
+                const float u = d_u01(pol_hash(seed ^ 0x1D0A17u, (uint32_t)(env_base + m), (uint32_t)s, step_key, 0u));
+                if (u < eps) act = (int)(pol_hash(seed ^ 0x1D0A17u, (uint32_t)(env_base + m), (uint32_t)s, step_key, 1u) % (uint32_t)na);
             }
             actions[(size_t)m * W.S + s] = act;
             if (q_out)
@@ -228,20 +235,20 @@ idqn_forward_body(PolicySmem &sm, const PolicyTab &W, const __half *__restrict__
 // One workgroup = one signal: the body is chosen by the signal's own head size (a workgroup-uniform switch).  W.hp_sig[s] == W.hp
 // for every signal until rs_idqn_set_lanes has told the library the networks' real input sizes.
 __global__ void __launch_bounds__(128)
-rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, int mode, float eps, uint32_t seed, uint32_t step_key,
+rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, int env_base, int mode, float eps, uint32_t seed, uint32_t step_key,
                        const uint32_t *__restrict__ dyn, int32_t *__restrict__ actions, float *__restrict__ q_out) {
     // dyn != NULL: epsilon (float bits) and step key come from device memory, so that a captured HIP graph of the
     // env-step can be replayed with values an earlier node of the same graph computed
     if (dyn) { eps = __uint_as_float(dyn[0]); step_key = dyn[1]; }
     __shared__ PolicySmem sm;
     switch (__builtin_amdgcn_readfirstlane(W.hp_sig[blockIdx.y])) {
-        case 1: idqn_forward_body<1>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
-        case 2: idqn_forward_body<2>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
-        case 3: idqn_forward_body<3>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
-        case 4: idqn_forward_body<4>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
-        case 5: idqn_forward_body<5>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
-        case 6: idqn_forward_body<6>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
-        case 7: idqn_forward_body<7>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
-        default: idqn_forward_body<8>(sm, W, obs, n_envs, mode, eps, seed, step_key, actions, q_out); break;
+        case 1: idqn_forward_body<1>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
+        case 2: idqn_forward_body<2>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
+        case 3: idqn_forward_body<3>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
+        case 4: idqn_forward_body<4>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
+        case 5: idqn_forward_body<5>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
+        case 6: idqn_forward_body<6>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
+        case 7: idqn_forward_body<7>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
+        default: idqn_forward_body<8>(sm, W, obs, n_envs, env_base, mode, eps, seed, step_key, actions, q_out); break;
     }
 }

@@ -483,7 +483,19 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         if ((rc = dev_alloc(h, &h->args, 1, false))) return fail(rc);
         if (hipMemcpy(h->args, &sa, sizeof(sa), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy(StepArgs) failed"; return fail(RS_EHIP); }
     }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(RS_EHIP); }
+    {   // The handle's stream gets a hardware queue of its OWN.  HIP multiplexes plain streams over GPU_MAX_HW_QUEUES (4) hardware
+        // queues, least-used first, and two streams that share one run their kernels one after the other: pipes (several handles
+        // per GPU whose launches are meant to overlap) lost a third of their rate whenever two of them met on a queue
+        // (profiles/r05_pipes_group.txt).  A stream created with a CU mask is never multiplexed; the mask enables every CU.
+        hipDeviceProp_t prop;
+        std::vector<uint32_t> mask;
+        if (getenv("RESCO_PLAIN_STREAMS") == nullptr && hipGetDeviceProperties(&prop, device_id) == hipSuccess)
+            mask.assign((size_t)(prop.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
+        if (mask.empty() || hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return fail(RS_EHIP); }
+        }
+    }
     *out = h;
     int r2 = rs_reset(h, nullptr);
     if (r2) { g_create_err = h->err; *out = nullptr; rs_destroy(h); return r2; }
@@ -811,8 +823,51 @@ extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, 
     if (!p || !obs || !actions || n_envs <= 0 || mode < 0 || mode > 1) return RS_EINVAL;
     if (hipSetDevice(p->device) != hipSuccess) return RS_EHIP;
     hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(128), 0, (hipStream_t)stream,
-                       p->W, (const __half *)obs, (int)n_envs, (int)mode, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
+                       p->W, (const __half *)obs, (int)n_envs, 0, (int)mode, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_EHIP;
+}
+
+// ---- one env-step (or n of them) of a whole group of handles in ONE call (include/resco_sim.h: rs_group_step)
+extern "C" int rs_group_step(const rs_handle *hs, int32_t n_handles, const rs_group_agent *agent, int32_t n_steps) {
+    if (!hs || n_handles <= 0 || n_steps <= 0) return RS_EINVAL;
+    const int kind = agent ? agent->kind : RS_AGENT_NONE;
+    for (int i = 0; i < n_handles; ++i) {
+        rs_sim *h = hs[i];
+        if (!h) return RS_EINVAL;
+        if (kind == RS_AGENT_MAXWAVE || kind == RS_AGENT_MAXPRESSURE) {
+            if (!h->pairs) { h->err = "rs_group_step: the MAXWAVE / MAXPRESSURE tables are installed by a first rs_act_maxwave call"; return RS_EINVAL; }
+            if (!(h->out_mask & (kind == RS_AGENT_MAXPRESSURE ? OUT_MPLIGHT : OUT_WAVE))) { h->err = "rs_group_step: the agent's input buffer is switched off (rs_set_outputs)"; return RS_EINVAL; }
+        } else if (kind == RS_AGENT_IDQN) {
+            if (!agent->policy || agent->mode < 0 || agent->mode > 1 || agent->policy->W.S != h->K.n_signals || agent->policy->W.lmax != h->K.lmax) {
+                h->err = "rs_group_step: RS_AGENT_IDQN needs a policy built for this scenario (n_signals, lmax)"; return RS_EINVAL; }
+            if (!(h->out_mask & OUT_DRQ_F16)) { h->err = "rs_group_step: RS_AGENT_IDQN reads RS_BUF_DRQ_NORM_F16, which rs_set_outputs has switched off"; return RS_EINVAL; }
+        } else if (kind != RS_AGENT_NONE && kind != RS_AGENT_RANDOM) { h->err = "rs_group_step: unknown agent kind"; return RS_EINVAL; }
+    }
+    for (int k = 0; k < n_steps; ++k)
+        for (int i = 0; i < n_handles; ++i) {
+            rs_sim *h = hs[i];
+            HIPCHK(h, hipSetDevice(h->device));
+            hipStream_t st = h->stream;
+            h->last = st;
+            const int total = h->n_envs * h->K.n_signals;
+            if (kind == RS_AGENT_RANDOM)
+                hipLaunchKernelGGL(rs_act_random_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->K, h->P, agent->step_key + (uint32_t)k, h->actions);
+            else if (kind == RS_AGENT_MAXWAVE || kind == RS_AGENT_MAXPRESSURE)
+                hipLaunchKernelGGL(rs_act_maxwave_kernel, dim3((total + 255) / 256), dim3(256), 0, st, h->K, h->P, (const int32_t *)h->pairs,
+                                   h->n_pairs, (const int32_t *)h->valid, (const int32_t *)h->order, (int)(kind == RS_AGENT_MAXPRESSURE),
+                                   (const int32_t *)h->O.mplight(), (const int32_t *)h->O.wave(), h->actions);
+            else if (kind == RS_AGENT_IDQN) {
+                float eps = agent->epsilon + (float)k * agent->epsilon_step;
+                if (eps < 0.0f) eps = 0.0f;
+                hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((h->n_envs + POL_TM - 1) / POL_TM, h->K.n_signals), dim3(128), 0, st,
+                                   agent->policy->W, (const __half *)h->O.drq_f16(), (int)h->n_envs, (int)h->P.env_base, (int)agent->mode, eps,
+                                   agent->seed, agent->step_key + (uint32_t)k, (const uint32_t *)nullptr, h->actions, (float *)nullptr);
+            }
+            if (kind != RS_AGENT_NONE) HIPCHK(h, hipGetLastError());
+            const int rc = launch_step(h, st, h->K.step_length * h->ratio, 1);
+            if (rc != RS_OK) return rc;
+        }
+    return RS_OK;
 }
 
 extern "C" int rs_idqn_set_device_weights(rs_policy_handle p, const float *conv_w, const float *conv_b, const uint16_t *w1, const float *b1,

@@ -31,7 +31,7 @@ TRIP_NONE = 0xFFFF
 ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_reinit_signals', 'rs_ticks', 'rs_step_sim', 'rs_set_outputs', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
                'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_phase_profile', 'rs_info',
-               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_set_lanes', 'rs_idqn_destroy']
+               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_set_lanes', 'rs_idqn_destroy', 'rs_group_step']
 
 _lib = None
 
@@ -65,6 +65,7 @@ def bind(L):
     L.rs_set_seed.argtypes = [vp, C.c_uint32]
     L.rs_phase_profile.argtypes = [vp, i32, vp]
     L.rs_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.rs_group_step.argtypes = [vp, i32, vp, i32]
     return L
 
 
@@ -86,6 +87,44 @@ def load_library():
             pass
     _lib = bind(C.CDLL(LIB_PATH))
     return _lib
+
+
+AGENT = {'none': 0, 'random': 1, 'maxwave': 2, 'maxpressure': 3, 'idqn': 4}      # enum rs_agent
+
+
+class GroupAgent(C.Structure):
+    """ctypes mirror of rs_group_agent (include/resco_sim.h)"""
+    _fields_ = [('kind', C.c_int32), ('step_key', C.c_uint32), ('policy', C.c_void_p), ('mode', C.c_int32),
+                ('epsilon', C.c_float), ('epsilon_step', C.c_float), ('seed', C.c_uint32)]
+
+
+class SimGroup:
+    """The handles ("pipes") of one GPU stepped together by ONE call through the C ABI per env-step (rs_group_step): for every
+    pipe the agent's kernel and the step kernel on the pipe's own stream.  agent: 'none' | 'random' | 'maxwave' | 'maxpressure' |
+    'idqn' (policy = an rs_policy_handle, e.g. FusedIDQN.handle)."""
+
+    def __init__(self, sims):
+        self.sims = list(sims)
+        self._lib = self.sims[0]._lib
+        self._hs = (C.c_void_p * len(self.sims))(*[s._h for s in self.sims])
+        self._agent = GroupAgent()
+
+    def step(self, agent='none', step_key=0, n_steps=1, policy=None, mode=0, epsilon=0.0, epsilon_step=0.0, seed=0):
+        a = self._agent
+        a.kind, a.step_key, a.policy = AGENT[agent], int(step_key) & 0xFFFFFFFF, policy
+        a.mode, a.epsilon, a.epsilon_step, a.seed = int(mode), float(epsilon), float(epsilon_step), int(seed) & 0xFFFFFFFF
+        if agent in ('maxwave', 'maxpressure'):
+            for s in self.sims:
+                s.require_output('mplight' if agent == 'maxpressure' else 'wave')
+                s._ensure_maxwave_tables(1 if agent == 'maxpressure' else 0)
+        rc = self._lib.rs_group_step(self._hs, len(self.sims), C.byref(a), int(n_steps))
+        if rc != 0:
+            msgs = [m.decode() for m in (self._lib.rs_last_error(s._h) for s in self.sims) if m]
+            raise RuntimeError('rs_group_step failed (%d): %s' % (rc, '; '.join(msgs)))
+
+    def sync(self):
+        for s in self.sims:
+            s.sync()
 
 
 def _murmur(seed, words):
@@ -270,6 +309,11 @@ class BatchedSim:
             self._maxwave_ready = True
             return
         self._check(self._lib.rs_act_maxwave(self._h, None, len(self._pairs), None, None, int(use_pressure), stream))
+
+    def _ensure_maxwave_tables(self, use_pressure):
+        """the phase-pair tables live on the device after the first rs_act_maxwave call (rs_group_step needs them there)"""
+        if not self._maxwave_ready:
+            self.act_maxwave(use_pressure)
 
     # ------------------------------------------------------------------ buffers
     def read(self, name):

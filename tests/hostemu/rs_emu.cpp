@@ -319,6 +319,23 @@ int rs_act_maxwave(rs_handle h, const int32_t *phase_pairs, int32_t n_pairs, con
     }
     return RS_OK;
 }
+// the static agents + the step of a group of handles in one call (include/resco_sim.h); the policy network is device code only
+int rs_group_step(const rs_handle *hs, int32_t n, const rs_group_agent *agent, int32_t n_steps) {
+    if (!hs || n <= 0 || n_steps <= 0) return RS_EINVAL;
+    const int kind = agent ? agent->kind : RS_AGENT_NONE;
+    if (kind == RS_AGENT_IDQN || kind < 0 || kind > RS_AGENT_IDQN) return RS_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if ((kind == RS_AGENT_MAXWAVE || kind == RS_AGENT_MAXPRESSURE) && hs[i]->n_pairs == 0) return RS_EINVAL;
+    for (int k = 0; k < n_steps; ++k)
+        for (int i = 0; i < n; ++i) {
+            int rc = RS_OK;
+            if (kind == RS_AGENT_RANDOM) rc = rs_act_random(hs[i], agent->step_key + (uint32_t)k, nullptr);
+            else if (kind == RS_AGENT_MAXWAVE || kind == RS_AGENT_MAXPRESSURE) rc = rs_act_maxwave(hs[i], nullptr, hs[i]->n_pairs, nullptr, nullptr, kind == RS_AGENT_MAXPRESSURE, nullptr);
+            if (rc != RS_OK) return rc;
+            rs_step(hs[i], nullptr, 1, nullptr);
+        }
+    return RS_OK;
+}
 int rs_get_buffer(rs_handle h, int32_t which, void **dev_ptr, int64_t shape[4], int32_t *ndim, int32_t *dtype) {
     if (!h || which < 0 || which >= RS_BUF_COUNT) return RS_EINVAL;
     auto &B = h->bufs[which];

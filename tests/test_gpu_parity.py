@@ -814,6 +814,68 @@ def test_fused_idqn_policy_matches_torch_reference(map_name, n):
     env.close()
 
 
+def test_group_step_idqn_and_static_agents_on_the_device():
+    """rs_group_step: one call through the ABI launches [agent, step] for every pipe of a GPU.  (i) random policy: two pipes
+    through the group == the single batch through rs_act_random + rs_step; (ii) IDQN, greedy (epsilon 0): the group == per pipe
+    rs_idqn_act + rs_step; (iii) IDQN with exploration: the draws are keyed by the GLOBAL environment index, so two pipes through
+    the group == one handle with the whole batch through the group; several steps per call"""
+    import torch
+    from resco_amd.agents.idqn_fused import FusedIDQN
+    from resco_amd.agents.idqn_rollout import BatchedIDQN
+    from resco_amd.sim import BatchedSim, SimGroup
+    sc = load_scenario('cologne8')
+    n = 96
+    mk = lambda cnt, base: BatchedSim(sc, cnt, seed=4, env_base=base)
+    # (i)
+    whole, pipes = mk(n, 0), [mk(n // 2, 0), mk(n // 2, n // 2)]
+    grp = SimGroup(pipes)
+    for k in range(0, 20, 5):
+        for j in range(5):
+            whole.act_random(k + j)
+            whole.step(None)
+        grp.step('random', step_key=k, n_steps=5)
+    grp.sync()
+    for name in ('veh_pos', 'veh_lane', 'phase', 'mplight', 'actions', 'drq_norm_f16'):
+        np.testing.assert_array_equal(whole.read(name), np.concatenate([p.read(name) for p in pipes]))
+    # (ii) + (iii)
+    net = BatchedIDQN.from_scenario(sc, dtype=torch.float16, device='cuda')
+    net.init_like_reference(seed=5)
+    pol = FusedIDQN(net, seed=9)
+    solo = [mk(n // 2, 0), mk(n // 2, n // 2)]
+    for k in range(20):                         # the same history as the pipes of (i)
+        for s_ in solo:
+            s_.act_random(k)
+            s_.step(None)
+    for k in range(6):
+        for s_ in solo:
+            s_.sync()
+            pol.act(s_.tensor('drq_norm_f16'), epsilon=0.0, step_key=k, out=s_.tensor('actions'))
+            torch.cuda.synchronize()
+            s_.step(None)
+        grp.step('idqn', step_key=k, policy=pol._h, epsilon=0.0, seed=9)
+    grp.sync()
+    for s_ in solo:
+        s_.sync()
+    for name in ('veh_pos', 'phase', 'actions'):
+        np.testing.assert_array_equal(np.concatenate([p.read(name) for p in solo]), np.concatenate([p.read(name) for p in pipes]))
+    whole2 = mk(n, 0)
+    g1, g2 = SimGroup([whole2]), SimGroup([mk(n // 2, 0), mk(n // 2, n // 2)])
+    for g in (g1, g2):
+        g.step('random', step_key=0, n_steps=8)
+        g.step('idqn', step_key=8, n_steps=6, policy=pol._h, epsilon=0.5, epsilon_step=-0.05, seed=9)
+        g.sync()
+    a1 = whole2.read('actions')
+    a2 = np.concatenate([p.read('actions') for p in g2.sims])
+    np.testing.assert_array_equal(a1, a2)
+    np.testing.assert_array_equal(whole2.read('veh_pos'), np.concatenate([p.read('veh_pos') for p in g2.sims]))
+    assert len(np.unique(a1[:, 0])) > 1
+    with pytest.raises(RuntimeError, match='switched off'):
+        g1.sims[0].set_outputs(('drq_norm',))
+        g1.step('idqn', policy=pol._h)
+    for s_ in [whole, whole2] + pipes + solo + g2.sims:
+        s_.close()
+
+
 def test_fused_policy_sampling_mode_follows_the_softmax():
     """rs_idqn_act mode 1 (IPPO head on the same trunk): actions are drawn from softmax(logits) with the counter
     hash; over many environments x step keys the empirical action frequencies match the mean probabilities the

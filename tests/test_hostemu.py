@@ -393,3 +393,26 @@ def test_route_kwarg_one_route_file_per_run(tmp_path, monkeypatch):
     with pytest.raises(EnvironmentError):
         env.reset()                                     # there is no demand_3.rou.xml
     env.close()
+
+
+def test_group_step_equals_the_calls_it_replaces():
+    """rs_group_step (one call through the ABI for all pipes of a GPU) == per pipe [rs_act_*, rs_step], for the random policy and
+    MAXWAVE / MAXPRESSURE, several steps per call; the union of the pipes is the single batch (env_base keys the RNG)"""
+    from resco_amd.sim import SimGroup
+    sc = load_scenario('cologne8')
+    for agent in ('random', 'maxwave', 'maxpressure'):
+        whole = EmuSim(sc, 4, seed=3)
+        pipes = [EmuSim(sc, 2, seed=3, env_base=0), EmuSim(sc, 2, seed=3, env_base=2)]
+        grp = SimGroup(pipes)
+        for k in range(0, 24, 4):
+            for j in range(4):
+                if agent == 'random':
+                    whole.act_random(k + j)
+                else:
+                    whole.act_maxwave(1 if agent == 'maxpressure' else 0)
+                whole.step(None)
+            grp.step(agent, step_key=k, n_steps=4)
+        for name in ('veh_pos', 'veh_lane', 'phase', 'wait', 'mplight', 'actions'):
+            np.testing.assert_array_equal(whole.read(name), np.concatenate([p.read(name) for p in pipes]))
+    with pytest.raises(RuntimeError):
+        grp.step('idqn')                        # the policy network is device code: the emulation refuses

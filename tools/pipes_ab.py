@@ -106,6 +106,36 @@ def rollout(sc, n, k, steps, eps_mode, start=170, prio=False):
     return dict(mode='sim_plus_fused_policy_' + eps_mode + ('_prio' if prio else ''), envs=n, pipes=k, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3)
 
 
+def group_run(sc, n, k, steps, agent, start=170, per_call=1):
+    """the same two loops through rs_group_step: ONE call through ctypes per env-step (or per `per_call` env-steps) for all pipes"""
+    from resco_amd.sim import SimGroup
+    per = n // k
+    idqn = agent == 'idqn'
+    sims = [BatchedSim(sc, per, seed=0, sigma=-1.0, speed_dev=1, env_base=i * per) for i in range(k)]
+    for s in sims:
+        s.set_outputs(('drq_norm_f16',) if idqn else ('drq_norm', 'mplight'))
+    grp = SimGroup(sims)
+    kw = {}
+    if idqn:
+        from resco_amd.agents.idqn_fused import FusedIDQN
+        from resco_amd.agents.idqn_rollout import BatchedIDQN
+        net = BatchedIDQN.from_scenario(sc, dtype=torch.float16, device='cuda')
+        net.init_like_reference(seed=0)
+        pol = FusedIDQN(net, seed=7)
+        kw = dict(policy=pol._h, epsilon=1.0, seed=7)
+    grp.step('idqn' if idqn else 'random', step_key=0, n_steps=start, **kw)
+    sync_all(sims)
+    t0 = time.perf_counter()
+    for j in range(start, start + steps, per_call):
+        grp.step('idqn' if idqn else 'random', step_key=j, n_steps=min(per_call, start + steps - j), **kw)
+    sync_all(sims)
+    dt = time.perf_counter() - t0
+    for s in sims:
+        s.close()
+    return dict(mode=('sim_plus_fused_policy_eps1' if idqn else 'sim_only') + '_group', envs=n, pipes=k, steps=steps, steps_per_call=per_call,
+                env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--map', default='ingolstadt21')
@@ -115,6 +145,7 @@ def main():
     ap.add_argument('--rollout-only', action='store_true')
     ap.add_argument('--no-rollout', action='store_true')
     ap.add_argument('--prio', action='store_true', help='rollout: policy kernels on high-priority streams')
+    ap.add_argument('--group', action='store_true', help='only the rs_group_step runs (one ctypes call per step for all pipes)')
     a = ap.parse_args()
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', a.map + '.npz'))
     rows = []
@@ -126,6 +157,16 @@ def main():
             with open(a.out, 'a') as f:
                 f.write(json.dumps(r) + '\n')
 
+    if a.group:
+        for n in (1024, 4096):
+            for k in (1, 2, 4, 8) + ((16,) if n == 1024 else ()):
+                emit(sim_only(sc, n, k, a.steps))
+                emit(group_run(sc, n, k, a.steps, 'random'))
+            for k in (2, 4, 8):
+                emit(rollout(sc, n, k, a.steps, 'eps1'))
+                emit(group_run(sc, n, k, a.steps, 'idqn'))
+                emit(group_run(sc, n, k, a.steps, 'idqn', per_call=10))
+        return
     shapes = [(4096, 1), (4096, 2), (4096, 4), (3840, 1), (4608, 1), (4608, 2), (3072, 1), (8192, 1), (8192, 2)]
     if a.quick:
         shapes = shapes[:3]
