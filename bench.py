@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 EPISODE_STEPS = 360
 OUTPUTS = ('drq_norm', 'mplight')
 DEFAULT_PIPES = 2
+PER_PIPE_CALLS = os.environ.get('RESCO_BENCH_PER_PIPE_CALLS') == '1'
 
 
 def shard(rank, world, envs_per_gpu):
@@ -131,7 +132,12 @@ def run_timed(sims, steps, warmup, barrier, sync, reduce_max, all_outputs_steps=
         if k > 0 and k % EPISODE_STEPS == 0:
             for sim in sims:
                 sim.reset()
-        group.step('random', step_key=k)
+        if PER_PIPE_CALLS:                      # round 4's driver: two calls through ctypes per pipe and step (tools/host_ceiling.sh)
+            for sim in sims:
+                sim.act_random(k)
+                sim.step(None)
+        else:
+            group.step('random', step_key=k)
         k += 1
 
     def stats():
@@ -146,9 +152,22 @@ def run_timed(sims, steps, warmup, barrier, sync, reduce_max, all_outputs_steps=
     n_all = min(all_outputs_steps, ff + warmup)
     n_all_ff = min(n_all, ff)                   # ... of which inside the fast-forward
     all_outputs_rate = None
-    for _ in range(ff - n_all_ff):
-        one()
-    for _ in range(0 if n_all_ff else warmup - n_all):
+    # What the HOST needs to issue one step (all pipes): the first (up to) 48 untimed steps are handed to the runtime back to back and
+    # timed until the last call returns -- before the device has worked them off (the queues take them all) -- and only then waited
+    # for.  Under N ranks this is one rank's issue cost with the others competing for the cores: 1 / it is the step rate the host
+    # side can sustain.  (The network is still empty then: these steps say nothing about the kernel.)
+    n_plain = (ff - n_all_ff) + (0 if n_all_ff else warmup - n_all)
+    n_probe = min(48, n_plain)
+    issue_s = None
+    if n_probe > 0:
+        sync()
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(n_probe):
+            one()
+        issue_s = (time.perf_counter() - t3) / n_probe
+        sync()
+    for _ in range(n_plain - n_probe):
         one()
     if n_all > 0:
         for sim in sims:
@@ -183,7 +202,7 @@ def run_timed(sims, steps, warmup, barrier, sync, reduce_max, all_outputs_steps=
         sim.timing(False)
     st1 = stats()
     elapsed = reduce_max(t1 - t0)
-    return elapsed, kernel_ms, launches, st0, st1, all_outputs_rate, n_all, t1 - t0
+    return elapsed, kernel_ms, launches, st0, st1, all_outputs_rate, n_all, t1 - t0, issue_s
 
 
 def state_digest(sims, dist, rank, world):
@@ -316,7 +335,7 @@ def main():
     local = int(os.environ.get('RESCO_BENCH_DEVICE', local))
     backend = os.environ.get('RESCO_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local)
-    numa = bind_to_gpu_numa_node(local) if world > 1 else None
+    numa = bind_to_gpu_numa_node(local) if world > 1 and os.environ.get('RESCO_BENCH_NO_NUMA') != '1' else None
     dist = None
     if world > 1 or os.environ.get('RESCO_BENCH_FORCE_DIST') == '1':      # the env var exercises the RCCL path at N=1
         import torch.distributed as dist
@@ -353,7 +372,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed, kernel_ms, launches, st0, st1, all_out_rate, n_all, elapsed_local = run_timed(sims, args.steps, args.warmup, barrier, sync, reduce_max,
+    elapsed, kernel_ms, launches, st0, st1, all_out_rate, n_all, elapsed_local, issue_s = run_timed(sims, args.steps, args.warmup, barrier, sync, reduce_max,
                                                                                              all_outputs_steps=20)
     ticks = (st1['ticks'] - st0['ticks']).astype('float64')
     mean_active = float(((st1['active_ticks'] - st0['active_ticks']) / ticks.clip(min=1)).mean()) if ticks.min() > 0 \
@@ -402,6 +421,10 @@ def main():
                      'note': 'state is Infinity-Cache resident and the kernel is issue/latency bound: the HBM '
                              'fraction is small by construction (SURVEY.md 8d)'},
         'mean_active_vehicles_per_env': mean_active,
+        'host': {'issue_us_per_step': issue_s * 1e6 if issue_s else None, 'calls_per_step': 2 * args.pipes if PER_PIPE_CALLS else 1,
+                 'note': 'rank 0: wall time of the calls that hand ONE step (agent + step kernel of every pipe) to the runtime, measured on the first (up to) 48 untimed steps, '
+                         'issued back to back and not waited for until all are issued; %s'
+                         % ('two calls through ctypes per pipe (rs_act_random, rs_step)' if PER_PIPE_CALLS else 'one call through ctypes (rs_group_step)')},
         'sim_ticks_per_s': value * 10, 'vehicle_ticks_per_s': value * 10 * mean_active,
         'all_outputs': {'value': world * n_local * all_out_rate if all_out_rate else None, 'unit': 'env-steps/s', 'steps': n_all,
                         'episode_window': [max(0, w0 - args.warmup - n_all), max(0, w0 - args.warmup - n_all) + n_all] if w0 - args.warmup >= n_all else [w0 - n_all, w0],
