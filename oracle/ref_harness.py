@@ -50,7 +50,8 @@ class FakeSumo:
         s = self
         self.trafficlight, self.lane, self.vehicle, self.simulation = _NS(), _NS(), _NS(), _NS()
         self.trafficlight.getIDList = lambda: tuple(sorted(scenario.signal_ids))
-        self.trafficlight.getControlledLinks = lambda sid: []
+        # (the net's <connection tl= linkIndex=> elements: what Signal.generate_config reads, traffic_signal.py:117)
+        self.trafficlight.getControlledLinks = lambda sid: [[tuple(t) for t in lk] for lk in scenario.signal_meta[sid].get('controlled_links', [])]
         self.trafficlight.getAllProgramLogics = s._logics
         self.trafficlight.setProgramLogic = s._set_logic
         self.trafficlight.getPhase = lambda sid: s.orc.get_phase(s.sig_index[sid])

@@ -223,13 +223,65 @@ def program_index_at(program, t):
     return 0, program[0][0]
 
 
-def derive_signal_lanes(sig_cfg_map, sid):
-    """Restatement of Signal.__init__ lane bookkeeping (traffic_signal.py:49-87).
+MOVEMENTS = ['S-W', 'S-S', 'S-E', 'W-N', 'W-W', 'W-S', 'N-E', 'N-N', 'N-W', 'E-S', 'E-E', 'E-N']
+
+
+def controlled_links(net, sid):
+    """trafficlight.getControlledLinks(sid): per link index of the programme the list of (from lane, to lane, via lane) it controls
+    (traffic_signal.py:34, 117), from the net's <connection tl= linkIndex=> elements"""
+    by = {}
+    for c in net.conns:
+        if c.tl == sid and c.link_index >= 0:
+            by.setdefault(c.link_index, []).append(('%s_%d' % (c.frm, c.from_lane), '%s_%d' % (c.to, c.to_lane), c.via or ''))
+    return [by.get(i, []) for i in range(max(by) + 1)] if by else []
+
+
+def generate_signal_config(links, sid=''):
+    """Restatement of Signal.generate_config (traffic_signal.py:106-170), the reference's fallback for a signal WITHOUT an entry in
+    signal_configs[map]: made for the grid maps (three links per movement, lane ids that start with the upstream node's name).
+    lanes = the from-lanes of the controlled links in link order; every third link opens one of the twelve movements, in the fixed order
+    S-W .. E-N; downstream[d] = the leading `letters + digits` of the first lane of the straight movement that LEAVES towards d, unless
+    that names the network's fringe.  lane_sets_outbound stays EMPTY (states that read it -- mplight, mplight_full, fma2c -- raise
+    KeyError in the reference; here their outbound sums are simply empty)."""
+    import re
+    lanes = []
+    lane_sets = {m: [] for m in MOVEMENTS}
+    downstream = {'N': None, 'E': None, 'S': None, 'W': None}
+    for i, link in enumerate(links):
+        if not link:
+            raise EnvironmentError('signal %s: link index %d controls nothing (generate_config reads link[0])' % (sid, i))
+        frm = link[0][0]
+        if frm not in lanes:
+            lanes.append(frm)
+        if i % 3 == 0:
+            if i // 3 >= len(MOVEMENTS):
+                raise EnvironmentError('signal %s has more than 36 controlled links: generate_config (traffic_signal.py:121-123) has '
+                                       'twelve movements of three links' % sid)
+            lane_sets[MOVEMENTS[i // 3]].append(frm)
+    for mv, d in (('S-S', 'N'), ('N-N', 'S'), ('W-W', 'E'), ('E-E', 'W')):
+        if not lane_sets[mv]:
+            raise EnvironmentError('signal %s: generate_config needs a lane for movement %s (traffic_signal.py:134-160)' % (sid, mv))
+        found = re.findall('[a-zA-Z]+[0-9]+', lane_sets[mv][0])
+        if not found:
+            raise EnvironmentError('signal %s: lane id %r does not start with a node name (generate_config is made for the grid maps)'
+                                   % (sid, lane_sets[mv][0]))
+        if not any(f in found[0] for f in ('top', 'right', 'left', 'bottom')):
+            downstream[d] = found[0]
+    return lanes, lane_sets, downstream
+
+
+def derive_signal_lanes(sig_cfg_map, sid, links=None):
+    """Restatement of Signal.__init__ lane bookkeeping (traffic_signal.py:49-87); for a signal without an entry in the map's
+    signal_configs the reference's generate_config fallback over the controlled `links` (traffic_signal.py:88-89, 106-170).
 
     Returns dict(lanes, lane_sets, lane_sets_outbound, outbound_lanes, out_lane_to_signalid,
     inbounds_fr_direction, downstream).
     """
     rev = {'N': 'S', 'E': 'W', 'S': 'N', 'W': 'E'}
+    if sid not in sig_cfg_map:
+        lanes, lane_sets, downstream = generate_signal_config(links or [], sid)
+        return dict(lanes=lanes, lane_sets=lane_sets, lane_sets_outbound={k: [] for k in lane_sets}, outbound_lanes=[],
+                    out_lane_to_signalid={}, inbounds_fr_direction={}, downstream=downstream, generated=True)
     cfg = sig_cfg_map[sid]
     lane_sets = cfg['lane_sets']
     downstream = cfg['downstream']
@@ -803,7 +855,8 @@ def compile_scenario(name, net: Net, vtypes_xml, trips_xml, begin, end, sig_cfg_
     obs_index = {}
     missing_obs_lanes = []
     for sid in tl_ids:
-        meta = derive_signal_lanes(sig_cfg_map, sid)
+        signal_meta[sid]['controlled_links'] = [[list(t) for t in lk] for lk in controlled_links(net, sid)]
+        meta = derive_signal_lanes(sig_cfg_map, sid, signal_meta[sid]['controlled_links'])
         signal_meta[sid].update(meta)
         for lane in meta['lanes']:
             if lane in obs_index:

@@ -265,6 +265,34 @@ def test_multisignal_matches_reference_python(tag, fast):
 
 
 @pytest.mark.parametrize('tag', HOT_CASES + ['cologne1_d50_full'])
+def test_generated_signal_config_on_the_device():
+    """A map WITHOUT per-signal signal_configs entries (grid4x4's net, synthetic demand): every signal's lanes come from the
+    reference's generate_config fallback (traffic_signal.py:106-170).  HIP path vs the fixture the reference's own Python produced
+    (tests/golden/make_generated_config_golden.py): phases, lane aggregates, wave, wait, pressure exact, drq_norm to fp32."""
+    import json
+    from conftest import GOLDEN
+    from resco_amd.scenario import Scenario
+    from resco_amd.sim import BatchedSim
+    with open(os.path.join(GOLDEN, 'grid4x4_generated.json')) as f:
+        meta = json.load(f)
+    g = dict(np.load(os.path.join(GOLDEN, 'grid4x4_generated.npz')))
+    sc = Scenario.load(os.path.join(GOLDEN, 'grid4x4_generated_scenario.npz'))
+    sim = BatchedSim(sc, 1, seed=meta['seed'], max_distance=200)
+    for k in range(meta['steps'] + 1):
+        if k > 0:
+            sim.step(g['actions'][k - 1][None, :])
+        np.testing.assert_array_equal(sim.read('phase')[0], g['phase'][k])
+        np.testing.assert_array_equal(sim.read('lane_agg')[0][:, :4], g['agg'][k][:, :4])
+        np.testing.assert_array_equal(sim.read('wave')[0].reshape(-1), g['wave'][k])
+        np.testing.assert_array_equal(sim.read('wait')[0], g['wait'][k])
+        np.testing.assert_array_equal(sim.read('pressure')[0], g['pressure'][k])
+        np.testing.assert_allclose(sim.read('drq_norm')[0], g['drq_norm'][k].reshape(sc.n_obs, 5), rtol=2e-6, atol=2e-6)
+    st = sim.stats()
+    for key in ('inserted', 'arrived', 'sum_duration', 'sum_waiting'):
+        assert int(st[key][0]) == meta['oracle_stats'][key], key
+    sim.close()
+
+
 def test_device_agents_match_reference(tag):
     """rs_act_maxwave (MAXPRESSURE / MAXWAVE on device) vs the reference agents' actions (golden)."""
     from resco_amd.sim import BatchedSim
