@@ -34,7 +34,7 @@ def _rank_main(rank, world, port, outdir):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed, kms, launches, st0, st1, _ = bench.run_timed(sims, STEPS, WARMUP, dist.barrier, lambda: None, reduce_max)
+    elapsed, kms, launches, st0, st1 = bench.run_timed(sims, STEPS, WARMUP, dist.barrier, lambda: None, reduce_max)[:5]
     with open(os.path.join(outdir, 'rank%d.pkl' % rank), 'wb') as f:
         pickle.dump(dict(base=base, n=n, elapsed=elapsed, launches=launches, mplight=np.concatenate([x.read('mplight') for x in sims]),
                          lane_agg=np.concatenate([x.read('lane_agg') for x in sims]), ticks=(st1['ticks'] - st0['ticks'])), f)

@@ -264,7 +264,8 @@ def test_multisignal_matches_reference_python(tag, fast):
     env.close()
 
 
-@pytest.mark.parametrize('tag', HOT_CASES + ['cologne1_d50_full'])
+
+
 def test_generated_signal_config_on_the_device():
     """A map WITHOUT per-signal signal_configs entries (grid4x4's net, synthetic demand): every signal's lanes come from the
     reference's generate_config fallback (traffic_signal.py:106-170).  HIP path vs the fixture the reference's own Python produced
@@ -293,6 +294,7 @@ def test_generated_signal_config_on_the_device():
     sim.close()
 
 
+@pytest.mark.parametrize('tag', HOT_CASES + ['cologne1_d50_full'])
 def test_device_agents_match_reference(tag):
     """rs_act_maxwave (MAXPRESSURE / MAXWAVE on device) vs the reference agents' actions (golden)."""
     from resco_amd.sim import BatchedSim
