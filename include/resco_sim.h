@@ -86,7 +86,9 @@ typedef struct rs_params {
     int32_t trip_log;         /* 1: keep a per-trip record (RS_BUF_TRIP_LOG) for tripinfo output; costs N x n_trips x 16 B */
     int32_t step_ratio;       /* simulation steps per step_sim() call (MultiSignal(step_ratio=...), multi_signal.py:102-105): an env-step runs
                                * yellow_length x step_ratio ticks before Signal.set_phase and step_length x step_ratio ticks in all; the
-                               * RESCO waiting rule still adds step_length per observe (traffic_signal.py:196).  0 or 1: one */
+                               * RESCO waiting rule still adds step_length per observe (traffic_signal.py:196).  0 or 1: one.
+                               * A tick is always ONE second: a sub-second SUMO step length (what the reference uses step_ratio for)
+                               * is not modelled -- k means k one-second ticks per step_sim() */
     int32_t tls_expiry;       /* what trafficlight.setPhase (Signal.prep_phase / set_phase, traffic_signal.py:176-187) leaves behind:
                                * 0 (default) the phase stays until the next setPhase; 1 it expires after its programme duration and the
                                * programme continues with the next index, i -> i + 1 (mod P) -- what SUMO's setPhase is documented to do

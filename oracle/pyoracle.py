@@ -89,11 +89,6 @@ class OracleEnv:
         self._trip_log = trip_log
         self._h = lib().orc_create(C.byref(self._st), C.byref(self._p), env_index)
         self.S, self.O = scenario.n_signals, scenario.n_obs
-        if os.environ.get('ORC_STUDY_CONFLICTS'):           # junction study build (oracle/study/junction_study.py), never in tests
-            z = np.load(os.path.join(_HERE, 'study', '_conflicts_%s.npz' % scenario.name))
-            self._cf = [np.ascontiguousarray(z[k], np.int32) for k in ('start', 'cnt', 'links')]
-            lib().orc_study_set_conflicts.argtypes = [C.c_void_p] * 4
-            lib().orc_study_set_conflicts(self._h, *[a.ctypes.data for a in self._cf])
 
     def close(self):
         if self._h:

@@ -81,9 +81,6 @@ struct orc_env {
     int32_t *lane_arr;      /* [n_obs] vehicles of the lane that are in their signal's `arrivals` set (rewards.fma2c fringe arrivals) */
     float *mplight_full;
     int64_t stats[10];
-#ifdef RM_STUDY_JUNCTION
-    const int32_t *cf_start, *cf_cnt, *cf_link;     /* study only: conflicting first-stage links per link (oracle/study/conflicts.py) */
-#endif
 };
 
 /* ------------------------------------------------------------------ counter-based RNG (murmur3_32) */
@@ -463,43 +460,6 @@ static int foe_blocked(const orc_env *e, int32_t link) {
     return 0;
 }
 
-#ifdef RM_STUDY_JUNCTION
-/* STUDY BUILD ONLY (oracle/study/junction_study.py; never the shipped oracle): two junction rules of SUMO this model does not have.
- *  bit 0  link leaders: a vehicle does not enter a junction while a vehicle of a CONFLICTING movement (the <request foes> matrix:
- *         crossing and merging paths, whatever their priority) is on that movement's junction lanes; of a movement that waits inside
- *         the junction (cont) only the part behind the waiting position counts.  bit 1: standing vehicles count as well as moving ones
- *  bit 2  keepClear: a vehicle does not enter a junction unless it fits behind the last STANDING vehicle of its destination lane */
-void orc_study_set_conflicts(orc_env *e, const int32_t *start, const int32_t *cnt, const int32_t *links) { e->cf_start = start; e->cf_cnt = cnt; e->cf_link = links; }
-static int lane_occupied(const orc_env *e, int32_t lane, int movers_only) {
-    for (int32_t s = e->lane_head[lane]; s != NIL; s = e->next_in_lane[s])
-        if (!movers_only || e->speed[s] > HALT_SPEED) return 1;
-    return 0;
-}
-static int study_conflict(const orc_env *e, int32_t link) {
-    const orc_scenario *sc = e->sc;
-    if (!e->cf_start) return 0;
-    const int movers_only = !((RM_STUDY_JUNCTION) & 2);
-    for (int32_t i = e->cf_start[link]; i < e->cf_start[link] + e->cf_cnt[link]; ++i) {
-        int32_t f = e->cf_link[i];
-        if (!sc->link_cont[f] && sc->link_via1[f] >= 0 && lane_occupied(e, sc->link_via1[f], movers_only)) return 1;
-        if (sc->link_via2[f] >= 0 && lane_occupied(e, sc->link_via2[f], movers_only)) return 1;
-    }
-    return 0;
-}
-static int study_no_room(const orc_env *e, int32_t link, const float *vt) {
-    const orc_scenario *sc = e->sc;
-    int32_t D = sc->link_dest_lane[link];
-    int32_t o = rearmost(e, D, BIGF);
-    if (o == NIL || e->speed[o] > HALT_SPEED) return 0;
-    float space = e->pos[o] - vt_of(e, trip_of_slot(e, o))[VT_LENGTH];
-    for (int k = 0; k < 2; ++k) {
-        int32_t via = k ? sc->link_via2[link] : sc->link_via1[link];
-        if (via < 0) continue;
-        for (int32_t s = e->lane_head[via]; s != NIL; s = e->next_in_lane[s]) { const float *vo = vt_of(e, trip_of_slot(e, s)); space -= vo[VT_LENGTH] + vo[VT_MINGAP]; }
-    }
-    return space - (vt[VT_LENGTH] + vt[VT_MINGAP]) < 0.0f;
-}
-#endif
 static void plan(orc_env *e) {
     const orc_scenario *sc = e->sc;
     for (int32_t s = 0; s < e->hw; ++s) {
@@ -589,12 +549,6 @@ static void plan(orc_env *e) {
                 if (seen > RM_VIS_DIST) { stop_here = 1; e->dbg_reason[s] = 7; e->dbg_block[s] = link; }
                 else if (sc->link_foe_cnt[link] > 0 && foe_blocked(e, link)) { stop_here = 1; e->dbg_reason[s] = 4; e->dbg_block[s] = link; }
             }
-#ifdef RM_STUDY_JUNCTION
-            if (!stop_here && !sc->lane_internal[cur] && seen >= orc_brake_gap(v, b)) {
-                if (((RM_STUDY_JUNCTION) & 1) && study_conflict(e, link)) { stop_here = 1; e->dbg_reason[s] = 4; e->dbg_block[s] = link; }
-                else if (((RM_STUDY_JUNCTION) & 4) && study_no_room(e, link, vt)) { stop_here = 1; e->dbg_reason[s] = 5; e->dbg_block[s] = link; }
-            }
-#endif
             if (stop_here) {
                 float g = seen - STOP_OFFSET;
                 float vs = orc_stop_speed(g > 0.0f ? g : 0.0f, b, tau);

@@ -86,9 +86,24 @@ class FusedIDQN:
         self.close()
         self._h = h
         lanes = np.asarray(self.net.lanes, np.int32)            # the signals' own head sizes: padded lanes are skipped
+        self._check_padded_rows_are_zero()
         self._lib.rs_idqn_set_lanes.argtypes = [C.c_void_p, C.c_void_p]
         if self._lib.rs_idqn_set_lanes(self._h, lanes.ctypes.data) != 0:
             raise RuntimeError('rs_idqn_set_lanes failed')
+
+    @torch.no_grad()
+    def _check_padded_rows_are_zero(self):
+        """rs_idqn_set_lanes makes the kernel skip the fc1 k-steps of a signal's padded lanes: only correct while the fc1 rows of
+        those lanes ARE zero (BatchedIDQN builds them so and the masked learner keeps them there).  Weights from anywhere else that
+        break this would silently change the Q-values: refuse them here."""
+        H = self.lmax - 1
+        w = self.net.fc1_w.detach()
+        for s, L in enumerate(self.net.lanes):
+            if L - 1 < H:
+                pad = w[s].reshape(64, H, 4, -1)[:, L - 1:]
+                if bool((pad != 0).any()):
+                    raise ValueError('signal %d observes %d lanes but its fc1 weights have non-zero rows for padded lanes: the fused kernel '
+                                     'would skip them (rs_idqn_set_lanes)' % (s, L))
 
     @torch.no_grad()
     def refresh_on_device(self):

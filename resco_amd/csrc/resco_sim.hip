@@ -342,7 +342,11 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     if (C < 64 || (C % 64) || C > 1984) { h->err = "capacity must be a multiple of 64 in [64, 1984]"; return fail(RS_ELIMIT); }
     if (sc->kmax < 1 || sc->kmax > 16) { h->err = "kmax (lanes per edge) must be in [1, 16]"; return fail(RS_ELIMIT); }
     PackedTables PT;
-    if (!PT.build(sc)) { h->err = PT.err; return fail(RS_ELIMIT); }
+    {   // grid cell length: build once to learn the sizes that do not depend on it, choose, build for good
+        PackedTables probe;
+        if (!probe.build(sc)) { h->err = probe.err; return fail(RS_ELIMIT); }
+        if (!PT.build(sc, pick_cell_len(sc, probe.n_arr, probe.n_dep, probe.tls_maxl))) { h->err = PT.err; return fail(RS_ELIMIT); }
+    }
     h->tls_ngreen.assign(sc->tls_ngreen, sc->tls_ngreen + sc->n_signals);
     int rc;
     KTab &K = h->K;
@@ -480,6 +484,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     {
         StepArgs sa{h->K, h->G, h->O, Lds{}};
         lds_carve(&sa.L, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
+        sa.L.cell_inv = PT.cell_inv;
         if ((rc = dev_alloc(h, &h->args, 1, false))) return fail(rc);
         if (hipMemcpy(h->args, &sa, sizeof(sa), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy(StepArgs) failed"; return fail(RS_EHIP); }
     }

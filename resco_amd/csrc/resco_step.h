@@ -195,6 +195,7 @@ struct Lds {
     LPtr<int32_t> sc;           // scalars, see SC_*
     LPtr<uint16_t> ls_h, ls_lc, ls_mh;      // work lists (slots), `lcap` entries each; a list that overflows is ignored and
     uint32_t lcap;                          // the phase falls back to the flags (every thread handles its own slots in full)
+    float cell_inv;                         // 1 / grid cell length of this handle's tables (PackedTables::cell_inv; set by rs_create)
 };
 #define SC_T 0
 #define SC_NINS 1
@@ -261,6 +262,17 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
     return o;
 }
 
+// The grid cell length of a scenario: the shortest of CELL_CHOICES with which the working memory of an environment still lets three
+// workgroups share a CU (resco_tables.h); n_arr / n_dep / tls_maxl as PackedTables::build found them (they do not depend on it)
+RS_CARVE float pick_cell_len(const rs_scenario *sc, int n_arr, int n_dep, int tls_maxl) {
+    const float choices[] = CELL_CHOICES;
+    const int n = (int)(sizeof(choices) / sizeof(choices[0]));
+    for (int i = 0; i < n; ++i)
+        if (lds_carve(nullptr, sc->capacity, PackedTables::count_cells(sc, choices[i]), n_arr, n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, tls_maxl) <= RS_LDS_3WG_LIMIT)
+            return choices[i];
+    return choices[n - 1];
+}
+
 // ------------------------------------------------------------------------------------------------ grid primitives
 #ifdef RS_EMU_DEBUG         // host emulation, debug build: a chain that does not end means a vehicle entered a grid twice
 #define RS_CHAIN_GUARD if (++rs_dbg_chain > 50000000L) { printf("endless chain walk\n"); fflush(stdout); abort(); }
@@ -275,8 +287,8 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
 #define RS_SEC(id) {}
 #endif
 RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
-RS_DEV int lane_cells(const LaneRec &LR) { return (int)(LR.len * CELL_INV) + 1; }
-RS_DEV int cell_of(float pos, int ncell) { const int c = (int)(pos * CELL_INV); return c < ncell ? c : ncell - 1; }
+RS_DEV int lane_cells(const Lds &L, const LaneRec &LR) { return (int)(LR.len * L.cell_inv) + 1; }
+RS_DEV int cell_of(const Lds &L, float pos, int ncell) { const int c = (int)(pos * L.cell_inv); return c < ncell ? c : ncell - 1; }
 
 // push slot s into cell c; returns the previous head (the new chain link).  16-bit cells, exchanged with a CAS on the
 // containing dword (LDS has no 16-bit atomics); the cell's vehicle count goes up by one
@@ -374,14 +386,14 @@ RS_DEV int chain_frontmost(const Lds &L, int head) {
 // rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
 RS_DEV int rearmost_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float win) {
     if (win < 0.0f) return NIL;
-    const int c = scan_up(grid, cell0, cell0 + cell_of(win, ncell));
+    const int c = scan_up(grid, cell0, cell0 + cell_of(L, win, ncell));
     if (c < 0) return NIL;
     const int o = chain_rearmost(L, grid[c]);
     return (o != NIL && L.node[o].pos > win) ? NIL : o;
 }
 // nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front)
 RS_DEV int leader_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
-    const int c = cell_of(pos, ncell);
+    const int c = cell_of(L, pos, ncell);
     int Ld = NIL, Lk = 0;
     float Lp = 0.0f;
     for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD        // my own cell first
@@ -392,7 +404,7 @@ RS_DEV int leader_within(const Lds &L, const uint16_t *grid, int cell0, int ncel
         if (ahead_of(nd.pos, nd.trip, pos, k) && (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip))) { Ld = cur; Lk = nd.trip; Lp = nd.pos; }
     }
     if (Ld == NIL && c + 1 < ncell) {
-        const int cc = scan_up(grid, cell0 + c + 1, cell0 + cell_of(pos + win, ncell));
+        const int cc = scan_up(grid, cell0 + c + 1, cell0 + cell_of(L, pos + win, ncell));
         if (cc >= 0) { Ld = chain_rearmost(L, grid[cc]); Lp = L.node[Ld].pos; }
     }
     if (Ld != NIL && Lp - pos > win) Ld = NIL;
@@ -400,7 +412,7 @@ RS_DEV int leader_within(const Lds &L, const uint16_t *grid, int cell0, int ncel
 }
 // nearest vehicle behind (pos, k) on the lane (not `self`), at most `win` metres away
 RS_DEV int follower_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
-    const int c = cell_of(pos, ncell);
+    const int c = cell_of(L, pos, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
     for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD
@@ -412,7 +424,7 @@ RS_DEV int follower_within(const Lds &L, const uint16_t *grid, int cell0, int nc
     }
     if (Fd == NIL && c > 0) {
         const float lo = pos - win;
-        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
+        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
         if (cc >= 0) { Fd = chain_frontmost(L, grid[cc]); Fp = L.node[Fd].pos; }
     }
     if (Fd != NIL && pos - Fp > win) Fd = NIL;
@@ -421,7 +433,7 @@ RS_DEV int follower_within(const Lds &L, const uint16_t *grid, int cell0, int nc
 // nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
 RS_DEV int at_or_behind_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float back, float win) {
     if (back < 0.0f) return NIL;
-    const int c = cell_of(back, ncell);
+    const int c = cell_of(L, back, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
     for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD
@@ -431,7 +443,7 @@ RS_DEV int at_or_behind_within(const Lds &L, const uint16_t *grid, int cell0, in
     }
     if (Fd == NIL && c > 0) {
         const float lo = back - win;
-        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(lo, ncell) : 0), cell0 + c - 1);
+        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
         if (cc >= 0) { Fd = chain_frontmost(L, grid[cc]); Fp = L.node[Fd].pos; }
     }
     if (Fd != NIL && back - Fp > win) Fd = NIL;
@@ -597,6 +609,10 @@ RS_DEV float plan_vfree(const float *vt, float v, float lane_vmax, float sf) {
     if (vt[VT_MAXSPEED] < vfree) vfree = vt[VT_MAXSPEED];
     return vfree;
 }
+// (classify() and phase_plan() both evaluate plan_vfree / plan_look, at different inline sites; the short paths of the plan and the move
+// rely on the two giving the SAME bits -- a vehicle without FL_H never has `seen < look` in its plan.  That holds because the library is
+// built with -ffp-contract=off (resco_amd/build.py): no site-dependent FMA fusion.  The host emulation asserts it (RS_ASSERT), and
+// every HIP == oracle test would see a missed stop line as a position difference.)
 RS_DEV float plan_look(const float *vt, float vfree) { return d_brake_gap(vfree, vt[VT_DECEL]) + vfree * vt[VT_TAU] + vt[VT_MINGAP] + 1.0f; }
 // FL_H for a vehicle at x on a lane of length len: the end of the lane is inside its look-ahead
 RS_DEV bool looks_beyond(const float *vt, float v, float x, float lane_len, float lane_vmax, float sf) {
@@ -649,7 +665,7 @@ template <bool LONG> RS_DEV void phase_plan(const KTab &T, const Lds &L, const u
     bool have = false;
     const float look = plan_look(vt, vfree);
     if (LONG) RS_SEC(7)
-    const int lead = leader_within(L, grid, LR.cell0, lane_cells(LR), x, k, s, look + T.maxlen);
+    const int lead = leader_within(L, grid, LR.cell0, lane_cells(L, LR), x, k, s, look + T.maxlen);
     if (LONG) RS_SEC(8)
     bool found = false;
     if (lead != NIL) {
@@ -706,7 +722,7 @@ template <bool LONG> RS_DEV void phase_plan(const KTab &T, const Lds &L, const u
                     if (vs < vsafe) vsafe = vs;
                 }
             }
-            const int o = rearmost_within(L, grid, LR.cell0, lane_cells(LR), look - seen + T.maxlen);
+            const int o = rearmost_within(L, grid, LR.cell0, lane_cells(L, LR), look - seen + T.maxlen);
             if (o != NIL) {
                 const Node od = L.node[o];
                 const float *vo = L.vtp + od.vt * VT_COLS;
@@ -776,7 +792,7 @@ template <bool LONG> RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_
     const int sw = ax.swait;
     int swn = sw;
     const float vn = L.vnx[s];
-    gold[LR.cell0 + cell_of(me.pos, lane_cells(LR))] = NIL;         // every vehicle of a cell stores the same: the old grid empties
+    gold[LR.cell0 + cell_of(L, me.pos, lane_cells(L, LR))] = NIL;         // every vehicle of a cell stores the same: the old grid empties
     int rq = ax.rq;
     uint16_t nlink = ax.nlink;              // the link after the lane the vehicle ends up on, as cache_link() returns it
     int link = (int)(nlink & 0x7FFF);
@@ -853,7 +869,7 @@ template <bool LONG> RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_
     L.aux[s] = na;
     Node nn = me;
     nn.pos = x; nn.speed = vn; nn.fl = (uint8_t)(me.fl & fl_mh(t));
-    nn.nxt = grid_push(gnew, LR.cell0 + cell_of(x, lane_cells(LR)), s, vn > RM_HALT_SPEED);
+    nn.nxt = grid_push(gnew, LR.cell0 + cell_of(L, x, lane_cells(L, LR)), s, vn > RM_HALT_SPEED);
     if (more) {
         if (LONG && relink) { R = cont_row(T, rq); if (na.nlink & NLINK_ARR) kw = link_reg_word(T, na.nlink); }
         nn.fl |= classify(L, s, L.vtp + me.vt * VT_COLS, vn, x, LR, lane, R, k, sfv, t + 1);
@@ -888,7 +904,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
     const int k = me.trip;
     const float *vt = L.vtp + me.vt * VT_COLS;
     const float x = me.pos, v = me.speed;
-    const int nc = lane_cells(LR);
+    const int nc = lane_cells(L, LR);
     int want = 0, dir = dir_allowed;
     float rem;
     const int sdir = strategic_dir(R, kk, n, x, v, 0, rem, grid, LR.cell0, nc, T.occ_unit);
@@ -979,8 +995,8 @@ RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, const uint16_t *gri
     const float *vt = L.vtp + T.trip_vtype()[k] * VT_COLS;
     const float mypos = vt[VT_LENGTH] < LR.len ? vt[VT_LENGTH] : LR.len;
     // only vehicles with pos - length < mypos + minGap can be in the way
-    const int nc = (int)(LR.len * CELL_INV) + 1;      // lane_cells()
-    const int c1 = LR.cell0 + cell_of(mypos + vt[VT_MINGAP] + T.maxlen, nc);
+    const int nc = (int)(LR.len * L.cell_inv) + 1;      // lane_cells(L, )
+    const int c1 = LR.cell0 + cell_of(L, mypos + vt[VT_MINGAP] + T.maxlen, nc);
     for (int c = scan_up(grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(grid, c + 1, c1) : -1))
         for (int o = grid[c] & NIL; o != NIL;) { RS_CHAIN_GUARD
             const Node od = L.node[o];
@@ -1059,7 +1075,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             L.aux[s] = ax;
             Node nn; nn.pos = x; nn.speed = sp; nn.trip = tr; nn.vt = T.trip_vtype()[tr];
             nn.fl = 0; nn.sfq = (uint16_t)(int)(G.sf()[eo + s] * RM_SF_QUANT + 0.5f);
-            nn.nxt = grid_push(grid0, LR0.cell0 + cell_of(x, lane_cells(LR0)), s, sp > RM_HALT_SPEED);
+            nn.nxt = grid_push(grid0, LR0.cell0 + cell_of(L, x, lane_cells(L, LR0)), s, sp > RM_HALT_SPEED);
             if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, sf_of(nn.sfq), L.sc[SC_T]);
             L.node[s] = nn;
             rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
@@ -1210,7 +1226,7 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
                         const float sfn = sf_of(sfq);
                         Node nn; nn.pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
                         nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.sfq = (uint16_t)sfq;
-                        nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(nn.pos, lane_cells(LRd)), s, false);
+                        nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(L, nn.pos, lane_cells(L, LRd)), s, false);
                         if (more) nn.fl = (uint8_t)classify(L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, cont_row(T, (int)RR.start), k, sfn, t + 1);
                         L.node[s] = nn;
                         Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.swait = 0;

@@ -29,10 +29,15 @@ enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, 
 // The lanes are covered by a grid of CELL_LEN-metre cells (floor(len / CELL_LEN) + 1 per lane, lanes in index order):
 // a cell holds the slot of a vehicle whose front is inside it (more than one: a short chain).  Every neighbour search of
 // the model is a bounded scan over a few consecutive cells.
-#ifndef CELL_LEN
-#define CELL_LEN 32.0f
+// The cell length is chosen per scenario when a handle is created (pick_cell_len, resco_step.h): the shortest of CELL_CHOICES with which the
+// working memory of an environment still lets three workgroups share a CU -- shorter cells mean shorter chains (30 m instead of
+// 32 m: +1.8 % on ingolstadt21 x 4096, profiles/r05_ab_cells.txt), one cell too many means two workgroups per CU (-25 %).
+#ifdef CELL_LEN                 // (study builds: one fixed length)
+#define CELL_CHOICES {CELL_LEN}
+#else
+#define CELL_CHOICES {30.0f, 32.0f, 36.0f, 40.0f, 48.0f}
 #endif
-#define CELL_INV (1.0f / CELL_LEN)
+#define RS_LDS_3WG_LIMIT 53760  // bytes of LDS per workgroup up to which three of them fit one CU of the MI355X (measured: 53 664 three, 53 824 two)
 
 // ---- 16-byte records: one global_load_dwordx4 fetches everything about a lane / foe / route
 struct __attribute__((aligned(16))) LaneRec {
@@ -167,6 +172,7 @@ struct PackedTables {
     std::vector<int32_t> obs_sig;
     int n_cells = 0, n_arr = 1, n_dep = 1, kmax = 1, lmax = 1, tls_maxl = 1;
     float maxlen = 0.0f, occ_unit = 0.0f;
+    float cell_len = 32.0f, cell_inv = 1.0f / 32.0f;       // grid cell length of this build of the tables (pick_cell_len)
     std::string err;
 
     // the link a vehicle on normal lane `ln` takes towards route step q + 1 (oracle/resco_oracle.c choose_link restated
@@ -192,7 +198,16 @@ struct PackedTables {
         if (n == 1) out[1] = out[0];
     }
 
-    bool build(const rs_scenario *sc) {
+    // grid cells of the whole network for a given cell length (what build() lays out)
+    static int count_cells(const rs_scenario *sc, float len) {
+        const float inv = 1.0f / len;
+        int n = 0;
+        for (int l = 0; l < sc->n_lanes; ++l) n += (int)(sc->lane_len[l] * inv) + 1;
+        return n;
+    }
+
+    bool build(const rs_scenario *sc, float cell_len_ = 32.0f) {
+        cell_len = cell_len_; cell_inv = 1.0f / cell_len_;
         if (sc->n_lanes >= 0xFFFE || sc->n_trips >= 0xFFFF || sc->n_routes > 0xFFFF || sc->n_vtypes > 255 || sc->n_signals > 254) {
             err = "scenario exceeds id widths (lanes/trips/routes u16, vtypes/signals u8)"; return false;
         }
@@ -220,8 +235,8 @@ struct PackedTables {
         // so short that a CELL_LEN-metre cell could hold that many fronts bumper to bumper
         for (int v = 0; v < sc->n_vtypes; ++v) {
             const float unit = sc->vtype_params[v * VT_COLS + VT_LENGTH] + sc->vtype_params[v * VT_COLS + VT_MINGAP];
-            if (!(unit > 0.0f) || (int)(CELL_LEN / unit) + 1 >= (int)CELL_CNT_MAX) {
-                err = "a vehicle type is too short for the grid cells: floor(CELL_LEN / (length + minGap)) + 1 must stay below 15"; return false;
+            if (!(unit > 0.0f) || (int)(cell_len / unit) + 1 >= (int)CELL_CNT_MAX) {
+                err = "a vehicle type is too short for the grid cells: floor(cell length / (length + minGap)) + 1 must stay below 15"; return false;
             }
         }
         std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
@@ -246,7 +261,7 @@ struct PackedTables {
             R.edge_lane0 = (uint16_t)(e >= 0 ? sc->edge_lane0[e] : 0);
             // grid cells: lanes of one edge are consecutive and equally long, so their cell blocks are consecutive and
             // equally sized (relied on by the lane change: the neighbour lane's block is one block further)
-            lane_nc[l] = (int)(sc->lane_len[l] * CELL_INV) + 1;
+            lane_nc[l] = (int)(sc->lane_len[l] * cell_inv) + 1;
             if (lane_nc[l] > 255) { err = "lane longer than 255 grid cells"; return false; }
             R.cell0 = (uint16_t)n_cells;
             n_cells += lane_nc[l];

@@ -103,6 +103,14 @@ class MultiSignal(_EnvBase):
                  fixed_program=False, scenario=None, use_fast_path=True, tripinfo=True, tls_expiry=False):
         if int(step_ratio) < 1:
             raise ValueError('step_ratio must be a positive integer')
+        if int(step_ratio) > 1:
+            # the reference uses step_ratio for SUB-SECOND SUMO steps (its .sumocfg sets the step length; e.g. four 0.25 s steps per
+            # step_sim()).  A tick here is always 1 s: step_ratio = k means k one-second ticks per step_sim(), so an env-step advances
+            # step_length x k simulated seconds and `done` comes after 1 / k of the env-steps.  The loop structure is the reference's
+            # (pinned by tests/golden/cologne8_d200_sr2), the time semantics of a sub-second configuration are not.
+            import warnings
+            warnings.warn('step_ratio=%d: ticks stay 1 s long here (a sub-second SUMO step length is not modelled); one env-step '
+                          'covers %d simulated seconds' % (int(step_ratio), int(step_length) * int(step_ratio)))
         self.libsumo, self.gymma, self.gui = libsumo, gymma, gui
         self.log_dir, self.net, self.route = log_dir, net, route
         self.state_fn, self.reward_fn = state_fn, reward_fn

@@ -154,7 +154,11 @@ extern "C" {
 // block_threads < 0 selects thread order: -1 descending, -2 shuffled (with one thread per slot); order > 0 as given
 int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id, int32_t block_threads, rs_handle *out) {
     rs_sim *h = new rs_sim();
-    if (!h->PT.build(sc)) { g_err = h->PT.err; delete h; return RS_ELIMIT; }
+    {   // (the library's choice of the grid cell length, resco_sim.hip)
+        PackedTables probe;
+        if (!probe.build(sc)) { g_err = probe.err; delete h; return RS_ELIMIT; }
+        if (!h->PT.build(sc, pick_cell_len(sc, probe.n_arr, probe.n_dep, probe.tls_maxl))) { g_err = h->PT.err; delete h; return RS_ELIMIT; }
+    }
     PackedTables &PT = h->PT;
     const int C = sc->capacity;
     h->order = device_id;           // the emulation has no device: the argument carries the thread order
@@ -198,6 +202,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->G.trip_log = nullptr;
     if (p->trip_log) { h->trip_log.assign(N * (size_t)sc->n_trips * 4, 0); h->G.trip_log = h->trip_log.data(); }
     h->lds = lds_carve(&h->L, C, K.n_cells, K.n_arr, K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, K.tls_maxl);
+    h->L.cell_inv = h->PT.cell_inv;
     h->smem.assign(h->lds + 64, 0);
     State &G = h->G; Out &O = h->O;
     const int64_t n = n_envs, cc = C, s = sc->n_signals, o = sc->n_obs, lmax = PT.lmax;
