@@ -134,7 +134,8 @@ int rs_ticks(rs_handle h, int32_t n_ticks, void *stream);
 int rs_step_sim(rs_handle h, int32_t n_ticks, void *stream);
 /* Which per-lane / per-movement output buffers the observes of the FOLLOWING launches write: bit b of buffer_mask = buffer id
  * b (RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_DRQ_NORM_F16, RS_BUF_LANE_ARRIVALS, RS_BUF_MPLIGHT, RS_BUF_WAVE,
- * RS_BUF_MPLIGHT_FULL); buffers left out keep their contents and cost no HBM traffic.  The per-signal scalars (phase,
+ * RS_BUF_MPLIGHT_FULL, and RS_BUF_VEH_ACCEL -- the per-vehicle acceleration of the last tick, which only the Signal views' vehicle
+ * dicts read); buffers left out keep their contents and cost no HBM traffic.  The per-signal scalars (phase,
  * wait, wait_norm, pressure, queue_sum / max, arrivals, departures) are always written.  Default: all. */
 int rs_set_outputs(rs_handle h, uint64_t buffer_mask);
 int rs_sync(rs_handle h);

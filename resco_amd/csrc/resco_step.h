@@ -813,7 +813,7 @@ template <bool LONG> RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_
         relink = true;
     }
     const float vref = LR.vmax * sfv;
-    if (last_tick) G.accel()[eo + s] = vn - me.speed;
+    if (last_tick && (P.out_mask & OUT_VEH_ACCEL)) G.accel()[eo + s] = vn - me.speed;
     if (vn <= RM_HALT_SPEED) {
         if (sw < 65535) swn = sw + 1;
         halted += 1;
@@ -1074,7 +1074,9 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             ax.swait = G.swait()[eo + s];
             L.aux[s] = ax;
             Node nn; nn.pos = x; nn.speed = sp; nn.trip = tr; nn.vt = T.trip_vtype()[tr];
-            nn.fl = 0; nn.sfq = (uint16_t)(int)(G.sf()[eo + s] * RM_SF_QUANT + 0.5f);
+            // the speed factor is a function of (seed, environment, trip): recomputed here (four hashes per vehicle and ENV-STEP) instead of
+            // read back -- 4 B per slot and step less from HBM; RS_BUF_VEH_SF is written at the insertion, for whoever reads it
+            nn.fl = 0; nn.sfq = (uint16_t)speed_factor_q(P, genv, tr, L.vtp + nn.vt * VT_COLS);
             nn.nxt = grid_push(grid0, LR0.cell0 + cell_of(L, x, lane_cells(L, LR0)), s, sp > RM_HALT_SPEED);
             if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, sf_of(nn.sfq), L.sc[SC_T]);
             L.node[s] = nn;

@@ -154,7 +154,8 @@ struct KParams {
 #define OUT_MPLIGHT 16u
 #define OUT_WAVE 32u
 #define OUT_MPLIGHT_FULL 64u
-#define OUT_ALL 127u
+#define OUT_VEH_ACCEL 128u       // RS_BUF_VEH_ACCEL (the last tick's acceleration per vehicle: only the Signal views' vehicle dicts read it)
+#define OUT_ALL 255u
 #define TLS_W 4         // ints per signal in State.tls: phase, time left, next_phase, |Signal.departures| collected since the last observe
 
 // ---------------------------------------------------------------------------------------------- host-side builder

@@ -20,7 +20,7 @@ BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_nor
            'veh_sf', 'veh_wtot', 'trip_log', 'dep_next', 'veh_coop', 'veh_cooplead', 'arrivals', 'departures',
            'mplight_full', 'lane_arrivals', 'veh_coop_odd', 'veh_cooplead_odd']
 BUF_ID = {n: i for i, n in enumerate(BUFFERS)}
-OUTPUT_GROUPS = ('lane_agg', 'drq_norm', 'drq_norm_f16', 'lane_arrivals', 'mplight', 'wave', 'mplight_full')
+OUTPUT_GROUPS = ('lane_agg', 'drq_norm', 'drq_norm_f16', 'lane_arrivals', 'mplight', 'wave', 'mplight_full', 'veh_accel')
 _NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64, np.uint32]
 _TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8', '<u4']
 STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10',

@@ -274,6 +274,7 @@ int rs_set_outputs(rs_handle h, uint64_t buffer_mask) {
     if (buffer_mask & (1ull << RS_BUF_MPLIGHT)) m |= OUT_MPLIGHT;
     if (buffer_mask & (1ull << RS_BUF_WAVE)) m |= OUT_WAVE;
     if (buffer_mask & (1ull << RS_BUF_MPLIGHT_FULL)) m |= OUT_MPLIGHT_FULL;
+    if (buffer_mask & (1ull << RS_BUF_VEH_ACCEL)) m |= OUT_VEH_ACCEL;
     h->out_mask = m;
     return RS_OK;
 }

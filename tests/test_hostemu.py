@@ -287,6 +287,11 @@ def test_output_mask_writes_only_what_was_asked_for():
     for b in ('lane_agg', 'wave', 'mplight_full', 'lane_arrivals'):
         np.testing.assert_array_equal(new[b], old[b], err_msg=b)
         assert not np.array_equal(new[b][0], ref[b])
+    # the per-vehicle acceleration (RS_BUF_VEH_ACCEL) is a maskable buffer too: not written since the mask was set
+    v = o.vehicles()
+    live = v['lane'] != 0xFFFF
+    assert live.any() and np.array_equal(sim.read('veh_speed')[0][live], v['speed'][live])
+    assert not np.array_equal(sim.read('veh_accel')[0][live], v['accel'][live])
     # consumers of a switched-off buffer fail loudly instead of acting on stale rows: the MAXWAVE agent reads `wave`
     # (off), the MAXPRESSURE agent `mplight` (on)
     with pytest.raises(RuntimeError):

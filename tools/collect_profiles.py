@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 PIPES = 2          # bench.py's default: launches per step
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the measured evidence of the current build on the MI355X box (run through gpurun); outputs land in
 # gpurun_out/$TAG/ and are copied into profiles/ (named per round) afterwards (tools/collect_profiles.py).
-#   gpurun --timeout 1500 -- 'TAG=r04 bash tools/refresh_profiles.sh'
+#   gpurun --timeout 2400 -- 'TAG=r05 bash tools/refresh_profiles.sh'      (HELDOUT=0 skips the four-minute IDQN trainings)
 set -u
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-final}
@@ -19,7 +19,8 @@ rm -f $OUT/pipes_ab.jsonl $OUT/idqn_rollout.jsonl
 python tools/pipes_ab.py --no-rollout --out $OUT/pipes_ab.jsonl > /dev/null 2>&1
 python tools/pipes_ab.py --rollout-only --out $OUT/idqn_rollout.jsonl > /dev/null 2>&1
 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "test_reference_result_bands or test_reference_result_known_gaps" -s 2>&1 | grep -o "band .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/reference_bands.txt
-python -m pytest tests/test_gpu_heldout.py -m gpu -q -s 2>&1 | grep -o "heldout .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/heldout_idqn.txt
+python -m pytest tests/test_gpu_parity.py -m gpu -q -k "test_tls_expiry_evidence" -s 2>&1 | grep -o "expiry .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/tls_expiry_bands.txt
+[ "${HELDOUT:-1}" = 1 ] && python -m pytest tests/test_gpu_heldout.py -m gpu -q -s 2>&1 | grep -o "heldout .*\|[0-9]* passed.*\|[0-9]* failed.*" > $OUT/heldout_idqn.txt
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the contract line (default --steps / --warmup), CPU baseline off: per-kernel time by rocprofv3
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
