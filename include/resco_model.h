@@ -6,7 +6,7 @@
  * Everything tagged [SUMO-K] restates SUMO behaviour from general knowledge of its published model; SUMO itself is not
  * available here, so these values are PARITY-UNPINNED against SUMO and calibrated against the delay figures the
  * reference publishes (resco_benchmark/utils/avg_timeLoss.py), see DESIGN.md section 2.  Every constant can be overridden on the
- * compiler command line (-DRM_...=...): that is how oracle/study/calibrate2.py searches them; the shipped values are the defaults.
+ * compiler command line (-DRM_...=...): that is how the coordinate search of round 3 varied them; the shipped values are the defaults.
  */
 #ifndef RESCO_MODEL_H
 #define RESCO_MODEL_H
