@@ -43,6 +43,34 @@ def test_struct_layout_matches_header():
     assert [f[0] for f in ScenarioStruct._fields_] == names
 
 
+def _struct_fields(text, name):
+    body = text[text.index('typedef struct %s {' % name) + len('typedef struct %s {' % name):text.index('} %s;' % name)]
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r'^(const\s+)?(int32_t|uint32_t|float|rs_policy_handle)\s*', '', decl)
+        names += [n.strip().lstrip('*') for n in decl.split(',')]
+    return names
+
+
+def test_params_and_group_agent_layouts_match_header():
+    """rs_params (incl. tls_expiry, round 5) and rs_group_agent: the ctypes mirrors list the header's fields in header order, with
+    4-byte scalars and one pointer"""
+    with open(os.path.join(ROOT, 'include', 'resco_sim.h')) as f:
+        text = f.read()
+    from resco_amd._abi import ParamsStruct
+    assert [f[0] for f in ParamsStruct._fields_] == _struct_fields(text, 'rs_params')
+    assert C.sizeof(ParamsStruct) == 4 * len(ParamsStruct._fields_)
+    assert [f[0] for f in rsim.GroupAgent._fields_] == _struct_fields(text, 'rs_group_agent')
+    assert C.sizeof(rsim.GroupAgent) == 8 + 8 + 4 * 4      # kind, step_key | policy pointer | mode, epsilon, epsilon_step, seed
+    enum = re.search(r'enum rs_agent \{(.*?)\}', text, flags=re.S).group(1)
+    vals = {k.strip(): int(v) for k, v in (item.split('=') for item in enum.split(','))}
+    assert {k[len('RS_AGENT_'):].lower(): v for k, v in vals.items()} == rsim.AGENT
+
+
 def test_no_silent_cpu_fallback():
     import torch
     if torch.cuda.is_available():
