@@ -828,7 +828,7 @@ extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, 
                            const void *dyn, int32_t *actions, float *q, void *stream) {
     if (!p || !obs || !actions || n_envs <= 0 || mode < 0 || mode > 1) return RS_EINVAL;
     if (hipSetDevice(p->device) != hipSuccess) return RS_EHIP;
-    hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(256), 0, (hipStream_t)stream,
                        p->W, (const __half *)obs, (int)n_envs, 0, (int)mode, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_EHIP;
 }
@@ -865,7 +865,7 @@ extern "C" int rs_group_step(const rs_handle *hs, int32_t n_handles, const rs_gr
             else if (kind == RS_AGENT_IDQN) {
                 float eps = agent->epsilon + (float)k * agent->epsilon_step;
                 if (eps < 0.0f) eps = 0.0f;
-                hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((h->n_envs + POL_TM - 1) / POL_TM, h->K.n_signals), dim3(128), 0, st,
+                hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((h->n_envs + POL_TM - 1) / POL_TM, h->K.n_signals), dim3(256), 0, st,
                                    agent->policy->W, (const __half *)h->O.drq_f16(), (int)h->n_envs, (int)h->P.env_base, (int)agent->mode, eps,
                                    agent->seed, agent->step_key + (uint32_t)k, (const uint32_t *)nullptr, h->actions, (float *)nullptr);
             }

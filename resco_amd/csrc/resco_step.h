@@ -844,7 +844,8 @@ template <bool LONG> RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_
         Aux na = ax; na.lane = LANE_NONE; na.swait = 0;
         L.aux[s] = na;
         L.node[s].trip = TRIP_NONE; L.node[s].fl = (uint8_t)(me.fl & fl_mh(t));
-        G.coop(0)[eo + s] = COOP_NONE; G.coop(1)[eo + s] = COOP_NONE; G.cooplead(0)[eo + s] = COOP_NONE; G.cooplead(1)[eo + s] = COOP_NONE;
+        // (the mailboxes of a free slot may keep a request nobody read: no request is addressed to a free slot, and the insertion
+        //  empties all four -- four scattered stores per arrival less)
         rs_atomic_and(&L.alive[s >> 5], ~(1u << (s & 31)));
         {   // Signal.departures of the signal that observed the vehicle last (traffic_signal.py:226-232)
             const int ow = G.owner()[eo + s];
