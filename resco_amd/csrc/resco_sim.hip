@@ -484,6 +484,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     {
         StepArgs sa{h->K, h->G, h->O, Lds{}};
         lds_carve(&sa.L, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
+        if (!lds_fix_matches(sa.L, C)) { h->err = "the layout of the working memory does not match the kernel's literals (lds_carve / LdsFix)"; return fail(RS_EINVAL); }
         sa.L.cell_inv = PT.cell_inv;
         if ((rc = dev_alloc(h, &h->args, 1, false))) return fail(rc);
         if (hipMemcpy(h->args, &sa, sizeof(sa), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy(StepArgs) failed"; return fail(RS_EHIP); }

@@ -222,44 +222,112 @@ struct Lds {
 #endif
 
 RS_CARVE size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-// Layout of the working memory: a table of offsets computed once by the host (read from the constant argument block, so an
-// offset costs a scalar load where it is used and no register in between).  The per-lane aggregates of the observe phase
-// live where vnx was (dead by then).
+// entries of a work list for capacity C
+RS_CARVE int lds_list_cap(int C) {
+#ifdef RS_LIST_CAP                  // (tests: lists so short that they overflow all the time)
+    (void)C;
+    return RS_LIST_CAP;
+#else
+    return ((C / 4 + 63) / 64) * 64;
+#endif
+}
+// Layout of the working memory: a table of offsets computed once by the host.  The arrays whose SIZE follows from the slot capacity
+// alone come first, so that their OFFSETS do too: a kernel instantiated for a capacity addresses them with literals (LdsFix below)
+// instead of a scalar load from the constant argument block per use -- +2 % when every offset is a literal
+// (profiles/r05_ab_const_layout.txt).  The others are read from the table where they are used (an offset costs a scalar load there
+// and no register in between).  The per-lane aggregates of the observe phase live where vnx was (dead by then) when they fit.
 RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
 #define CARVE(field, bytes) { if (L) L->field.off = (uint32_t)o; o += align16(bytes); }
-    CARVE(node, (size_t)C * 16) CARVE(aux, (size_t)C * 8)
-    {
-        const size_t ab = align16((size_t)n_obs * 4), a = (size_t)C * 4, b = 6 * ab;
-        if (L) {
-            const uint32_t p = (uint32_t)o;
-            L->vnx.off = p;
-            L->agg_q.off = p; L->agg_a.off = p + (uint32_t)ab; L->agg_w.off = p + (uint32_t)(2 * ab);
-            L->agg_m.off = p + (uint32_t)(3 * ab); L->agg_s.off = p + (uint32_t)(4 * ab); L->agg_n.off = p + (uint32_t)(5 * ab);
-        }
-        o += align16(a > b ? a : b);
-    }
+    // ---- sizes that follow from C (LdsFix<C> restates these offsets; lds_fix_matches() compares)
+    CARVE(node, (size_t)C * 16) CARVE(aux, (size_t)C * 8) CARVE(vnx, (size_t)C * 4)
     CARVE(sc, (size_t)(SC_STATS + ST_N) * 4)
     CARVE(alive, (size_t)((C + 31) / 32) * 4) CARVE(alive0, (size_t)((C + 31) / 32) * 4)
+    {
+        const int cap = lds_list_cap(C);
+        if (L) L->lcap = (uint32_t)cap;
+        CARVE(ls_h, (size_t)cap * 2) CARVE(ls_lc, (size_t)cap * 2) CARVE(ls_mh, (size_t)cap * 2)
+    }
+    // ---- the first array of scenario-dependent size still starts at a known place
+    if (L) L->gstride = (uint32_t)((n_cells + 8 + 7) & ~7);
+    CARVE(grid, (size_t)((n_cells + 8 + 7) & ~7) * 2 * 2)
+    // ---- scenario-dependent
     CARVE(insm, (size_t)((n_dep + 31) / 32) * 4)
     CARVE(vtp, (size_t)n_vt * VT_COLS * 4)
     CARVE(phase, (size_t)S * 4) CARVE(left, (size_t)S * 4) CARVE(nextp, (size_t)S * 4)
     CARVE(sig_arr, (size_t)S * 4) CARVE(sig_dep, (size_t)S * 4)
     CARVE(tstate, (size_t)S * tls_maxl)
-    if (L) L->gstride = (uint32_t)((n_cells + 8 + 7) & ~7);
-    CARVE(grid, (size_t)((n_cells + 8 + 7) & ~7) * 2 * 2)
     CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2) CARVE(dep_t, (size_t)n_dep * 2)
     {
-#ifdef RS_LIST_CAP                  // (tests: lists so short that they overflow all the time)
-        const int cap = RS_LIST_CAP;
-#else
-        const int cap = ((C / 4 + 63) / 64) * 64;
-#endif
-        if (L) L->lcap = (uint32_t)cap;
-        CARVE(ls_h, (size_t)cap * 2) CARVE(ls_lc, (size_t)cap * 2) CARVE(ls_mh, (size_t)cap * 2)
+        const size_t ab = align16((size_t)n_obs * 4);
+        uint32_t p = L ? L->vnx.off : 0u;
+        if (6 * ab > align16((size_t)C * 4)) { p = (uint32_t)o; o += 6 * ab; }       // (more observed lanes than the slots' next speeds leave room for)
+        if (L) {
+            L->agg_q.off = p; L->agg_a.off = p + (uint32_t)ab; L->agg_w.off = p + (uint32_t)(2 * ab);
+            L->agg_m.off = p + (uint32_t)(3 * ab); L->agg_s.off = p + (uint32_t)(4 * ab); L->agg_n.off = p + (uint32_t)(5 * ab);
+        }
     }
 #undef CARVE
     return o;
+}
+
+// The same working memory seen by a kernel that knows the capacity C at compile time: literals for the offsets that follow from C,
+// references into the host's table (constant argument block) for the rest.  The phases are written against `L.<array>[i]` and take
+// either this view or the table itself (capacity only known at run time).
+template <class Tp, uint32_t OFF> struct CPtr {
+    RS_MEM Tp &operator[](int i) const { return ((Tp *)(RS_SMEM + OFF))[i]; }
+    RS_MEM operator Tp *() const { return (Tp *)(RS_SMEM + OFF); }
+};
+template <int C> struct LdsFix {
+    static constexpr uint32_t a16(uint32_t x) { return (x + 15u) & ~15u; }
+#ifdef RS_LIST_CAP
+    static constexpr uint32_t kcap = RS_LIST_CAP;
+#else
+    static constexpr uint32_t kcap = ((C / 4 + 63) / 64) * 64;
+#endif
+    static constexpr uint32_t o_node = 0, o_aux = o_node + a16(C * 16), o_vnx = o_aux + a16(C * 8), o_sc = o_vnx + a16(C * 4),
+                              o_alive = o_sc + a16((SC_STATS + ST_N) * 4), o_alive0 = o_alive + a16(((C + 31) / 32) * 4),
+                              o_ls_h = o_alive0 + a16(((C + 31) / 32) * 4), o_ls_lc = o_ls_h + a16(kcap * 2), o_ls_mh = o_ls_lc + a16(kcap * 2),
+                              o_grid = o_ls_mh + a16(kcap * 2);
+    CPtr<Node, o_node> node;
+    CPtr<Aux, o_aux> aux;
+    CPtr<float, o_vnx> vnx;
+    CPtr<int32_t, o_sc> sc;
+    CPtr<uint32_t, o_alive> alive;
+    CPtr<uint32_t, o_alive0> alive0;
+    CPtr<uint16_t, o_ls_h> ls_h;
+    CPtr<uint16_t, o_ls_lc> ls_lc;
+    CPtr<uint16_t, o_ls_mh> ls_mh;
+    CPtr<uint16_t, o_grid> grid;
+    static constexpr uint32_t lcap = kcap;
+    const LPtr<float> &vtp;
+    const uint32_t &gstride;
+    const LPtr<int32_t> &arr;
+    const LPtr<uint16_t> &dep, &dep_t;
+    const LPtr<uint32_t> &insm;
+    const LPtr<int32_t> &agg_q, &agg_a, &agg_w, &agg_m, &agg_n;
+    const LPtr<uint32_t> &agg_s;
+    const LPtr<int32_t> &sig_arr, &sig_dep, &phase, &left, &nextp;
+    const LPtr<uint8_t> &tstate;
+    const float &cell_inv;
+    RS_MEM explicit LdsFix(const Lds &T)
+        : vtp(T.vtp), gstride(T.gstride), arr(T.arr), dep(T.dep), dep_t(T.dep_t), insm(T.insm), agg_q(T.agg_q), agg_a(T.agg_a), agg_w(T.agg_w),
+          agg_m(T.agg_m), agg_n(T.agg_n), agg_s(T.agg_s), sig_arr(T.sig_arr), sig_dep(T.sig_dep), phase(T.phase), left(T.left), nextp(T.nextp),
+          tstate(T.tstate), cell_inv(T.cell_inv) {}
+    // does the host's table put the arrays where this view expects them?  (rs_create checks it: a mismatch is a build error)
+    static RS_HD bool matches(const Lds &T) {
+        return T.node.off == o_node && T.aux.off == o_aux && T.vnx.off == o_vnx && T.sc.off == o_sc && T.alive.off == o_alive && T.alive0.off == o_alive0 &&
+               T.ls_h.off == o_ls_h && T.ls_lc.off == o_ls_lc && T.ls_mh.off == o_ls_mh && T.grid.off == o_grid && T.lcap == kcap;
+    }
+};
+RS_CARVE bool lds_fix_matches(const Lds &T, int C) {
+    switch (C) {
+        case 128: return LdsFix<128>::matches(T);
+        case 256: return LdsFix<256>::matches(T);
+        case 512: return LdsFix<512>::matches(T);
+        case 1024: return LdsFix<1024>::matches(T);
+        default: return true;           // (the kernel of a run-time capacity reads every offset from the table)
+    }
 }
 
 // The grid cell length of a scenario: the shortest of CELL_CHOICES with which the working memory of an environment still lets three
@@ -287,8 +355,8 @@ RS_CARVE float pick_cell_len(const rs_scenario *sc, int n_arr, int n_dep, int tl
 #define RS_SEC(id) {}
 #endif
 RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
-RS_DEV int lane_cells(const Lds &L, const LaneRec &LR) { return (int)(LR.len * L.cell_inv) + 1; }
-RS_DEV int cell_of(const Lds &L, float pos, int ncell) { const int c = (int)(pos * L.cell_inv); return c < ncell ? c : ncell - 1; }
+template <class LT> RS_DEV int lane_cells(const LT &L, const LaneRec &LR) { return (int)(LR.len * L.cell_inv) + 1; }
+template <class LT> RS_DEV int cell_of(const LT &L, float pos, int ncell) { const int c = (int)(pos * L.cell_inv); return c < ncell ? c : ncell - 1; }
 
 // push slot s into cell c; returns the previous head (the new chain link).  16-bit cells, exchanged with a CAS on the
 // containing dword (LDS has no 16-bit atomics); the cell's vehicle count goes up by one
@@ -362,7 +430,7 @@ RS_DEV bool cells_have_mover(const uint16_t *grid, int c0, int nc) {
     return false;
 }
 // rear-most vehicle of a cell chain (min pos, ties -> larger trip)
-RS_DEV int chain_rearmost(const Lds &L, int head) {
+template <class LT> RS_DEV int chain_rearmost(const LT &L, int head) {
     int best = NIL, bk = 0;
     float bp = 0.0f;
     for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
@@ -373,7 +441,7 @@ RS_DEV int chain_rearmost(const Lds &L, int head) {
     return best;
 }
 // front-most vehicle of a cell chain (max pos, ties -> smaller trip)
-RS_DEV int chain_frontmost(const Lds &L, int head) {
+template <class LT> RS_DEV int chain_frontmost(const LT &L, int head) {
     int best = NIL, bk = 0;
     float bp = 0.0f;
     for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
@@ -384,7 +452,7 @@ RS_DEV int chain_frontmost(const Lds &L, int head) {
     return best;
 }
 // rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
-RS_DEV int rearmost_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float win) {
+template <class LT> RS_DEV int rearmost_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float win) {
     if (win < 0.0f) return NIL;
     const int c = scan_up(grid, cell0, cell0 + cell_of(L, win, ncell));
     if (c < 0) return NIL;
@@ -392,7 +460,7 @@ RS_DEV int rearmost_within(const Lds &L, const uint16_t *grid, int cell0, int nc
     return (o != NIL && L.node[o].pos > win) ? NIL : o;
 }
 // nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front)
-RS_DEV int leader_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
+template <class LT> RS_DEV int leader_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(L, pos, ncell);
     int Ld = NIL, Lk = 0;
     float Lp = 0.0f;
@@ -411,7 +479,7 @@ RS_DEV int leader_within(const Lds &L, const uint16_t *grid, int cell0, int ncel
     return Ld;
 }
 // nearest vehicle behind (pos, k) on the lane (not `self`), at most `win` metres away
-RS_DEV int follower_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
+template <class LT> RS_DEV int follower_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(L, pos, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
@@ -431,7 +499,7 @@ RS_DEV int follower_within(const Lds &L, const uint16_t *grid, int cell0, int nc
     return Fd;
 }
 // nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
-RS_DEV int at_or_behind_within(const Lds &L, const uint16_t *grid, int cell0, int ncell, float back, float win) {
+template <class LT> RS_DEV int at_or_behind_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float back, float win) {
     if (back < 0.0f) return NIL;
     const int c = cell_of(L, back, ncell);
     int Fd = NIL, Fk = 0;
@@ -451,7 +519,7 @@ RS_DEV int at_or_behind_within(const Lds &L, const uint16_t *grid, int cell0, in
 }
 
 // ------------------------------------------------------------------------------------------------ model helpers
-RS_DEV int tls_state(const KTab &T, const Lds &L, int tls, int pos) {
+template <class LT> RS_DEV int tls_state(const KTab &T, const LT &L, int tls, int pos) {
     if (tls == 0xFF) return TLS_G;
     return L.tstate[tls * T.tls_maxl + pos];
 }
@@ -462,7 +530,7 @@ RS_DEV uint16_t cache_link(const KTab &T, const LaneRec &LR, int lane, int rq, i
     if (LR.flags & LF_INTERNAL) { const int l = LR.link_start; return (uint16_t)(l | (T.links()[l].arr_idx >= 0 ? NLINK_ARR : 0)); }
     return T.next_link()[((size_t)rq * T.kmax + (lane - (int)LR.edge_lane0)) * 2 + (trip & 1)];
 }
-RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const uint16_t *grid, const LinkRec &K) {
+template <class LT> RS_DEV bool foe_blocked(const KTab &T, const LT &L, const uint16_t *grid, const LinkRec &K) {
     for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
         const FoeRec F = T.foes()[i];
         if (F.tls != 0xFF && tls_state(T, L, F.tls, F.tls_pos) == TLS_R) continue;
@@ -473,7 +541,7 @@ RS_DEV bool foe_blocked(const KTab &T, const Lds &L, const uint16_t *grid, const
     return false;
 }
 // copy the link states of signal s in phase ph into the working memory (called by the thread that owns the signal)
-RS_DEV void tls_refresh(const KTab &T, const Lds &L, const KParams &P, int s, int ph) {
+template <class LT> RS_DEV void tls_refresh(const KTab &T, const LT &L, const KParams &P, int s, int ph) {
     // rows of the state tables are tls_maxl bytes (a multiple of 4, zero padded) and 4-byte aligned: the row is copied with
     // independent 32-bit loads (up to 8 of them in flight) -- all signals change phase in the same ticks, and this copy is on the
     // critical path of those ticks' C phase
@@ -488,7 +556,7 @@ RS_DEV void tls_refresh(const KTab &T, const Lds &L, const KParams &P, int s, in
 #pragma unroll 1
     for (int i = 8; i < w; ++i) dst[i] = src[i];
 }
-RS_DEV void set_phase(const KTab &T, const Lds &L, const KParams &P, int s, int ph) {
+template <class LT> RS_DEV void set_phase(const KTab &T, const LT &L, const KParams &P, int s, int ph) {
     if (ph < 0 || ph >= T.cold.tls_nphase[s]) return;
     L.phase[s] = ph;
     L.left[s] = P.tls_expiry ? T.cold.tls_dur[T.cold.tls_dur_off[s] + ph] : RM_TLS_HOLD_TICKS;      // rs_params.tls_expiry
@@ -496,7 +564,7 @@ RS_DEV void set_phase(const KTab &T, const Lds &L, const KParams &P, int s, int 
 }
 // TLS switch events at the beginning of tick `tick` of this launch, preceded by Signal.set_phase when the yellow
 // ticks are over
-RS_DEV void tls_begin_of_tick(const KTab &T, const Lds &L, const KParams &P, int s, int tick) {
+template <class LT> RS_DEV void tls_begin_of_tick(const KTab &T, const LT &L, const KParams &P, int s, int tick) {
     if (P.do_fsm && !P.fixed_program && tick == T.yellow_length) set_phase(T, L, P, s, L.nextp[s]);
     int left = L.left[s];
     if (left == 0) {
@@ -551,7 +619,7 @@ RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int 
 // its arrival time there (v, pos, vType, lane length and next link of the vehicle AFTER this tick's move)
 // (the three fields of the link the registration needs are one dword of its record: arr_idx | tls << 16 | tls_pos << 24)
 RS_DEV uint32_t link_reg_word(const KTab &T, int nlk) { return ((const uint32_t *)&T.links()[nlk & 0x7FFF])[2]; }
-RS_DEV void register_approach_w(const KTab &T, const Lds &L, uint32_t kw, float v, float pos, float lane_len, int vt) {
+template <class LT> RS_DEV void register_approach_w(const KTab &T, const LT &L, uint32_t kw, float v, float pos, float lane_len, int vt) {
     const int st = tls_state(T, L, (int)((kw >> 16) & 0xFFu), (int)(kw >> 24));
     if (st == TLS_R) return;
     const float dist = lane_len - pos;
@@ -560,14 +628,14 @@ RS_DEV void register_approach_w(const KTab &T, const Lds &L, uint32_t kw, float 
     const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
     rs_atomic_min(&L.arr[(int16_t)(kw & 0xFFFFu)], q);
 }
-RS_DEV void register_approach(const KTab &T, const Lds &L, int nlk, float v, float pos, float lane_len, int vt) {
+template <class LT> RS_DEV void register_approach(const KTab &T, const LT &L, int nlk, float v, float pos, float lane_len, int vt) {
     if (!(nlk & NLINK_ARR)) return;         // nobody yields to my next link (or I have none)
     if (v <= RM_HALT_SPEED) return;
     register_approach_w(T, L, link_reg_word(T, nlk), v, pos, lane_len, vt);
 }
 // follow `X` (a vehicle on a neighbouring lane of my edge) as if it were my leader, braking no harder than comfortably:
 // the cooperative part of the lane changing (oracle: plan(), coop / coop_lead).  key = trip << 16 | slot.
-RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool clamp_gap, const LaneRec &LR, int lane, float x, float v,
+template <class LT> RS_DEV void follow_neighbour(const KTab &T, const LT &L, uint32_t key, bool clamp_gap, const LaneRec &LR, int lane, float x, float v,
                              float b, float tau, float mingap, float &vsafe) {
     const int X = (int)(key & 0xFFFFu), kx = (int)(key >> 16);
     if ((int)L.node[X].trip != kx) return;
@@ -589,14 +657,14 @@ RS_DEV void follow_neighbour(const KTab &T, const Lds &L, uint32_t key, bool cla
 
 // mark slot s as one whose move of tick t is a long one and queue it (the plan's thread and the lane-change thread of a
 // vehicle may both do it, at the same time: an atomic OR on the dword that holds Node.fl decides who queues it)
-RS_DEV void list_push(const Lds &L, const LPtr<uint16_t> &list, int counter, int s);
-RS_DEV void flag_mover(const Lds &L, int s, int t, int lct = 0) {
+template <class LT, class LP> RS_DEV void list_push(const LT &L, const LP &list, int counter, int s);
+template <class LT> RS_DEV void flag_mover(const LT &L, int s, int t, int lct = 0) {
     uint32_t *w = (uint32_t *)((Node *)L.node + s) + 3;
     const uint32_t bit = (uint32_t)fl_mh(t) << 8;
     if (!(rs_atomic_fetch_or(w, bit | ((uint32_t)lct << 8)) & bit)) list_push(L, L.ls_mh, SC_NMH + (t & 1), s);
 }
 // queue slot s in a work list (best effort: the flag in Node.fl is what counts, see the phases)
-RS_DEV void list_push(const Lds &L, const LPtr<uint16_t> &list, int counter, int s) {
+template <class LT, class LP> RS_DEV void list_push(const LT &L, const LP &list, int counter, int s) {
     const int i = rs_wave_ticket(&L.sc[counter]);
     if (i < (int)L.lcap) list[i] = (uint16_t)s;
 }
@@ -632,7 +700,7 @@ RS_DEV bool may_change_lanes(const ContRow &R, const LaneRec &LR, int lane, int 
     return tk >= 0 && tk < n && strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem, OCC_NONE, 0, 0, 0.0f) == 0;
 }
 // The work of tick t for the vehicle in slot s (state as of the beginning of that tick): its flags, and it is queued
-RS_DEV int classify(const Lds &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, const ContRow &R, int k, float sf, int t) {
+template <class LT> RS_DEV int classify(const LT &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, const ContRow &R, int k, float sf, int t) {
     int fl = 0;
     if (looks_beyond(vt, v, x, LR.len, LR.vmax, sf)) { fl |= FL_H; list_push(L, L.ls_h, SC_NH, s); }
     if (may_change_lanes(R, LR, lane, k, x, v, t)) { fl |= FL_LC; list_push(L, L.ls_lc, SC_NLC, s); }
@@ -643,7 +711,7 @@ RS_DEV int classify(const Lds &L, int s, const float *vt, float v, float x, cons
 // P: plan (Krauss car-following + links) for slot s.  LONG = false: the short path, for a vehicle WITHOUT FL_H -- nothing beyond
 // the end of its lane is inside its look-ahead (classify() decided that on the very state this plan sees; the host emulation
 // checks it) --, so the walk over the links is not compiled into what the waves on the short path run.
-template <bool LONG> RS_DEV void phase_plan(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
+template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L, const uint16_t *grid, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
     RS_SEC_BEGIN
     const Aux ax = L.aux[s];
     const int lane = ax.lane;
@@ -769,7 +837,7 @@ template <bool LONG> RS_DEV void phase_plan(const KTab &T, const Lds &L, const u
 
 // M: move slot s -- sideways first (the lane change decided in the plan phase), then forward, over to the next lanes, or
 // out of the network; leave the old grid, enter the new one; register the approach of the coming tick
-template <bool LONG> RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_t *gold, uint16_t *gnew, const State &G, const KParams &P, int env, size_t eo,
+template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L, uint16_t *gold, uint16_t *gnew, const State &G, const KParams &P, int env, size_t eo,
                        int t, bool last_tick, bool more, int s, int &active, int &halted, int &top) {
     const Aux ax = L.aux[s];
     const Node me = L.node[s];
@@ -882,7 +950,7 @@ template <bool LONG> RS_DEV void phase_move(const KTab &T, const Lds &L, uint16_
 
 // the vehicle on the lane with cells [cell0, cell0 + ncell) whose body overlaps the one at (pos, k) lengthwise (the nearer one
 // ahead first), NIL: none
-RS_DEV int overlapping(const Lds &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float len_self) {
+template <class LT> RS_DEV int overlapping(const LT &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float len_self) {
     const int lead = leader_within(L, grid, cell0, ncell, pos, k, self, RM_NB_WINDOW);
     if (lead != NIL && L.node[lead].pos - L.vtp[L.node[lead].vt * VT_COLS + VT_LENGTH] - pos < 0.0f) return lead;
     const int foll = follower_within(L, grid, cell0, ncell, pos, k, self, RM_NB_WINDOW);
@@ -892,7 +960,7 @@ RS_DEV int overlapping(const Lds &L, const uint16_t *grid, int cell0, int ncell,
 
 // The lane-change decision of slot s on the state at the beginning of the tick: returns LCT_* (0: stay).  A blocked strategic
 // changer asks for cooperation; a mutual block is swapped out (oracle: lane_change())
-RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, const State &G, size_t eo, int t, int s, const Aux &ax, const Node &me) {
+template <class LT> RS_DEV int phase_lc_decide(const KTab &T, const LT &L, const uint16_t *grid, const State &G, size_t eo, int t, int s, const Aux &ax, const Node &me) {
     const int lane = ax.lane;
     // (everything the decision may need from global memory is requested at once)
     const LaneRec LR = T.lanes()[lane];
@@ -988,7 +1056,7 @@ RS_DEV int phase_lc_decide(const KTab &T, const Lds &L, const uint16_t *grid, co
 
 // C: does the oldest waiting trip of departure lane d get onto the network in tick t?  The space on its lane is judged
 // AFTER this tick's move of the vehicles that are on it now -- their next speeds are known (oracle: insertion_check)
-RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, const uint16_t *grid, int t, int d) {
+template <class LT> RS_DEV bool phase_insert_decide(const KTab &T, const LT &L, const uint16_t *grid, int t, int d) {
     if ((int)L.dep_t[d] > t) return false;           // nothing due on this lane (the common case: no global access)
     const int k = L.dep[d];
     // (one 8-byte record per departure lane instead of lane id -> lane record: the two loads of this check are independent)
@@ -1009,7 +1077,7 @@ RS_DEV bool phase_insert_decide(const KTab &T, const Lds &L, const uint16_t *gri
 }
 
 // the r-th (0-based) free slot in ascending order, -1: none
-RS_DEV int nth_free_slot(const Lds &L, int C, int r) {      // (in the occupancy snapshot of the beginning of the tick)
+template <class LT> RS_DEV int nth_free_slot(const LT &L, int C, int r) {      // (in the occupancy snapshot of the beginning of the tick)
 #pragma unroll 1
     for (int w = 0; w < (C + 31) / 32; ++w) {
         uint32_t fr = ~L.alive0[w];
@@ -1025,9 +1093,9 @@ RS_DEV int nth_free_slot(const Lds &L, int C, int r) {      // (in the occupancy
 
 // ------------------------------------------------------------------------------------------------ the step
 // CAP: the slot capacity as a compile-time constant (0: read it from the tables at run time)
-template <int CAP, class Exec>
-RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, const Out &O, const KParams &P,
-                         const int32_t *actions, int env) {
+template <int CAP, class Exec, class LT>
+RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G, const Out &O, const KParams &P,
+                            const int32_t *actions, int env) {
     const int B = ex.B;
     const int C = CAP ? CAP : T.capacity, S = T.n_signals, NO = T.n_obs;
     const int genv = P.env_base + env;
@@ -1414,4 +1482,14 @@ RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, 
             } else st[tid] += L.sc[SC_STATS + tid];
         }
     });
+}
+
+// the step for a capacity known at compile time (CAP: the offsets that follow from it are literals) or at run time (CAP = 0)
+template <int CAP, class Exec>
+RS_DEV void rs_step_body(Exec &ex, const Lds &L, const KTab &T, const State &G, const Out &O, const KParams &P,
+                         const int32_t *actions, int env) {
+    if constexpr (CAP != 0) {
+        const LdsFix<CAP> Lf(L);
+        rs_step_body_on<CAP>(ex, Lf, T, G, O, P, actions, env);
+    } else rs_step_body_on<CAP>(ex, L, T, G, O, P, actions, env);
 }

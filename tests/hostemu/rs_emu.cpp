@@ -202,6 +202,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->G.trip_log = nullptr;
     if (p->trip_log) { h->trip_log.assign(N * (size_t)sc->n_trips * 4, 0); h->G.trip_log = h->trip_log.data(); }
     h->lds = lds_carve(&h->L, C, K.n_cells, K.n_arr, K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, K.tls_maxl);
+    if (!lds_fix_matches(h->L, C)) { g_err = "the layout of the working memory does not match the kernel's literals (lds_carve / LdsFix)"; delete h; return RS_EINVAL; }
     h->L.cell_inv = h->PT.cell_inv;
     h->smem.assign(h->lds + 64, 0);
     State &G = h->G; Out &O = h->O;
