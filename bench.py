@@ -311,6 +311,21 @@ def _cpu_worker(job):
     return steps
 
 
+def launch_ranks(n):
+    """re-exec as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>`"""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # RCCL on this pool: dmabuf IPC only
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -325,12 +340,26 @@ def main():
     ap.add_argument('--digest', action='store_true', help='add a digest of the final per-environment state (all ranks, global env order)')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the contract's launch -- N ranks, one per GPU, through torch.distributed.run
+        # (the reference's only parallelism is a process per trial, main.py:40-44; here a process per GPU)
+        launch_ranks(args.gpus)         # does not return
     import torch
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        # a launcher / flag mismatch must never print a line that claims N GPUs while timing another number of them
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: start exactly --gpus ranks '
+                         '(python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d, or plain python bench.py --gpus %d)'
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    if 'RESCO_BENCH_DEVICE' not in os.environ and torch.cuda.device_count() < world:
+        raise SystemExit('bench.py: --gpus %d but only %d device(s) visible (RESCO_BENCH_DEVICE=<id> puts every rank on one device: a '
+                         'functional check, not a measurement)' % (world, torch.cuda.device_count()))
     # RESCO_BENCH_DEVICE / RESCO_BENCH_BACKEND: several ranks on ONE GPU with a gloo rendezvous -- how the N > 1 path is run
     # end to end where no multi-GPU node exists (tests/test_gpu_parity.py::test_two_ranks_through_bench_on_one_gpu)
     local = int(os.environ.get('RESCO_BENCH_DEVICE', local))
@@ -341,6 +370,10 @@ def main():
     if world > 1 or os.environ.get('RESCO_BENCH_FORCE_DIST') == '1':      # the env var exercises the RCCL path at N=1
         import torch.distributed as dist
         dist.init_process_group(backend, rank=rank, world_size=world)     # RCCL: barrier + one MAX only
+    # the world size the process group itself reports (None: single process, no group)
+    rccl_ranks = dist.get_world_size() if dist is not None else None
+    if rccl_ranks is not None and rccl_ranks != args.gpus:
+        raise SystemExit('bench.py: the process group has %d ranks, --gpus says %d' % (rccl_ranks, args.gpus))
 
     from resco_amd.scenario import Scenario
     from resco_amd.sim import BatchedSim
@@ -350,7 +383,7 @@ def main():
         raise SystemExit('--envs must be a multiple of --pipes')
     per = n_local // args.pipes
     sims = [BatchedSim(sc, per, device=local, seed=args.seed, sigma=-1.0, speed_dev=1, env_base=env_base + i * per,
-                       block_threads=args.block) for i in range(args.pipes)]
+                       block_threads=args.block, device_envs=n_local) for i in range(args.pipes)]
     sim = sims[0]
     # BASELINE config 3 / SURVEY 8(d): "state fns computed every step: lane aggregates -> drq_norm + mplight; rewards wait +
     # pressure" -- only what those consume is written (the per-signal rewards and metrics always are)
@@ -393,7 +426,7 @@ def main():
     w0 = window_start(args.steps, args.warmup)
     traffic, traffic_note = pmc_traffic(args, n_local, world)
     out = {
-        'metric': 'env-steps/sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'metric': 'env-steps/sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s x %d lock-step envs per GPU (BASELINE config 3), fixed demand from the map\'s '

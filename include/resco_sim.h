@@ -103,19 +103,31 @@ typedef struct rs_sim *rs_handle;
 /* env_base: global index of this handle's first environment (keys the counter-based RNG so that a batch
  * sharded over several GPUs reproduces the single-GPU batch).
  * block_threads selects the workgroup shape and the register budget of the step kernel:
- *    0            default: one thread per TWO vehicle slots (capacity / 2, a multiple of 64, at most 512) with the 80-VGPR
- *                 build -- three 512-thread workgroups per CU for a 1024-slot scenario;
+ *    0            default = rs_default_block(capacity, n_envs, device_id): one thread per TWO vehicle slots (capacity / 2, a
+ *                 multiple of 64, at most 512) with the 80-VGPR build -- three 512-thread workgroups per CU for a 1024-slot
+ *                 scenario --, and MORE waves per environment (up to capacity / 64 + 1) while the device's resident-wave budget
+ *                 still holds all n_envs environments at once (small batches: BASELINE configs 2 and 4);
  *    n > 0        n threads (a multiple of 64, <= 1024) with the 64-VGPR build;
  *    -n, n <= 512 n threads with the 128-VGPR build;
  *    -(10000 + n) n threads (<= 768) with the 80-VGPR build.
  * Results do not depend on the choice (tests/test_gpu_parity.py::test_block_sizes_and_register_budgets_bit_exact). */
 int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
               int32_t block_threads, rs_handle *out);
+/* The block_threads value (in the encoding above) that rs_create's default stands for when `n_envs_on_device` environments of a
+ * `capacity`-slot scenario share the GPU.  A caller that splits the environments of one GPU over several handles ("pipes") passes
+ * the TOTAL here and the result to every rs_create, so that the shape fits the device and not the share of one handle.
+ * 0: bad argument.  (Replaces nothing in the reference: its only sizing knob is the number of trial processes, main.py:40-44.) */
+int32_t rs_default_block(int32_t capacity, int32_t n_envs_on_device, int32_t device_id);
 void rs_destroy(rs_handle h);
 const char *rs_last_error(rs_handle h);     /* h may be NULL: error of the last failed rs_create on this thread */
 
 /* Start a new episode in every environment and run the first observe.
- * stream (here and below): a hipStream_t to launch on, or NULL for the handle's own non-blocking stream.  A
+ * stream (here and below): a hipStream_t to launch on, or NULL for the handle's own stream.  That stream owns a hardware queue
+ * (hipExtStreamCreateWithCUMask, all CUs enabled -- see DESIGN.md "pipes") and is therefore a BLOCKING stream in HIP's sense: it
+ * synchronises implicitly with the legacy NULL stream, which is PyTorch's default stream.  Learner kernels or synchronous hipMemcpy
+ * calls issued on the NULL stream serialise with every handle's launches: run agent / learner work that is meant to overlap on
+ * non-default streams (torch.cuda.Stream), or set RESCO_PLAIN_STREAMS=1 to get plain hipStreamNonBlocking streams (multiplexed
+ * over HIP's four hardware queues).  A
  * caller that works on the default (null) stream - e.g. PyTorch's default stream, whose handle is 0 - must pass
  * hipStreamLegacy ((hipStream_t)1), not 0, to be ordered with its own kernels.  The synchronous calls (rs_sync,
  * rs_read_buffer, rs_stats, rs_snapshot, rs_restore) wait for the handle's stream and for the stream of the most
@@ -182,7 +194,7 @@ enum rs_buffer {
     RS_BUF_VEH_OWNER,      /* u8  [N][C]  index of the signal that observed the vehicle last, 0xFF none */
     RS_BUF_STATS,          /* i64 [N][10] see rs_stats */
     RS_BUF_DRQ_NORM_F16,   /* f16 [N][S][Lmax][5] zero padded states.drq_norm (IDQN rollout layout) */
-    RS_BUF_VEH_SF,         /* f32 [N][C]  per-vehicle speedFactor */
+    RS_BUF_VEH_SF,         /* f32 [N][C]  per-vehicle speedFactor (written at the insertion; the kernel does not read it back) */
     RS_BUF_VEH_WTOT,       /* u16 [N][C]  total halted seconds of the trip so far (maintained only with trip_log) */
     RS_BUF_TRIP_LOG,       /* i32 [N][n_trips][4] depart tick, arrival tick (0: not arrived), timeLoss (1/1024 s), waiting (s);
                               [N][0][4] when trip_log is off */
@@ -220,7 +232,10 @@ int rs_timing(rs_handle h, int32_t enable);
 int rs_timing_read(rs_handle h, float *total_ms, int32_t *launches);   /* syncs; resets the accumulators */
 
 /* new RNG seed for subsequent launches (the reference restarts SUMO with --random every episode,
- * multi_signal.py:127); call between rs_reset()s */
+ * multi_signal.py:127).  Call it right before rs_reset(): a vehicle's speedFactor is a function of (seed, environment, trip) that
+ * the kernel RE-COMPUTES at every load instead of reading RS_BUF_VEH_SF back (that buffer is write-only: filled at the insertion
+ * for whoever reads it), so a new seed without a reset would change the speed factors of the vehicles already on the network.
+ * rs_snapshot stores the seed and rs_restore brings it back with the state. */
 int rs_set_seed(rs_handle h, uint32_t seed);
 
 /* in-kernel phase timers (development aid): enable, run steps, then read 16 accumulators of wall_clock64 ticks
@@ -240,7 +255,8 @@ int rs_phase_profile(rs_handle h, int32_t enable, uint64_t *host_out16);
  *   conv_w f32 [S][64][4], conv_b f32 [S][64], w1 f16 [S][64][hp][2][64][4], b1 f32 [S][64], w2 f16 [S][8][2][64][4],
  *   b2 f32 [S][64], w3 f16 [S][8][64][4], b3 f32 [S][32], n_actions i32 [S];  hp = ceil((lmax - 1) / 2), lmax <= 17.
  * rs_idqn_act: obs / actions (int32 [N][S]) / q (float [N][S][8] or NULL) are DEVICE pointers; mode 0: epsilon-greedy with
- * the counter hash over (seed; env, signal, step_key); mode 1: the outputs are logits and the action is drawn from
+ * the counter hash over (seed; env_base + env, signal, step_key) -- env_base = the global index of row 0, as in rs_create, so that
+ * the pipes of a split batch draw what the single batch draws and what rs_group_step draws; mode 1: the outputs are logits and the action is drawn from
  * softmax(logits) - the IPPO policy head on the same trunk (resco_benchmark/agents/pfrl_ppo.py:49-64, SoftmaxCategoricalHead); launched on `stream` (same convention as rs_step).  dyn: NULL, or a
  * device pointer to {float epsilon; uint32 step_key} that overrides the two scalar arguments - for replaying a captured
  * HIP graph of the whole env-step (policy kernel + rs_step) with values computed by an earlier node of the graph. */
@@ -248,7 +264,7 @@ typedef struct rs_policy *rs_policy_handle;
 int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax, const int32_t *n_actions, const float *conv_w,
                    const float *conv_b, const uint16_t *w1, const float *b1, const uint16_t *w2, const float *b2,
                    const uint16_t *w3, const float *b3, rs_policy_handle *out);
-int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, int32_t mode, float epsilon, uint32_t seed,
+int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, int32_t env_base, int32_t mode, float epsilon, uint32_t seed,
                 uint32_t step_key, const void *dyn, int32_t *actions, float *q, void *stream);
 /* Point the policy at caller-owned DEVICE copies of the packed weights (same layouts as rs_idqn_create; any pointer may
  * be NULL = keep the current one).  The buffers are borrowed: they must stay alive and are read by later rs_idqn_act

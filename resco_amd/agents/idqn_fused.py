@@ -67,7 +67,7 @@ class FusedIDQN:
         L = self._lib
         vp = C.c_void_p
         L.rs_idqn_create.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [vp] * 9 + [C.POINTER(vp)]
-        L.rs_idqn_act.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+        L.rs_idqn_act.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
         L.rs_idqn_destroy.argtypes = [vp]
         L.rs_idqn_destroy.restype = None
         self._h = None
@@ -152,13 +152,14 @@ class FusedIDQN:
         except Exception:
             pass
 
-    def act(self, obs, epsilon=0.0, step_key=0, want_q=False, stream=None, out=None, dyn=None, sample=False):
+    def act(self, obs, epsilon=0.0, step_key=0, want_q=False, stream=None, out=None, dyn=None, sample=False, env_base=0):
         """obs: fp16 CUDA tensor [N, S, lmax, 5] (the simulator's drq_norm_f16).  Returns int32 actions [N, S]
         (`out`, e.g. the simulator's own RS_BUF_ACTIONS tensor so that env.step(None) consumes them without a copy,
         or a tensor reused between calls) and, with want_q, the Q-values [N, S, 8] (-inf beyond a signal's actions).
         dyn: optional CUDA tensor of two 32-bit words {epsilon as float32 bits, step key} read by the kernel instead of
         the scalar arguments (for HIP-graph replay).  sample=True: treat the outputs as logits and draw the action
-        from softmax(logits) (IPPO policy head) instead of epsilon-greedy."""
+        from softmax(logits) (IPPO policy head) instead of epsilon-greedy.  env_base: global index of obs[0]'s environment (the
+        exploration draws are keyed by the global index: pass the pipe's env_base when a batch is split over handles)."""
         assert obs.is_cuda and obs.dtype == torch.float16 and obs.is_contiguous()
         N = obs.shape[0]
         assert tuple(obs.shape[1:]) == (self.S, self.lmax, 5)
@@ -171,7 +172,7 @@ class FusedIDQN:
             actions = self._actions[N]
         q = torch.empty(N, self.S, 8, dtype=torch.float32, device=obs.device) if want_q else None
         st = torch_stream(self.device) if stream is None else stream
-        rc = self._lib.rs_idqn_act(self._h, obs.data_ptr(), N, 1 if sample else 0, float(epsilon), self.seed, int(step_key) & 0xFFFFFFFF,
+        rc = self._lib.rs_idqn_act(self._h, obs.data_ptr(), N, int(env_base), 1 if sample else 0, float(epsilon), self.seed, int(step_key) & 0xFFFFFFFF,
                                    dyn.data_ptr() if dyn is not None else None, actions.data_ptr(),
                                    q.data_ptr() if want_q else None, st)
         if rc != 0:

@@ -324,6 +324,32 @@ static hipError_t wait_idle(rs_sim *h) {
     return e;
 }
 
+// The workgroup shape rs_create picks for block_threads = 0 (include/resco_sim.h).  Base: one thread per TWO slots (the capacity is the
+// episode's peak, about twice the typical occupancy), at most 512 threads, 80 VGPRs -- at large batches the fewest waves per
+// environment win (cologne1, 128 slots: 64 threads 13.3 M env-steps/s against 12.5 M with 128 at 16 384 environments).  A SMALL batch
+// leaves the chip empty at that shape -- 1024 environments x one wave are 4 waves per CU -- and a phase of the tick is the latency of
+// its chunks one after the other on that wave: as long as the resident-wave budget of the device (7 waves per SIMD with the 80-VGPR
+// build) holds every environment at once, the environment gets more waves, up to one per chunk of a phase (capacity / 64 slots chunks
+// + one list chunk).  Measured on one MI355X, random policy (profiles/r06_block_sweep.txt): cologne1 x 1024 2.65 -> 4.94 M with 256
+// threads, cologne8 x 2048 6.04 -> 6.88 M with 192, and at >= 4096 environments the base shape again.
+extern "C" int32_t rs_default_block(int32_t capacity, int32_t n_envs_on_device, int32_t device_id) {
+    const int C = capacity;
+    if (C < 64 || n_envs_on_device <= 0) return 0;
+    const int base = C >= 1024 ? 8 : ((C / 2) + 63) / 64;           // waves
+    int waves = base;
+    if (C < 1024) {         // (a 1024-slot scenario is at three 512-thread workgroups per CU already: more threads lose the third)
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        else (void)hipGetLastError();
+        const long budget = (long)cus * 4 * 7;                      // resident waves of the 80-VGPR build
+        const int fit = (int)(budget / n_envs_on_device), most = C / 64 + 1;
+        waves = fit < most ? fit : most;
+        if (waves < base) waves = base;
+    }
+    return -(10000 + 64 * waves);
+}
+
 extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
                          int32_t block_threads, rs_handle *out) {
     if (!sc || !p || !out || n_envs <= 0) { g_create_err = "rs_create: bad argument"; return RS_EINVAL; }
@@ -448,17 +474,14 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_VEH_COOP_ODD, G.coop(1), RS_U32, 2, n, c); set_buf(h, RS_BUF_VEH_COOPLEAD_ODD, G.cooplead(1), RS_U32, 2, n, c);
 
     h->lds = lds_carve(nullptr, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
+    if (const char *pad = getenv("RESCO_STUDY_LDS_PAD")) h->lds += (size_t)atoi(pad);      // study knob: unused bytes, to hold the residency fixed in an A/B
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
     // block_threads: 0 = one thread per slot (at most 1024); a negative value selects the 128-VGPR build with |value|
     // threads (<= 512), -(10000 + threads) the 80-VGPR build -- tuning knobs, see DESIGN.md
     if (block_threads < 0) { h->use_v128 = 1; block_threads = -block_threads; if (block_threads >= 10000) { h->use_v128 = 2; block_threads -= 10000; } }
     else if (block_threads == 0) {
-        // default: one thread per TWO slots (the capacity is the episode's peak, about twice the typical occupancy), at most
-        // 512 threads, 80 VGPRs -- three workgroups of 512 threads share a CU when the working memory stays below 53 KB
-        // (DESIGN.md section 4).  Measured: cologne1 (128 slots) 64 threads 12.3 M vs 128 threads 10.1 M env-steps/s,
-        // cologne8 (256 slots) 128 threads 6.5 M vs 256 threads 6.3 M
-        block_threads = C >= 1024 ? 512 : (((C / 2) + 63) / 64) * 64;
-        h->use_v128 = 2;
+        block_threads = rs_default_block(C, n_envs, device_id);        // (encoded: -(10000 + threads) = the 80-VGPR build)
+        if (block_threads < 0) { h->use_v128 = 2; block_threads = -block_threads - 10000; }
     }
     if (block_threads % 64 || block_threads > (h->use_v128 == 1 ? 512 : (h->use_v128 == 2 ? 768 : 1024)) || block_threads < 64) {
         h->err = "block_threads must be a multiple of 64 in [64, 1024] ([64, 768] for the 80-VGPR build, [64, 512] for the 128-VGPR build)";
@@ -688,7 +711,7 @@ extern "C" int rs_stats(rs_handle h, int64_t *host_out) {
     return rs_read_buffer(h, RS_BUF_STATS, host_out, (int64_t)h->n_envs * ST_N * 8);
 }
 
-struct Snapshot { std::vector<void *> ptrs; };
+struct Snapshot { std::vector<void *> ptrs; uint32_t seed = 0; };     // the seed: the speed factors are recomputed from (seed, env, trip) at every load
 // state AND the observation buffers: re-running observe would advance Signal.waiting_times
 static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, RS_BUF_MPLIGHT, RS_BUF_WAVE, RS_BUF_WAIT,
                                 RS_BUF_WAIT_NORM, RS_BUF_PRESSURE, RS_BUF_QUEUE_SUM, RS_BUF_QUEUE_MAX, RS_BUF_DRQ_NORM_F16,
@@ -702,6 +725,7 @@ extern "C" int rs_snapshot(rs_handle h, void **snap) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, wait_idle(h));
     Snapshot *S = new Snapshot();
+    S->seed = h->P.seed;
     for (int b : kSnapBufs) {
         void *d = nullptr;
         if (h->bufs[b].bytes == 0) { S->ptrs.push_back(nullptr); continue; }
@@ -719,6 +743,7 @@ extern "C" int rs_restore(rs_handle h, const void *snap) {
     const Snapshot *S = (const Snapshot *)snap;
     size_t i = 0;
     for (int b : kSnapBufs) { if (h->bufs[b].bytes) HIPCHK(h, hipMemcpy(h->bufs[b].ptr, S->ptrs[i], h->bufs[b].bytes, hipMemcpyDeviceToDevice)); ++i; }
+    h->P.seed = S->seed;        // the vehicles on the network keep the speed factors they were inserted with
     return RS_OK;
 }
 extern "C" void rs_snapshot_free(rs_handle h, void *snap) {
@@ -825,12 +850,12 @@ extern "C" int rs_idqn_create(int32_t device_id, int32_t n_signals, int32_t lmax
     return RS_OK;
 }
 
-extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, int32_t mode, float epsilon, uint32_t seed, uint32_t step_key,
+extern "C" int rs_idqn_act(rs_policy_handle p, const void *obs, int32_t n_envs, int32_t env_base, int32_t mode, float epsilon, uint32_t seed, uint32_t step_key,
                            const void *dyn, int32_t *actions, float *q, void *stream) {
     if (!p || !obs || !actions || n_envs <= 0 || mode < 0 || mode > 1) return RS_EINVAL;
     if (hipSetDevice(p->device) != hipSuccess) return RS_EHIP;
     hipLaunchKernelGGL(rs_idqn_forward_kernel, dim3((n_envs + POL_TM - 1) / POL_TM, p->W.S), dim3(256), 0, (hipStream_t)stream,
-                       p->W, (const __half *)obs, (int)n_envs, 0, (int)mode, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
+                       p->W, (const __half *)obs, (int)n_envs, (int)env_base, (int)mode, epsilon, seed, step_key, (const uint32_t *)dyn, actions, q);
     return hipGetLastError() == hipSuccess ? RS_OK : RS_EHIP;
 }
 
@@ -847,6 +872,7 @@ extern "C" int rs_group_step(const rs_handle *hs, int32_t n_handles, const rs_gr
         } else if (kind == RS_AGENT_IDQN) {
             if (!agent->policy || agent->mode < 0 || agent->mode > 1 || agent->policy->W.S != h->K.n_signals || agent->policy->W.lmax != h->K.lmax) {
                 h->err = "rs_group_step: RS_AGENT_IDQN needs a policy built for this scenario (n_signals, lmax)"; return RS_EINVAL; }
+            if (agent->policy->device != h->device) { h->err = "rs_group_step: the policy's weights live on another device than this handle"; return RS_EINVAL; }
             if (!(h->out_mask & OUT_DRQ_F16)) { h->err = "rs_group_step: RS_AGENT_IDQN reads RS_BUF_DRQ_NORM_F16, which rs_set_outputs has switched off"; return RS_EINVAL; }
         } else if (kind != RS_AGENT_NONE && kind != RS_AGENT_RANDOM) { h->err = "rs_group_step: unknown agent kind"; return RS_EINVAL; }
     }

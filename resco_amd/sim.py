@@ -31,7 +31,8 @@ TRIP_NONE = 0xFFFF
 ABI_SYMBOLS = ['rs_create', 'rs_destroy', 'rs_last_error', 'rs_reset', 'rs_step', 'rs_sync', 'rs_reinit_signals', 'rs_ticks', 'rs_step_sim', 'rs_set_outputs', 'rs_act_random',
                'rs_act_maxwave', 'rs_get_buffer', 'rs_read_buffer', 'rs_stats', 'rs_snapshot', 'rs_restore',
                'rs_snapshot_free', 'rs_timing', 'rs_timing_read', 'rs_set_seed', 'rs_phase_profile', 'rs_info',
-               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_set_lanes', 'rs_idqn_destroy', 'rs_group_step']
+               'rs_idqn_create', 'rs_idqn_act', 'rs_idqn_set_device_weights', 'rs_idqn_set_lanes', 'rs_idqn_destroy', 'rs_group_step',
+               'rs_default_block']
 
 _lib = None
 
@@ -66,6 +67,9 @@ def bind(L):
     L.rs_phase_profile.argtypes = [vp, i32, vp]
     L.rs_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.rs_group_step.argtypes = [vp, i32, vp, i32]
+    if hasattr(L, 'rs_default_block'):      # (the host emulation of the CPU tests exports only what it implements)
+        L.rs_default_block.argtypes = [i32, i32, i32]
+        L.rs_default_block.restype = i32
     return L
 
 
@@ -185,7 +189,9 @@ class BatchedSim:
 
     def __init__(self, scenario, n_envs, device=0, seed=0, max_distance=200.0, sigma=-1.0, speed_dev=1,
                  fixed_program=0, env_base=0, step_length=10, yellow_length=None, block_threads=0, trip_log=0, step_ratio=1,
-                 tls_expiry=0):
+                 tls_expiry=0, device_envs=None):
+        """device_envs: how many environments share this GPU when the batch is split over several handles (pipes) -- the default
+        workgroup shape (block_threads = 0) is chosen for the device's load, not for this handle's share (rs_default_block)"""
         self.sc = scenario
         self.n_envs = int(n_envs)
         self.device = int(device)
@@ -199,6 +205,8 @@ class BatchedSim:
                                int(fixed_program), int(trip_log), int(step_ratio), 1 if tls_expiry else 0)
         self.step_ratio = max(1, int(step_ratio))
         self._h = C.c_void_p()
+        if not block_threads and device_envs and int(device_envs) != self.n_envs and hasattr(self._lib, 'rs_default_block'):
+            block_threads = self._lib.rs_default_block(int(scenario.capacity), int(device_envs), self.device)
         rc = self._lib.rs_create(C.byref(self._st), C.byref(self._p), self.n_envs, int(env_base), self.device,
                                  int(block_threads), C.byref(self._h))
         if rc != 0:

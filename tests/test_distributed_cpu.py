@@ -8,6 +8,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from conftest import ROOT, load_scenario
@@ -68,3 +69,32 @@ def test_algorithmic_bytes_formula():
     # 60 B per active vehicle + 12 B per signal (action, FSM in / out) + 20 B per observed lane + 8 B of rewards per signal
     assert b == 300 * 60 + 21 * 12 + 163 * 20 + 21 * 8
     assert bench.designed_bytes_per_env_step(sc, 300.0) > b
+
+
+def test_bench_gpus_flag_means_that_many_ranks(monkeypatch):
+    """`python bench.py --gpus N` (no launcher) re-executes itself as the contract's N-rank launch; a launcher whose world size differs
+    from --gpus is refused with a non-zero exit BEFORE anything is timed (round-5 review: `--gpus 8` under one process silently timed
+    one GPU and printed n_gpus 1)."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_execve(exe, cmd, env):
+        seen['cmd'], seen['env'] = cmd, env
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, 'execve', fake_execve)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # launcher / flag mismatch: a world of 1 with --gpus 2 (and the reverse) must fail loudly, on any box
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for world, gpus in ((1, 2), (2, 1)):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '2', '--warmup', '1'],
+                           env=dict(os.environ, WORLD_SIZE=str(world), RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=170)
+        assert r.returncode != 0 and 'started WORLD_SIZE=%d' % world in r.stderr and '{"metric"' not in r.stdout

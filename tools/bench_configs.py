@@ -23,7 +23,7 @@ def run(name, n, policy, steps=360, warm=0, fixed=0, pipes=1):
     """`pipes` handles of n / pipes environments each, every one stepping on its own HIP stream (bench.py --pipes)"""
     sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
     per = n // pipes
-    sims = [BatchedSim(sc, per, seed=0, fixed_program=fixed, env_base=i * per) for i in range(pipes)]
+    sims = [BatchedSim(sc, per, seed=0, fixed_program=fixed, env_base=i * per, device_envs=n) for i in range(pipes)]
 
     def one(k):
         for sim in sims:
