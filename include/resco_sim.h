@@ -109,7 +109,9 @@ typedef struct rs_sim *rs_handle;
  *                 still holds all n_envs environments at once (small batches: BASELINE configs 2 and 4);
  *    n > 0        n threads (a multiple of 64, <= 1024) with the 64-VGPR build;
  *    -n, n <= 512 n threads with the 128-VGPR build;
- *    -(10000 + n) n threads (<= 768) with the 80-VGPR build.
+ *    -(10000 + n) n threads (<= 768) with the 80-VGPR build;
+ *    -(20000 + n) n threads, the build chosen by the library (what rs_default_block returns): 64 VGPRs where four 512-thread
+ *                 workgroups fit a CU (working memory <= 40 KiB per environment), else 80.
  * Results do not depend on the choice (tests/test_gpu_parity.py::test_block_sizes_and_register_budgets_bit_exact). */
 int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
               int32_t block_threads, rs_handle *out);
@@ -192,7 +194,7 @@ enum rs_buffer {
     RS_BUF_VEH_RWAIT,      /* u16 [N][C]  RESCO Signal.waiting_times value (s), 0 = not in the dict */
     RS_BUF_VEH_DEPART,     /* u16 [N][C] */
     RS_BUF_VEH_OWNER,      /* u8  [N][C]  index of the signal that observed the vehicle last, 0xFF none */
-    RS_BUF_STATS,          /* i64 [N][10] see rs_stats */
+    RS_BUF_STATS,          /* i64 [N][11] see rs_stats */
     RS_BUF_DRQ_NORM_F16,   /* f16 [N][S][Lmax][5] zero padded states.drq_norm (IDQN rollout layout) */
     RS_BUF_VEH_SF,         /* f32 [N][C]  per-vehicle speedFactor (written at the insertion; the kernel does not read it back) */
     RS_BUF_VEH_WTOT,       /* u16 [N][C]  total halted seconds of the trip so far (maintained only with trip_log) */
@@ -219,8 +221,9 @@ int rs_read_buffer(rs_handle h, int32_t which, void *host_dst, int64_t nbytes);
 
 /* per env: [0] inserted [1] arrived [2] sum duration(s) [3] sum departDelay(s) [4] sum waiting(s)
  * [5] sum timeLoss (1/1024 s) [6] active now [7] backlog: trips whose insertion was tried and has failed so far
- * [8] sum over ticks of active vehicles [9] ticks */
-int rs_stats(rs_handle h, int64_t *host_out /* [n_envs][10] */);
+ * [8] sum over ticks of active vehicles [9] ticks [10] insertions refused because all `capacity` slots of the environment were
+ * taken (the trip stays in its backlog and enters later: non-zero means the run met the limit of the working memory) */
+int rs_stats(rs_handle h, int64_t *host_out /* [n_envs][11] */);
 
 /* environment snapshots (device-resident copies of the SoA state) */
 int rs_snapshot(rs_handle h, void **snap);

@@ -171,8 +171,8 @@ class OracleEnv:
         return float(out[1]), int(out[0])
 
     def stats(self):
-        out = (C.c_int64 * 10)()
+        out = (C.c_int64 * 11)()
         lib().orc_stats(self._h, out)
         keys = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10',
-                'active', 'pending', 'active_ticks', 'ticks']
+                'active', 'pending', 'active_ticks', 'ticks', 'cap_blocked']
         return dict(zip(keys, [int(x) for x in out]))

@@ -80,7 +80,7 @@ struct orc_env {
     int32_t *sig_arr, *sig_dep, *out_arr, *out_dep;     /* |Signal.arrivals| / |Signal.departures| of the running / last observe */
     int32_t *lane_arr;      /* [n_obs] vehicles of the lane that are in their signal's `arrivals` set (rewards.fma2c fringe arrivals) */
     float *mplight_full;
-    int64_t stats[10];
+    int64_t stats[11];
 };
 
 /* ------------------------------------------------------------------ counter-based RNG (murmur3_32) */
@@ -399,6 +399,12 @@ static void insertion_apply(orc_env *e) {
     const orc_scenario *sc = e->sc;
     int32_t C = sc->capacity;
     int32_t room = e->room_ins;             /* the network holds at most `capacity` vehicles */
+    /* stats[10]: insertions refused because every slot was taken (the trip stays in its backlog): winners beyond the free capacity */
+    {
+        int32_t winners = 0;
+        for (int32_t dl = 0; dl < sc->n_lanes; ++dl) if (e->lane_ins[dl] >= 0) winners += 1;
+        if (winners > room) e->stats[10] += winners - (room > 0 ? room : 0);
+    }
     for (int32_t dl = 0; dl < sc->n_lanes && room > 0; ++dl) {      /* lower lane index first when the network is full */
         int32_t k = e->lane_ins[dl];
         if (k < 0) continue;
@@ -946,7 +952,7 @@ void orc_backlog(const orc_env *e, int64_t out[2], int32_t *per_lane) {
 }
 const uint16_t *orc_wtot(const orc_env *e) { return e->wtot; }
 void orc_debug(const orc_env *e, const int32_t **reason, const int32_t **block) { *reason = e->dbg_reason; *block = e->dbg_block; }
-void orc_stats(const orc_env *e, int64_t out[10]) {
+void orc_stats(const orc_env *e, int64_t out[11]) {
     memcpy(out, e->stats, sizeof(e->stats));
     /* [7]: trips whose insertion has been tried and failed so far (departed before the last tick, not yet on the network) */
     int32_t hz = e->t - 1 <= e->sc->horizon ? e->t - 1 : e->sc->horizon;

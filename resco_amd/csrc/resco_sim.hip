@@ -85,43 +85,51 @@ __device__ unsigned long long *g_sec_prof;
 
 // ------------------------------------------------------------------------------------------------ kernels
 // grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 1024), normally one thread per slot.
-struct DevExec {
+// PROF: the build with the in-kernel timers (rs_phase_profile); the production kernels carry none of that code
+template <bool PROF> struct DevExec {
     int B;
+    int wave;                       // threadIdx.x / 64, wave-uniform: lives in a scalar register
     unsigned long long *prof;       // optional per-phase timers (rs_phase_profile)
     unsigned long long t0;
     template <class F> __device__ __forceinline__ void phase(int id, F f) {
-        // the thread index is made opaque per phase: otherwise every address derived from it (the small strided loops of the
-        // tick's phases) is computed once before the tick loop and kept alive across it -- 18 VGPRs spilled to scratch, written
-        // once per thread and launch: two thirds of the kernel's HBM write traffic
-        int tid = (int)threadIdx.x;
+        // The thread index is RECOMPUTED per phase from the wave's index (a scalar) and the lane's position in the wave (two VALU
+        // instructions): kept in a register across the kernel it costs a VGPR the 64-VGPR build does not have (it lived in scratch
+        // and was re-loaded at the top of every phase), and an index the compiler can see through has every address derived from
+        // it (the small strided loops of the tick's phases) computed once before the tick loop and kept alive across it --
+        // 18 VGPRs spilled to scratch (round 2).
+        int w = wave;
+        uint32_t ones = ~0u;
+        asm volatile("" : "+s"(w), "+s"(ones));     // (opaque: neither the lane index nor anything derived from it is hoisted out of the phase)
+        int tid = (w << 6) | (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
         asm volatile("" : "+v"(tid));
         f(tid);
         __syncthreads();
-        if (prof) {         // (t0 stays wave-uniform: every thread takes the time, thread 0 adds it up)
+        if (PROF && prof) {         // (t0 stays wave-uniform: every thread takes the time, thread 0 adds it up)
             const unsigned long long t1 = wall_clock64();
-            if (threadIdx.x == 0) atomicAdd(&prof[id], t1 - t0);
+            if (tid == 0) atomicAdd(&prof[id], t1 - t0);
             t0 = t1;
         }
     }
     // tid / 64 as a wave-uniform value: what is derived from it (the roles of the waves inside a phase) stays in scalar registers
-    __device__ __forceinline__ int wave_of(int tid) const { return __builtin_amdgcn_readfirstlane(tid >> 6); }
+    __device__ __forceinline__ int wave_of(int) const { return wave; }
     // the next work chunk of this wave: one LDS atomic per wave (called with the wave converged), broadcast from its first lane
     __device__ __forceinline__ int next_chunk(int32_t *ctr, int, int, int) const {
         int c = 0;
-        if ((threadIdx.x & 63) == 0) c = atomicAdd(ctr, 1);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) c = atomicAdd(ctr, 1);
         return __builtin_amdgcn_readfirstlane(c);
     }
     // time a wave spends in one role of a phase: sum of the 100 MHz ticks in the low 40 bits, number of waves above
-    __device__ __forceinline__ unsigned long long role_begin() const { return prof ? wall_clock64() : 0ull; }
+    __device__ __forceinline__ unsigned long long role_begin() const { return (PROF && prof) ? wall_clock64() : 0ull; }
     __device__ __forceinline__ void role_end(int id, unsigned long long start) const {
 #ifdef RS_STUDY_SECTIONS
         return;
 #endif
-        if (prof && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicAdd(&prof[id], (wall_clock64() - start) + (1ull << 40));   // (every 16th environment: the sum stays below 2^40)
+        if (PROF && prof && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicAdd(&prof[id], (wall_clock64() - start) + (1ull << 40));   // (every 16th environment: the sum stays below 2^40)
     }
 };
-// Two register budgets: 64 VGPRs (two 1024-thread workgroups = 32 waves share a CU) and 128 VGPRs (blocks of <= 512);
-// CAP = the slot capacity as a compile-time constant (0: any)
+// Register budgets: 64 VGPRs (eight waves per SIMD: FOUR 512-thread workgroups per CU -- the default where the working memory of an
+// environment fits four times, round 6) and 80 VGPRs (three 512-thread workgroups per CU; `_v128` is the same code under a third
+// launch bound); CAP = the slot capacity as a compile-time constant (0: any).
 // The tables / state / output descriptors live in ONE constant block in device memory (StepArgs): passed by value they
 // would pin ~70 SGPRs for the whole kernel (beyond ~100 the compiler spills SGPRs into VGPR lanes around every use);
 // behind a const __restrict__ pointer every field is a re-loadable scalar load.
@@ -129,39 +137,27 @@ struct StepArgs { KTab T; State G; Out O; Lds L; };
 // the block is read through the CONSTANT address space: scalar loads, and the compiler takes pointers loaded from it for
 // global ones (global_load instead of flat_load, which would also tie up the LDS wait counter)
 typedef const __attribute__((address_space(4))) StepArgs *StepArgsPtr;
+template <int CAP, bool PROF> __device__ __forceinline__ void rs_step_kernel_body(StepArgsPtr Ac, const KParams &P, const int32_t *__restrict__ actions) {
+    if ((int)blockIdx.x >= P.n_envs) return;
+    const StepArgs *A = (const StepArgs *)Ac;
+#ifdef RS_STUDY_SECTIONS
+    if (threadIdx.x == 0) g_sec_prof = P.prof;
+#endif
+    DevExec<PROF> ex{(int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), PROF ? P.prof : nullptr, (PROF && P.prof) ? wall_clock64() : 0ull};
+    rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
+}
 template <int CAP>
 __global__ void __launch_bounds__(1024, 8)
-rs_step_kernel_v64(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
-    if ((int)blockIdx.x >= P.n_envs) return;
-    const StepArgs *A = (const StepArgs *)Ac;
-#ifdef RS_STUDY_SECTIONS
-    if (threadIdx.x == 0) g_sec_prof = P.prof;
-#endif
-    DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
-    rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
-}
+rs_step_kernel_v64(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false>(Ac, P, actions); }
 template <int CAP>
 __global__ void __launch_bounds__(768, 6)
-rs_step_kernel_v80(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
-    if ((int)blockIdx.x >= P.n_envs) return;
-    const StepArgs *A = (const StepArgs *)Ac;
-#ifdef RS_STUDY_SECTIONS
-    if (threadIdx.x == 0) g_sec_prof = P.prof;
-#endif
-    DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
-    rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
-}
+rs_step_kernel_v80(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false>(Ac, P, actions); }
 template <int CAP>
 __global__ void __launch_bounds__(512, 4)
-rs_step_kernel_v128(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) {
-    if ((int)blockIdx.x >= P.n_envs) return;
-    const StepArgs *A = (const StepArgs *)Ac;
-#ifdef RS_STUDY_SECTIONS
-    if (threadIdx.x == 0) g_sec_prof = P.prof;
-#endif
-    DevExec ex{(int)blockDim.x, P.prof, P.prof ? wall_clock64() : 0ull};
-    rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
-}
+rs_step_kernel_v128(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false>(Ac, P, actions); }
+// the profiling build (rs_phase_profile / RS_STUDY_SECTIONS): any capacity, 80 VGPRs
+__global__ void __launch_bounds__(768, 6)
+rs_step_kernel_prof(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<0, true>(Ac, P, actions); }
 
 // reset every environment: no vehicles, every backlog at its first trip, TLS programs freshly installed
 // (Signal.__init__, traffic_signal.py:93-100)
@@ -303,18 +299,24 @@ static void set_buf(rs_sim *h, int which, void *ptr, int dtype, int ndim, int64_
 }
 
 typedef void (*step_kernel_fn)(StepArgsPtr, KParams, const int32_t *);
-static const int kStepCaps[] = {0, 128, 256, 512, 768, 1024};
+static const int kStepCaps[] = {0, 128, 256, 512, 768, 896, 1024};
 // regs: 0 = 64 VGPRs (blocks up to 1024 threads), 1 = 128 VGPRs, 2 = 80 VGPRs (blocks up to 512 threads)
 #define RS_PICK(cap_) (regs == 1 ? rs_step_kernel_v128<cap_> : (regs == 2 ? rs_step_kernel_v80<cap_> : rs_step_kernel_v64<cap_>))
 static step_kernel_fn step_kernel_for(int regs, int capacity) {
+#ifdef RS_ONE_CAP       // study builds (seconds instead of minutes to compile): one capacity, the 64- and the 80-VGPR kernel only
+    (void)capacity;
+    return regs == 0 ? rs_step_kernel_v64<RS_ONE_CAP> : rs_step_kernel_v80<RS_ONE_CAP>;
+#else
     switch (capacity) {
         case 128: return RS_PICK(128);
         case 256: return RS_PICK(256);
         case 512: return RS_PICK(512);
         case 768: return RS_PICK(768);
+        case 896: return RS_PICK(896);
         case 1024: return RS_PICK(1024);
         default: return RS_PICK(0);
     }
+#endif
 }
 
 // every synchronous entry point waits for the handle's own stream AND the caller stream of the last launch
@@ -335,19 +337,19 @@ static hipError_t wait_idle(rs_sim *h) {
 extern "C" int32_t rs_default_block(int32_t capacity, int32_t n_envs_on_device, int32_t device_id) {
     const int C = capacity;
     if (C < 64 || n_envs_on_device <= 0) return 0;
-    const int base = C >= 1024 ? 8 : ((C / 2) + 63) / 64;           // waves
+    const int base = C >= 768 ? 8 : ((C / 2) + 63) / 64;            // waves
     int waves = base;
-    if (C < 1024) {         // (a 1024-slot scenario is at three 512-thread workgroups per CU already: more threads lose the third)
+    if (C < 768) {          // (the large scenarios run three or four 512-thread workgroups per CU: more threads would lose one)
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         else (void)hipGetLastError();
-        const long budget = (long)cus * 4 * 7;                      // resident waves of the 80-VGPR build
+        const long budget = (long)cus * 4 * 7;                      // resident waves of the 80-VGPR build (what these shapes run with)
         const int fit = (int)(budget / n_envs_on_device), most = C / 64 + 1;
         waves = fit < most ? fit : most;
         if (waves < base) waves = base;
     }
-    return -(10000 + 64 * waves);
+    return -(20000 + 64 * waves);
 }
 
 extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t env_base, int32_t device_id,
@@ -478,11 +480,14 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     if (h->lds > 160 * 1024) { h->err = "scenario needs more than 160 KiB of LDS per environment"; return fail(RS_ELIMIT); }
     // block_threads: 0 = one thread per slot (at most 1024); a negative value selects the 128-VGPR build with |value|
     // threads (<= 512), -(10000 + threads) the 80-VGPR build -- tuning knobs, see DESIGN.md
-    if (block_threads < 0) { h->use_v128 = 1; block_threads = -block_threads; if (block_threads >= 10000) { h->use_v128 = 2; block_threads -= 10000; } }
-    else if (block_threads == 0) {
-        block_threads = rs_default_block(C, n_envs, device_id);        // (encoded: -(10000 + threads) = the 80-VGPR build)
-        if (block_threads < 0) { h->use_v128 = 2; block_threads = -block_threads - 10000; }
-    }
+    if (block_threads == 0) block_threads = rs_default_block(C, n_envs, device_id);
+    if (block_threads <= -20000) {
+        // the shape rs_default_block proposes: the register budget follows from what fits a CU.  Where the working memory lets FOUR
+        // 512-thread workgroups share a CU they need eight waves per SIMD, i.e. the 64-VGPR build (ingolstadt21 with 896 slots:
+        // 40 768 B; +14 % env-steps/s over three workgroups of the 80-VGPR build, profiles/r06_ab_occupancy.txt); else 80 VGPRs
+        block_threads = -block_threads - 20000;
+        h->use_v128 = (block_threads == 512 && h->lds <= RS_LDS_4WG_LIMIT) ? 0 : 2;
+    } else if (block_threads < 0) { h->use_v128 = 1; block_threads = -block_threads; if (block_threads >= 10000) { h->use_v128 = 2; block_threads -= 10000; } }
     if (block_threads % 64 || block_threads > (h->use_v128 == 1 ? 512 : (h->use_v128 == 2 ? 768 : 1024)) || block_threads < 64) {
         h->err = "block_threads must be a multiple of 64 in [64, 1024] ([64, 768] for the 80-VGPR build, [64, 512] for the 128-VGPR build)";
         return fail(RS_EINVAL);
@@ -501,6 +506,9 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
                     if (hipFuncSetAttribute((const void *)step_kernel_for(v, cp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
                         h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
                     }
+            if (hipFuncSetAttribute((const void *)rs_step_kernel_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+                h->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return fail(RS_EHIP);
+            }
             cur = h->lds;
         }
     }
@@ -557,7 +565,9 @@ static int launch_step(rs_sim *h, hipStream_t st, int n_ticks, int do_fsm, int d
         h->ev_used += 1;
         HIPCHK(h, hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(step_kernel_for(h->use_v128, h->K.capacity), dim3(h->n_envs), dim3(h->block), h->lds, st, (StepArgsPtr)h->args, P, (const int32_t *)h->actions);
+    // (the in-kernel timers live in a kernel of their own: any capacity, 80 VGPRs, at most 768 threads)
+    const step_kernel_fn fn = (h->prof && h->block <= 768) ? (step_kernel_fn)rs_step_kernel_prof : step_kernel_for(h->use_v128, h->K.capacity);
+    hipLaunchKernelGGL(fn, dim3(h->n_envs), dim3(h->block), h->lds, st, (StepArgsPtr)h->args, P, (const int32_t *)h->actions);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     return RS_OK;

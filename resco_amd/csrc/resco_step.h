@@ -181,9 +181,9 @@ struct Lds {
     LPtr<Node> node;
     LPtr<Aux> aux;
     LPtr<float> vnx, vtp;
-    LPtr<uint16_t> grid;        // TWO grids of cells (bit 15 of a cell: it holds a moving vehicle): a tick reads the grid of its
-                                // parity and builds the other one while it moves the vehicles
-    uint32_t gstride;           // cells per grid (padded)
+    LPtr<uint16_t> grid;        // ONE grid of cells (resco_tables.h: a cell carries the parity of the tick it is valid for): a tick
+                                // reads the cells of its parity and pushes the moved vehicles with the other one
+    uint32_t gstride;           // cells of the grid (padded to a multiple of 8)
     LPtr<int32_t> arr;          // link approach registers
     LPtr<uint16_t> dep, dep_t;  // head trip of every departure lane's backlog, and its departure second (0xFFFF: none)
     LPtr<uint32_t> alive, alive0, insm;     // bit per slot: occupied (now / at the beginning of the tick); bit per departure lane: inserts this tick
@@ -235,7 +235,7 @@ RS_CARVE int lds_list_cap(int C) {
 // alone come first, so that their OFFSETS do too: a kernel instantiated for a capacity addresses them with literals (LdsFix below)
 // instead of a scalar load from the constant argument block per use -- +2 % when every offset is a literal
 // (profiles/r05_ab_const_layout.txt).  The others are read from the table where they are used (an offset costs a scalar load there
-// and no register in between).  The per-lane aggregates of the observe phase live where vnx was (dead by then) when they fit.
+// and no register in between).
 RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int n_obs, int S, int n_vt, int tls_maxl) {
     size_t o = 0;
 #define CARVE(field, bytes) { if (L) L->field.off = (uint32_t)o; o += align16(bytes); }
@@ -249,8 +249,10 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
         CARVE(ls_h, (size_t)cap * 2) CARVE(ls_lc, (size_t)cap * 2) CARVE(ls_mh, (size_t)cap * 2)
     }
     // ---- the first array of scenario-dependent size still starts at a known place
+    const uint32_t grid_off = (uint32_t)o;
+    const size_t grid_bytes = align16((size_t)((n_cells + 8 + 7) & ~7) * 2);
     if (L) L->gstride = (uint32_t)((n_cells + 8 + 7) & ~7);
-    CARVE(grid, (size_t)((n_cells + 8 + 7) & ~7) * 2 * 2)
+    CARVE(grid, (size_t)((n_cells + 8 + 7) & ~7) * 2)
     // ---- scenario-dependent
     CARVE(insm, (size_t)((n_dep + 31) / 32) * 4)
     CARVE(vtp, (size_t)n_vt * VT_COLS * 4)
@@ -259,9 +261,14 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
     CARVE(tstate, (size_t)S * tls_maxl)
     CARVE(arr, (size_t)n_arr * 4) CARVE(dep, (size_t)n_dep * 2) CARVE(dep_t, (size_t)n_dep * 2)
     {
+        // the per-lane aggregates of the observe phase live where the grid was (dead after the last tick), else where the next
+        // speeds were, else in a region of their own
         const size_t ab = align16((size_t)n_obs * 4);
-        uint32_t p = L ? L->vnx.off : 0u;
-        if (6 * ab > align16((size_t)C * 4)) { p = (uint32_t)o; o += 6 * ab; }       // (more observed lanes than the slots' next speeds leave room for)
+        uint32_t p = grid_off;
+        if (6 * ab > grid_bytes) {
+            p = (uint32_t)(align16((size_t)C * 16) + align16((size_t)C * 8));           // vnx (the third array above)
+            if (6 * ab > align16((size_t)C * 4)) { p = (uint32_t)o; o += 6 * ab; }
+        }
         if (L) {
             L->agg_q.off = p; L->agg_a.off = p + (uint32_t)ab; L->agg_w.off = p + (uint32_t)(2 * ab);
             L->agg_m.off = p + (uint32_t)(3 * ab); L->agg_s.off = p + (uint32_t)(4 * ab); L->agg_n.off = p + (uint32_t)(5 * ab);
@@ -325,20 +332,27 @@ RS_CARVE bool lds_fix_matches(const Lds &T, int C) {
         case 128: return LdsFix<128>::matches(T);
         case 256: return LdsFix<256>::matches(T);
         case 512: return LdsFix<512>::matches(T);
+        case 768: return LdsFix<768>::matches(T);
+        case 896: return LdsFix<896>::matches(T);
         case 1024: return LdsFix<1024>::matches(T);
         default: return true;           // (the kernel of a run-time capacity reads every offset from the table)
     }
 }
 
-// The grid cell length of a scenario: the shortest of CELL_CHOICES with which the working memory of an environment still lets three
-// workgroups share a CU (resco_tables.h); n_arr / n_dep / tls_maxl as PackedTables::build found them (they do not depend on it)
+// The grid cell length of a scenario: the shortest of CELL_CHOICES that can count the scenario's vehicles (PackedTables::cell_len_ok)
+// and with which the working memory of an environment lets four workgroups share a CU; failing that, three; failing that the
+// shortest countable one (resco_tables.h).  n_arr / n_dep / tls_maxl as PackedTables::build found them (they do not depend on it)
 RS_CARVE float pick_cell_len(const rs_scenario *sc, int n_arr, int n_dep, int tls_maxl) {
     const float choices[] = CELL_CHOICES;
     const int n = (int)(sizeof(choices) / sizeof(choices[0]));
-    for (int i = 0; i < n; ++i)
-        if (lds_carve(nullptr, sc->capacity, PackedTables::count_cells(sc, choices[i]), n_arr, n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, tls_maxl) <= RS_LDS_3WG_LIMIT)
-            return choices[i];
-    return choices[n - 1];
+    const size_t limits[2] = {RS_LDS_4WG_LIMIT, RS_LDS_3WG_LIMIT};
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < n; ++i)
+            if (PackedTables::cell_len_ok(sc, choices[i]) &&
+                lds_carve(nullptr, sc->capacity, PackedTables::count_cells(sc, choices[i]), n_arr, n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, tls_maxl) <= limits[k])
+                return choices[i];
+    for (int i = 0; i < n; ++i) if (PackedTables::cell_len_ok(sc, choices[i])) return choices[i];
+    return choices[0];          // (PackedTables::build reports the vehicle type that is too short)
 }
 
 // ------------------------------------------------------------------------------------------------ grid primitives
@@ -358,46 +372,60 @@ RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj
 template <class LT> RS_DEV int lane_cells(const LT &L, const LaneRec &LR) { return (int)(LR.len * L.cell_inv) + 1; }
 template <class LT> RS_DEV int cell_of(const LT &L, float pos, int ncell) { const int c = (int)(pos * L.cell_inv); return c < ncell ? c : ncell - 1; }
 
+// THE grid as a tick sees it: the cells, and the tag (0 / CELL_TAG) of the contents this user means -- a reader the tag of its tick,
+// the move phase that of the next one.  A cell that carries the other tag is empty for both.
+struct Grid { uint16_t *c; uint32_t tag; };
+RS_DEV unsigned long long grid_tag4(const Grid &g) { return g.tag ? 0x8000800080008000ull : 0ull; }
+// head slot of the chain of cell c (NIL: the cell is empty or holds last tick's contents)
+RS_DEV int cell_head(const Grid &g, int c) {
+    const uint32_t v = g.c[c];
+    return ((v ^ g.tag) & CELL_TAG) ? (int)NIL : (int)(v & NIL);
+}
 // push slot s into cell c; returns the previous head (the new chain link).  16-bit cells, exchanged with a CAS on the
 // containing dword (LDS has no 16-bit atomics); the cell's vehicle count goes up by one
-RS_DEV uint16_t grid_push(uint16_t *grid, int c, int s, bool mover) {
-    uint32_t *w = (uint32_t *)grid + (c >> 1);
+RS_DEV uint16_t grid_push(const Grid &g, int c, int s, bool mover) {
+    uint32_t *w = (uint32_t *)g.c + (c >> 1);
     const int sh = (c & 1) * 16;
-    const uint32_t flag = mover ? CELL_MOVER : 0u;
-    uint32_t old = *w, assumed;
+    const uint32_t flag = (mover ? CELL_MOVER : 0u) | g.tag;
+    uint32_t old = *w, assumed, cell;
     do {
         assumed = old;
-        const uint32_t cell = (assumed >> sh) & 0xFFFFu;
+        cell = (assumed >> sh) & 0xFFFFu;
+        if ((cell ^ g.tag) & CELL_TAG) cell = NIL;                // the other tag: last tick's contents -- an empty cell
         const uint32_t keep = cell & CELL_MOVER;                  // sticky mover flag of the cell
         uint32_t cnt = (cell >> CELL_CNT_SHIFT) & CELL_CNT_MAX;
         if (cnt < CELL_CNT_MAX) cnt += 1u;
         old = rs_atomic_cas(w, assumed, (assumed & ~(0xFFFFu << sh)) | (((uint32_t)s | (cnt << CELL_CNT_SHIFT) | keep | flag) << sh));
     } while (old != assumed);
-    return (uint16_t)((old >> sh) & NIL);
+    return (uint16_t)(cell & NIL);
 }
+// the 4 cells of the aligned quad starting at b, with the tag bit of a cell CLEAR iff it carries this user's tag
+RS_DEV unsigned long long quad_load(const Grid &g, int b) { return *(const unsigned long long *)(g.c + b) ^ grid_tag4(g); }
 // occupancy mask of the 4 cells of the aligned quad starting at b: bit 16 j + 11 set iff cell b + j is occupied
-RS_DEV unsigned long long quad_occ(const uint16_t *grid, int b) {
-    const unsigned long long w = *(const unsigned long long *)(grid + b);
+RS_DEV unsigned long long quad_occ(const Grid &g, int b) {
+    const unsigned long long w = quad_load(g, b);
     const unsigned long long x = (w & 0x07FF07FF07FF07FFull) ^ 0x07FF07FF07FF07FFull;       // 11-bit field != 0: occupied
-    return (x + 0x07FF07FF07FF07FFull) & 0x0800080008000800ull;
+    return (x + 0x07FF07FF07FF07FFull) & 0x0800080008000800ull & ~(w >> 4);                 // ... and the tag is this tick's
 }
 // number of vehicles in the cells [c0, c0 + nc) (the lane with these cells): the sum of the cells' counters
-RS_DEV int cells_count(const uint16_t *grid, int c0, int nc) {
+RS_DEV int cells_count(const Grid &g, int c0, int nc) {
     const int c1 = c0 + nc - 1;
     int n = 0;
     for (int b = c0 & ~3; b <= c1; b += 4) {
-        unsigned long long m = (*(const unsigned long long *)(grid + b) >> CELL_CNT_SHIFT) & 0x000F000F000F000Full;
+        const unsigned long long w = quad_load(g, b);
+        unsigned long long m = (w >> CELL_CNT_SHIFT) & 0x0007000700070007ull;
+        m &= ~(((w >> 15) & 0x0001000100010001ull) * 7ull);     // cells of the other tag count nothing
         const int lo = c0 - b, hi = c1 - b;
         if (lo > 0) m &= ~0ull << (16 * lo);
         if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
-        n += (int)((m * 0x0001000100010001ull) >> 48);      // the four 4-bit counters added up in the top 16 bits
+        n += (int)((m * 0x0001000100010001ull) >> 48);      // the four 3-bit counters added up in the top 16 bits
     }
     return n;
 }
 // first occupied cell of [c0, c1] scanning upwards, -1: none
-RS_DEV int scan_up(const uint16_t *grid, int c0, int c1) {
+RS_DEV int scan_up(const Grid &g, int c0, int c1) {
     for (int b = c0 & ~3; b <= c1; b += 4) {
-        unsigned long long m = quad_occ(grid, b);
+        unsigned long long m = quad_occ(g, b);
         const int lo = c0 - b, hi = c1 - b;
         if (lo > 0) m &= ~0ull << (16 * lo);
         if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
@@ -406,9 +434,9 @@ RS_DEV int scan_up(const uint16_t *grid, int c0, int c1) {
     return -1;
 }
 // first occupied cell of [c0, c1] scanning downwards from c1, -1: none
-RS_DEV int scan_down(const uint16_t *grid, int c0, int c1) {
+RS_DEV int scan_down(const Grid &g, int c0, int c1) {
     for (int b = c1 & ~3; b + 3 >= c0; b -= 4) {
-        unsigned long long m = quad_occ(grid, b);
+        unsigned long long m = quad_occ(g, b);
         const int lo = c0 - b, hi = c1 - b;
         if (lo > 0) m &= ~0ull << (16 * lo);
         if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
@@ -418,10 +446,11 @@ RS_DEV int scan_down(const uint16_t *grid, int c0, int c1) {
     return -1;
 }
 // any moving vehicle in the cells [c0, c0 + nc)?
-RS_DEV bool cells_have_mover(const uint16_t *grid, int c0, int nc) {
+RS_DEV bool cells_have_mover(const Grid &g, int c0, int nc) {
     const int c1 = c0 + nc - 1;
     for (int b = c0 & ~3; b <= c1; b += 4) {
-        unsigned long long m = *(const unsigned long long *)(grid + b) & 0x8000800080008000ull;
+        const unsigned long long w = quad_load(g, b);
+        unsigned long long m = w & 0x4000400040004000ull & ~(w >> 1);
         const int lo = c0 - b, hi = c1 - b;
         if (lo > 0) m &= ~0ull << (16 * lo);
         if (hi < 3) m &= ~0ull >> (16 * (3 - hi));
@@ -452,19 +481,19 @@ template <class LT> RS_DEV int chain_frontmost(const LT &L, int head) {
     return best;
 }
 // rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
-template <class LT> RS_DEV int rearmost_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float win) {
+template <class LT> RS_DEV int rearmost_within(const LT &L, const Grid &grid, int cell0, int ncell, float win) {
     if (win < 0.0f) return NIL;
     const int c = scan_up(grid, cell0, cell0 + cell_of(L, win, ncell));
     if (c < 0) return NIL;
-    const int o = chain_rearmost(L, grid[c]);
+    const int o = chain_rearmost(L, cell_head(grid, c));
     return (o != NIL && L.node[o].pos > win) ? NIL : o;
 }
 // nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front)
-template <class LT> RS_DEV int leader_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
+template <class LT> RS_DEV int leader_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(L, pos, ncell);
     int Ld = NIL, Lk = 0;
     float Lp = 0.0f;
-    for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD        // my own cell first
+    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD        // my own cell first
         const Node nd = L.node[s];
         const int cur = s;
         s = nd.nxt;
@@ -473,17 +502,17 @@ template <class LT> RS_DEV int leader_within(const LT &L, const uint16_t *grid, 
     }
     if (Ld == NIL && c + 1 < ncell) {
         const int cc = scan_up(grid, cell0 + c + 1, cell0 + cell_of(L, pos + win, ncell));
-        if (cc >= 0) { Ld = chain_rearmost(L, grid[cc]); Lp = L.node[Ld].pos; }
+        if (cc >= 0) { Ld = chain_rearmost(L, cell_head(grid, cc)); Lp = L.node[Ld].pos; }
     }
     if (Ld != NIL && Lp - pos > win) Ld = NIL;
     return Ld;
 }
 // nearest vehicle behind (pos, k) on the lane (not `self`), at most `win` metres away
-template <class LT> RS_DEV int follower_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float win) {
+template <class LT> RS_DEV int follower_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(L, pos, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
-    for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD
+    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         const int cur = s;
         s = nd.nxt;
@@ -493,18 +522,18 @@ template <class LT> RS_DEV int follower_within(const LT &L, const uint16_t *grid
     if (Fd == NIL && c > 0) {
         const float lo = pos - win;
         const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) { Fd = chain_frontmost(L, grid[cc]); Fp = L.node[Fd].pos; }
+        if (cc >= 0) { Fd = chain_frontmost(L, cell_head(grid, cc)); Fp = L.node[Fd].pos; }
     }
     if (Fd != NIL && pos - Fp > win) Fd = NIL;
     return Fd;
 }
 // nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
-template <class LT> RS_DEV int at_or_behind_within(const LT &L, const uint16_t *grid, int cell0, int ncell, float back, float win) {
+template <class LT> RS_DEV int at_or_behind_within(const LT &L, const Grid &grid, int cell0, int ncell, float back, float win) {
     if (back < 0.0f) return NIL;
     const int c = cell_of(L, back, ncell);
     int Fd = NIL, Fk = 0;
     float Fp = 0.0f;
-    for (int s = grid[cell0 + c] & NIL; s != NIL;) { RS_CHAIN_GUARD
+    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
         const Node nd = L.node[s];
         if (!(nd.pos > back) && (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk))) { Fd = s; Fk = nd.trip; Fp = nd.pos; }
         s = nd.nxt;
@@ -512,7 +541,7 @@ template <class LT> RS_DEV int at_or_behind_within(const LT &L, const uint16_t *
     if (Fd == NIL && c > 0) {
         const float lo = back - win;
         const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) { Fd = chain_frontmost(L, grid[cc]); Fp = L.node[Fd].pos; }
+        if (cc >= 0) { Fd = chain_frontmost(L, cell_head(grid, cc)); Fp = L.node[Fd].pos; }
     }
     if (Fd != NIL && back - Fp > win) Fd = NIL;
     return Fd;
@@ -530,7 +559,7 @@ RS_DEV uint16_t cache_link(const KTab &T, const LaneRec &LR, int lane, int rq, i
     if (LR.flags & LF_INTERNAL) { const int l = LR.link_start; return (uint16_t)(l | (T.links()[l].arr_idx >= 0 ? NLINK_ARR : 0)); }
     return T.next_link()[((size_t)rq * T.kmax + (lane - (int)LR.edge_lane0)) * 2 + (trip & 1)];
 }
-template <class LT> RS_DEV bool foe_blocked(const KTab &T, const LT &L, const uint16_t *grid, const LinkRec &K) {
+template <class LT> RS_DEV bool foe_blocked(const KTab &T, const LT &L, const Grid &grid, const LinkRec &K) {
     for (int i = K.foe_start; i < K.foe_start + K.foe_cnt; ++i) {
         const FoeRec F = T.foes()[i];
         if (F.tls != 0xFF && tls_state(T, L, F.tls, F.tls_pos) == TLS_R) continue;
@@ -595,9 +624,9 @@ RS_DEV float cont_of(const ContRow &R, int j) {
 // `grid` is the tick's grid and cell0 / nc the cell block of lane kk (the blocks of an edge's lanes are consecutive and
 // equally sized).  OCC_NONE / OCC_FULL instead of a grid: assume that lane empty / full -- the bounds the scheduling hints
 // are computed with while the next tick's grid is still being built.
-#define OCC_NONE ((const uint16_t *)0)
-#define OCC_FULL ((const uint16_t *)1)
-RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int extra, float &rem, const uint16_t *grid, int cell0, int nc, float occ_unit) {
+#define OCC_NONE (Grid{(uint16_t *)0, 0u})
+#define OCC_FULL (Grid{(uint16_t *)1, 0u})
+RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int extra, float &rem, const Grid &grid, int cell0, int nc, float occ_unit) {
     float best = 0.0f;
     for (int j = 0; j < n; ++j) { const float c = cont_of(R, j); if (c > best) best = c; }
     const float mine = cont_of(R, kk);
@@ -607,11 +636,11 @@ RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int 
     for (int j = kk + 1; j < n; ++j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dl = j - kk; break; }
     for (int j = kk - 1; j >= 0; --j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dr = kk - j; break; }
     const int dir = (dr <= dl) ? -1 : +1;
-    if (grid == OCC_FULL) return dir;
+    if (grid.c == (uint16_t *)1) return dir;
     const int off = (dr <= dl ? dr : dl) + extra;
     const float la = (v > RM_LOOK_MIN_SPEED ? v : RM_LOOK_MIN_SPEED) * RM_LOOK_TIME + RM_LOOK_BASE;
     int cnt = 0;
-    if (grid != OCC_NONE) cnt = cells_count(grid, cell0 + ((dr <= dl) ? -dr : dl) * nc, nc);
+    if (grid.c != (uint16_t *)0) cnt = cells_count(grid, cell0 + ((dr <= dl) ? -dr : dl) * nc, nc);
     if (rem - (float)cnt * occ_unit >= la * (float)off) return 0;
     return dir;
 }
@@ -711,7 +740,7 @@ template <class LT> RS_DEV int classify(const LT &L, int s, const float *vt, flo
 // P: plan (Krauss car-following + links) for slot s.  LONG = false: the short path, for a vehicle WITHOUT FL_H -- nothing beyond
 // the end of its lane is inside its look-ahead (classify() decided that on the very state this plan sees; the host emulation
 // checks it) --, so the walk over the links is not compiled into what the waves on the short path run.
-template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L, const uint16_t *grid, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
+template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, const KParams &P, int genv, int t, int s) {
     RS_SEC_BEGIN
     const Aux ax = L.aux[s];
     const int lane = ax.lane;
@@ -837,7 +866,7 @@ template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L
 
 // M: move slot s -- sideways first (the lane change decided in the plan phase), then forward, over to the next lanes, or
 // out of the network; leave the old grid, enter the new one; register the approach of the coming tick
-template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L, uint16_t *gold, uint16_t *gnew, const State &G, const KParams &P, int env, size_t eo,
+template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L, const Grid &gnew, const State &G, const KParams &P, int env, size_t eo,
                        int t, bool last_tick, bool more, int s, int &active, int &halted, int &top) {
     const Aux ax = L.aux[s];
     const Node me = L.node[s];
@@ -860,7 +889,6 @@ template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L
     const int sw = ax.swait;
     int swn = sw;
     const float vn = L.vnx[s];
-    gold[LR.cell0 + cell_of(L, me.pos, lane_cells(L, LR))] = NIL;         // every vehicle of a cell stores the same: the old grid empties
     int rq = ax.rq;
     uint16_t nlink = ax.nlink;              // the link after the lane the vehicle ends up on, as cache_link() returns it
     int link = (int)(nlink & 0x7FFF);
@@ -950,7 +978,7 @@ template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L
 
 // the vehicle on the lane with cells [cell0, cell0 + ncell) whose body overlaps the one at (pos, k) lengthwise (the nearer one
 // ahead first), NIL: none
-template <class LT> RS_DEV int overlapping(const LT &L, const uint16_t *grid, int cell0, int ncell, float pos, int k, int self, float len_self) {
+template <class LT> RS_DEV int overlapping(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float len_self) {
     const int lead = leader_within(L, grid, cell0, ncell, pos, k, self, RM_NB_WINDOW);
     if (lead != NIL && L.node[lead].pos - L.vtp[L.node[lead].vt * VT_COLS + VT_LENGTH] - pos < 0.0f) return lead;
     const int foll = follower_within(L, grid, cell0, ncell, pos, k, self, RM_NB_WINDOW);
@@ -960,7 +988,7 @@ template <class LT> RS_DEV int overlapping(const LT &L, const uint16_t *grid, in
 
 // The lane-change decision of slot s on the state at the beginning of the tick: returns LCT_* (0: stay).  A blocked strategic
 // changer asks for cooperation; a mutual block is swapped out (oracle: lane_change())
-template <class LT> RS_DEV int phase_lc_decide(const KTab &T, const LT &L, const uint16_t *grid, const State &G, size_t eo, int t, int s, const Aux &ax, const Node &me) {
+template <class LT> RS_DEV int phase_lc_decide(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, int t, int s, const Aux &ax, const Node &me) {
     const int lane = ax.lane;
     // (everything the decision may need from global memory is requested at once)
     const LaneRec LR = T.lanes()[lane];
@@ -1056,7 +1084,7 @@ template <class LT> RS_DEV int phase_lc_decide(const KTab &T, const LT &L, const
 
 // C: does the oldest waiting trip of departure lane d get onto the network in tick t?  The space on its lane is judged
 // AFTER this tick's move of the vehicles that are on it now -- their next speeds are known (oracle: insertion_check)
-template <class LT> RS_DEV bool phase_insert_decide(const KTab &T, const LT &L, const uint16_t *grid, int t, int d) {
+template <class LT> RS_DEV bool phase_insert_decide(const KTab &T, const LT &L, const Grid &grid, int t, int d) {
     if ((int)L.dep_t[d] > t) return false;           // nothing due on this lane (the common case: no global access)
     const int k = L.dep[d];
     // (one 8-byte record per departure lane instead of lane id -> lane record: the two loads of this check are independent)
@@ -1067,7 +1095,7 @@ template <class LT> RS_DEV bool phase_insert_decide(const KTab &T, const LT &L, 
     const int nc = (int)(LR.len * L.cell_inv) + 1;      // lane_cells(L, )
     const int c1 = LR.cell0 + cell_of(L, mypos + vt[VT_MINGAP] + T.maxlen, nc);
     for (int c = scan_up(grid, LR.cell0, c1); c >= 0; c = (c < c1 ? scan_up(grid, c + 1, c1) : -1))
-        for (int o = grid[c] & NIL; o != NIL;) { RS_CHAIN_GUARD
+        for (int o = cell_head(grid, c); o != NIL;) { RS_CHAIN_GUARD
             const Node od = L.node[o];
             const float back = (od.pos + L.vnx[o]) - L.vtp[od.vt * VT_COLS + VT_LENGTH];
             if (back - mypos - vt[VT_MINGAP] < 0.0f) return false;
@@ -1102,13 +1130,13 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
     const size_t eo = (size_t)env * C;
     const int n_ticks = P.n_ticks;
 
-    uint16_t *const grid0 = L.grid, *const grid1 = grid0 + L.gstride;
+    uint16_t *const grid0 = L.grid;
 
     // ---- L0: scalars, tables, TLS, backlog heads
     ex.phase(0, [&](int tid) {
         if (tid < SC_STATS + ST_N) L.sc[tid] = tid < 4 ? G.env[env * 4 + tid] : 0;
         for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold.vtype_params[i];
-        for (int i = tid; i < (int)L.gstride; i += B) ((uint32_t *)grid0)[i] = 0x07FF07FFu;      // both grids: 2 * gstride cells
+        for (int i = tid; i < (int)(L.gstride >> 1); i += B) ((uint32_t *)grid0)[i] = 0x07FF07FFu;      // every cell empty (tag 0)
         for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
         for (int i = tid; i < (C + 31) / 32; i += B) L.alive[i] = 0u;
         for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
@@ -1146,7 +1174,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
             // the speed factor is a function of (seed, environment, trip): recomputed here (four hashes per vehicle and ENV-STEP) instead of
             // read back -- 4 B per slot and step less from HBM; RS_BUF_VEH_SF is written at the insertion, for whoever reads it
             nn.fl = 0; nn.sfq = (uint16_t)speed_factor_q(P, genv, tr, L.vtp + nn.vt * VT_COLS);
-            nn.nxt = grid_push(grid0, LR0.cell0 + cell_of(L, x, lane_cells(L, LR0)), s, sp > RM_HALT_SPEED);
+            nn.nxt = grid_push(Grid{grid0, 0u}, LR0.cell0 + cell_of(L, x, lane_cells(L, LR0)), s, sp > RM_HALT_SPEED);
             if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, sf_of(nn.sfq), L.sc[SC_T]);
             L.node[s] = nn;
             rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
@@ -1186,7 +1214,8 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
     int cur = 0;
     for (int tick = 0; tick < n_ticks; ++tick) {
         const int t = L.sc[SC_T], hw = L.sc[cur ? SC_HWNEW : SC_HW];
-        uint16_t *const gold = cur ? grid1 : grid0, *const gnew = cur ? grid0 : grid1;
+        // the grid as this tick reads it (the cells tagged with its parity) and as its move phase builds it for the next one
+        const Grid gold{grid0, cur ? CELL_TAG : 0u}, gnew{grid0, cur ? 0u : CELL_TAG};
         const bool more = tick + 1 < n_ticks;
         const int lcap = (int)L.lcap;
         const int nwv = B >> 6;
@@ -1246,6 +1275,15 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
         ex.phase(5, [&](int tid) {
             for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
             for (int i = tid; i < (C + 31) / 32; i += B) L.alive0[i] = L.alive[i];
+            // the cells that still carry the tag the move phase is about to push with hold what was valid a tick ago (nobody read
+            // them in this tick): they are emptied now, so that every cell of that tag the move meets is one it has filled itself.
+            // (Readers of this phase are not disturbed: the cells of their tag are written back as they are.)
+            for (int i = tid; i < (int)(L.gstride >> 2); i += B) {
+                unsigned long long *q = (unsigned long long *)grid0 + i;
+                const unsigned long long w = *q;
+                const unsigned long long st = ((w ^ grid_tag4(gold)) >> 15) & 0x0001000100010001ull;    // 1: the cell carries the other tag
+                if (st) { const unsigned long long m = st * 0xFFFFull; *q = (w & ~m) | ((0x07FF07FF07FF07FFull | grid_tag4(gold)) & m); }
+            }
             for (int d = B - 1 - tid; d < T.n_dep; d += B)
                 if (phase_insert_decide(T, L, gold, t, d)) rs_atomic_or(&L.insm[d >> 5], 1u << (d & 31));
             if (more)
@@ -1278,14 +1316,14 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
                 if (c < mch) {
                     list = true;
                     const int w = c * RS_LIST_CHUNK + ln;
-                    if (ln < RS_LIST_CHUNK && w < nmh) phase_move<true>(T, L, gold, gnew, G, P, env, eo, t, !more, more, L.ls_mh[w], active, halted, top);
+                    if (ln < RS_LIST_CHUNK && w < nmh) phase_move<true>(T, L, gnew, G, P, env, eo, t, !more, more, L.ls_mh[w], active, halted, top);
                 } else if (c < mch + ich) {
                     // the winners of the departure lanes take the slots that were free at the beginning of the tick, lower lane first
                     for (int d = 63 - ln; d < T.n_dep; d += 64) {
                         if (!(L.insm[d >> 5] & (1u << (d & 31)))) continue;
                         int rank = rs_popc(L.insm[d >> 5] & ((1u << (d & 31)) - 1u));
                         for (int w = 0; w < (d >> 5); ++w) rank += rs_popc(L.insm[w]);
-                        if (rank >= L.sc[SC_ROOM]) continue;            // the network is full
+                        if (rank >= L.sc[SC_ROOM]) { rs_atomic_add(&L.sc[SC_STATS + ST_CAP_BLOCKED], 1); continue; }    // the network is full: counted, the trip stays in its backlog
                         const int s = nth_free_slot(L, C, rank);
                         if (s < 0) continue;
                         const int k = L.dep[d];
@@ -1322,8 +1360,8 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
                     const int w = (c - mch - ich) * 64 + ln;
                     // (the vehicles of the list have FL_MH of this tick's parity set: their chunk moves them)
                     if (w < hw && (L.alive0[w >> 5] & (1u << (w & 31)))) {
-                        if (all) phase_move<true>(T, L, gold, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
-                        else if (!(L.node[w].fl & fl_mh(t))) phase_move<false>(T, L, gold, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
+                        if (all) phase_move<true>(T, L, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
+                        else if (!(L.node[w].fl & fl_mh(t))) phase_move<false>(T, L, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
                     }
                 }
             }

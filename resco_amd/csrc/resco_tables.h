@@ -12,16 +12,21 @@
 
 enum { VT_LENGTH, VT_MINGAP, VT_ACCEL, VT_DECEL, VT_TAU, VT_SIGMA, VT_MAXSPEED, VT_SF_MEAN, VT_SF_DEV, VT_EMERGENCY, VT_COLS };
 enum { TLS_R = 0, TLS_Y = 1, TLS_g = 2, TLS_G = 3 };
-enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, ST_ACTIVE, ST_PENDING, ST_ACTIVE_TICKS, ST_TICKS, ST_N };
+enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, ST_ACTIVE, ST_PENDING, ST_ACTIVE_TICKS, ST_TICKS, ST_CAP_BLOCKED, ST_N };
 
 #define LANE_NONE 0xFFFFu
 #define OWNER_NONE 0xFFu
 #define NIL 0x7FF               /* empty grid cell / end of a cell chain (11-bit slot ids) */
-// a grid cell (16 bits): bits 0..10 the head slot of its chain (NIL: empty), bits 11..14 the number of vehicles in it
-// (saturating; a CELL_LEN-metre cell cannot hold 15), bit 15 = it holds a moving vehicle
+// a grid cell (16 bits): bits 0..10 the head slot of its chain (NIL: empty), bits 11..13 the number of vehicles in it
+// (saturating at 7: the cell length is chosen so that a cell cannot hold more fronts, see PackedTables::build), bit 14 = it holds a
+// moving vehicle, bit 15 = the TAG: the parity of the tick the contents are valid for.  There is ONE grid: the move of tick t pushes
+// the vehicles into it with the tag of tick t + 1, and whoever reads or pushes takes a cell that carries the other tag for empty
+// (resco_step.h: Grid).  Round 6: the second grid of rounds 1-5 (9 KB of working memory for ingolstadt21) is what stood between
+// three and four workgroups per CU.
 #define CELL_CNT_SHIFT 11
-#define CELL_CNT_MAX 15u
-#define CELL_MOVER 0x8000u
+#define CELL_CNT_MAX 7u
+#define CELL_MOVER 0x4000u
+#define CELL_TAG 0x8000u
 #define ARR_NONE 65535
 #define COOP_NONE 0xFFFFFFFFu
 #define TRIP_NONE 0xFFFFu
@@ -30,14 +35,18 @@ enum { ST_INSERTED, ST_ARRIVED, ST_DURATION, ST_DEPDELAY, ST_WAITING, ST_TLOSS, 
 // a cell holds the slot of a vehicle whose front is inside it (more than one: a short chain).  Every neighbour search of
 // the model is a bounded scan over a few consecutive cells.
 // The cell length is chosen per scenario when a handle is created (pick_cell_len, resco_step.h): the shortest of CELL_CHOICES with which the
-// working memory of an environment still lets three workgroups share a CU -- shorter cells mean shorter chains (30 m instead of
-// 32 m: +1.8 % on ingolstadt21 x 4096, profiles/r05_ab_cells.txt), one cell too many means two workgroups per CU (-25 %).
+// working memory of an environment lets FOUR workgroups share a CU -- or, failing that, three -- (resco_tables.h); shorter cells mean
+// shorter chains (30 m instead of 32 m: +1.8 % on ingolstadt21 x 4096, profiles/r05_ab_cells.txt), one workgroup less per CU costs
+// 15-25 %.
 #ifdef CELL_LEN                 // (study builds: one fixed length)
 #define CELL_CHOICES {CELL_LEN}
 #else
 #define CELL_CHOICES {30.0f, 32.0f, 36.0f, 40.0f, 48.0f}
 #endif
-#define RS_LDS_3WG_LIMIT 53760  // bytes of LDS per workgroup up to which three of them fit one CU of the MI355X (measured: 53 664 three, 53 824 two)
+// bytes of LDS per workgroup up to which three / four of them fit one CU of the MI355X: 160 KiB in granules of 1280 bytes (measured in
+// round 5: 53 664 three, 53 824 two; round 6: 40 960 = 32 granules four)
+#define RS_LDS_3WG_LIMIT 53760
+#define RS_LDS_4WG_LIMIT 40960
 
 // ---- 16-byte records: one global_load_dwordx4 fetches everything about a lane / foe / route
 struct __attribute__((aligned(16))) LaneRec {
@@ -173,7 +182,7 @@ struct PackedTables {
     std::vector<int32_t> obs_sig;
     int n_cells = 0, n_arr = 1, n_dep = 1, kmax = 1, lmax = 1, tls_maxl = 1;
     float maxlen = 0.0f, occ_unit = 0.0f;
-    float cell_len = 32.0f, cell_inv = 1.0f / 32.0f;       // grid cell length of this build of the tables (pick_cell_len)
+    float cell_len = 30.0f, cell_inv = 1.0f / 30.0f;       // grid cell length of this build of the tables (pick_cell_len)
     std::string err;
 
     // the link a vehicle on normal lane `ln` takes towards route step q + 1 (oracle/resco_oracle.c choose_link restated
@@ -207,7 +216,18 @@ struct PackedTables {
         return n;
     }
 
-    bool build(const rs_scenario *sc, float cell_len_ = 32.0f) {
+    // can a grid of `len`-metre cells count the vehicles of this scenario?  (the 3-bit counter of a cell saturates at 7, the oracle's
+    // per-lane count is exact: a vehicle type must not be so short that a cell could hold more fronts than that -- in a standing
+    // queue, length + minGap apart, with one to spare, and bumper to bumper, what an urgent lane change accepts, at all)
+    static bool cell_len_ok(const rs_scenario *sc, float len_) {
+        for (int v = 0; v < sc->n_vtypes; ++v) {
+            const float len = sc->vtype_params[v * VT_COLS + VT_LENGTH], unit = len + sc->vtype_params[v * VT_COLS + VT_MINGAP];
+            if (!(len > 0.0f) || (int)(len_ / unit) + 1 >= (int)CELL_CNT_MAX || (int)(len_ / len) + 1 > (int)CELL_CNT_MAX) return false;
+        }
+        return true;
+    }
+
+    bool build(const rs_scenario *sc, float cell_len_ = 30.0f) {
         cell_len = cell_len_; cell_inv = 1.0f / cell_len_;
         if (sc->n_lanes >= 0xFFFE || sc->n_trips >= 0xFFFF || sc->n_routes > 0xFFFF || sc->n_vtypes > 255 || sc->n_signals > 254) {
             err = "scenario exceeds id widths (lanes/trips/routes u16, vtypes/signals u8)"; return false;
@@ -232,13 +252,8 @@ struct PackedTables {
             occ_unit = (sc->vtype_params[best * VT_COLS + VT_LENGTH] + sc->vtype_params[best * VT_COLS + VT_MINGAP]) * RM_OCC_FACTOR;
         }
         if (sc->capacity >= NIL) { err = "capacity exceeds the 11-bit slot ids of the grid cells"; return false; }
-        // the 4-bit vehicle counter of a grid cell saturates at 15 (the oracle's per-lane count is exact): refuse vehicle types
-        // so short that a CELL_LEN-metre cell could hold that many fronts bumper to bumper
-        for (int v = 0; v < sc->n_vtypes; ++v) {
-            const float unit = sc->vtype_params[v * VT_COLS + VT_LENGTH] + sc->vtype_params[v * VT_COLS + VT_MINGAP];
-            if (!(unit > 0.0f) || (int)(cell_len / unit) + 1 >= (int)CELL_CNT_MAX) {
-                err = "a vehicle type is too short for the grid cells: floor(cell length / (length + minGap)) + 1 must stay below 15"; return false;
-            }
+        if (!cell_len_ok(sc, cell_len)) {
+            err = "a vehicle type is too short for the grid cells: floor(cell length / (length + minGap)) + 1 must stay below 7 (and floor(cell length / length) + 1 at or below 7)"; return false;
         }
         std::vector<int16_t> link_arr((size_t)sc->n_links, -1);
         int n_foe_targets = 0;

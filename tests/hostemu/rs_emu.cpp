@@ -144,6 +144,7 @@ static void run_step(rs_sim *h, int n_ticks, int do_fsm, int do_observe = 1) {
         switch (h->K.capacity) {
             case 128: rs_step_body<128>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
             case 256: rs_step_body<256>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
+            case 896: rs_step_body<896>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
             case 1024: rs_step_body<1024>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
             default: rs_step_body<0>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;
         }

@@ -81,7 +81,7 @@ def test_table_consistency():
         assert (cont[np.arange(len(nl)), 0] >= A['lane_len'][A['edge_lane0'][A['route_edge']]] - 1e-3).all()
         # internal lanes have exactly one outgoing link
         assert (A['lane_link_cnt'][A['lane_internal'] == 1] == 1).all()
-        assert sc.capacity & (sc.capacity - 1) == 0
+        assert sc.capacity % 64 == 0 and 64 <= sc.capacity <= 1984
 
 
 # ------------------------------------------------------------------------------------------------ tables every checker shares

@@ -18,6 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF = os.environ.get('RESCO_REFERENCE', '/root/reference')
 MAPS = ['cologne1', 'cologne3', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21']
+# vehicle slots per environment where the compiler's rule (next power of two above 4 x the free-flow concurrency) is overridden.
+# ingolstadt21: the rule gives 1024; 896 is the largest capacity whose working memory (40 768 B) lets FOUR workgroups share a CU
+# of the MI355X (+14 % env-steps/s, profiles/r06_ab_occupancy.txt).  Peak number of vehicles on the network over whole episodes
+# (oracle, four environments each): FIXED 590, STOCHASTIC 610-740, MAXWAVE / MAXPRESSURE with the repaired valid_acts 340 / 570;
+# the as-configured MAXWAVE / MAXPRESSURE cells (known gaps: one approach never gets green) reach 870 / 1024 -- they ran into the
+# limit of 1024 as well.  Trips that find the network full wait in their backlog and are counted (stats: `cap_blocked`).
+CAPACITY = {'ingolstadt21': 896}
 
 
 def load_ref_module(rel, name):
@@ -53,7 +60,7 @@ def main():
         mc = mc_mod.map_configs[m]
         cfgpath = os.path.join(REF, 'resco_benchmark', mc['net'])
         sc = compile_from_sumocfg(m, cfgpath, sc_mod.signal_configs[m], lights=mc['lights'],
-                                  yellow_length=mc['yellow_length'])
+                                  yellow_length=mc['yellow_length'], capacity=CAPACITY.get(m))
         sc.save(os.path.join(ROOT, 'resco_amd', 'scenarios', m + '.npz'))
         print(m, 'lanes', sc.n_lanes, 'links', sc.n_links, 'edges', sc.n_edges, 'routes', sc.n_routes,
               'trips', sc.n_trips, 'dropped', sc.dropped_trips, 'signals', sc.n_signals, 'obs', sc.n_obs,
