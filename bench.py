@@ -85,8 +85,8 @@ def pmc_traffic(args, n_local, world):
     (tools/pmc_passes.sh <tag> K W -> profiles/r03_pmc_s<K>_w<W>.json), so a figure is reported only when a committed
     summary exists for this run's --steps / --warmup on the default workload AND was measured on the kernel sources that are
     running now (source hash); otherwise None, with the reason."""
-    path = os.path.join(ROOT, 'profiles', 'r05_pmc_s%d_w%d.json' % (args.steps, args.warmup))
-    default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0 and args.pipes == DEFAULT_PIPES
+    path = os.path.join(ROOT, 'profiles', 'r06_pmc_s%d_w%d.json' % (args.steps, args.warmup))
+    default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0 and args.pipes == DEFAULT_PIPES and args.tls_expiry == 0
     if not default_workload or not os.path.exists(path):
         return None, ('HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_passes.sh); '
                       'there is no committed summary for this workload / window (%s)' % os.path.basename(path))
@@ -337,6 +337,9 @@ def main():
     ap.add_argument('--block', type=int, default=0, help='threads per workgroup (0 = library default)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tls-expiry', type=int, default=0, choices=(0, 1),
+                    help='rs_params.tls_expiry: 0 (default) a phase set through setPhase stays, 1 it expires after its programme duration '
+                         '(SUMO\'s documented setPhase); the headline figure is reported for both (profiles/r06_bench_both_modes.txt)')
     ap.add_argument('--digest', action='store_true', help='add a digest of the final per-environment state (all ranks, global env order)')
     args = ap.parse_args()
 
@@ -383,7 +386,7 @@ def main():
         raise SystemExit('--envs must be a multiple of --pipes')
     per = n_local // args.pipes
     sims = [BatchedSim(sc, per, device=local, seed=args.seed, sigma=-1.0, speed_dev=1, env_base=env_base + i * per,
-                       block_threads=args.block, device_envs=n_local) for i in range(args.pipes)]
+                       block_threads=args.block, device_envs=n_local, tls_expiry=args.tls_expiry) for i in range(args.pipes)]
     sim = sims[0]
     # BASELINE config 3 / SURVEY 8(d): "state fns computed every step: lane aggregates -> drq_norm + mplight; rewards wait +
     # pressure" -- only what those consume is written (the per-signal rewards and metrics always are)
@@ -432,7 +435,7 @@ def main():
         'config': {'workload': '%s x %d lock-step envs per GPU (BASELINE config 3), fixed demand from the map\'s '
                                'rou.xml, on-device seeded random policy, Krauss sigma 0.5 + speedFactor dev 0.1'
                                % (args.map, n_local),
-                   'map': args.map, 'envs_per_gpu': n_local, 'pipes': args.pipes, 'ticks_per_env_step': 10,
+                   'tls_expiry': args.tls_expiry, 'map': args.map, 'envs_per_gpu': n_local, 'pipes': args.pipes, 'ticks_per_env_step': 10,
                    'episode_window': [w0, w0 + args.steps], 'untimed_fast_forward_steps': w0 - args.warmup,
                    'block_threads': info['block_threads'], 'lds_bytes_per_env': info['lds_bytes'],
                    'outputs_per_step': list(OUTPUTS) + ['wait', 'wait_norm', 'pressure', 'phase', 'queue_sum', 'queue_max', 'arrivals', 'departures'],

@@ -194,7 +194,7 @@ enum rs_buffer {
     RS_BUF_VEH_RWAIT,      /* u16 [N][C]  RESCO Signal.waiting_times value (s), 0 = not in the dict */
     RS_BUF_VEH_DEPART,     /* u16 [N][C] */
     RS_BUF_VEH_OWNER,      /* u8  [N][C]  index of the signal that observed the vehicle last, 0xFF none */
-    RS_BUF_STATS,          /* i64 [N][11] see rs_stats */
+    RS_BUF_STATS,          /* i64 [N][12] see rs_stats */
     RS_BUF_DRQ_NORM_F16,   /* f16 [N][S][Lmax][5] zero padded states.drq_norm (IDQN rollout layout) */
     RS_BUF_VEH_SF,         /* f32 [N][C]  per-vehicle speedFactor (written at the insertion; the kernel does not read it back) */
     RS_BUF_VEH_WTOT,       /* u16 [N][C]  total halted seconds of the trip so far (maintained only with trip_log) */
@@ -222,8 +222,10 @@ int rs_read_buffer(rs_handle h, int32_t which, void *host_dst, int64_t nbytes);
 /* per env: [0] inserted [1] arrived [2] sum duration(s) [3] sum departDelay(s) [4] sum waiting(s)
  * [5] sum timeLoss (1/1024 s) [6] active now [7] backlog: trips whose insertion was tried and has failed so far
  * [8] sum over ticks of active vehicles [9] ticks [10] insertions refused because all `capacity` slots of the environment were
- * taken (the trip stays in its backlog and enters later: non-zero means the run met the limit of the working memory) */
-int rs_stats(rs_handle h, int64_t *host_out /* [n_envs][11] */);
+ * taken (the trip stays in its backlog and enters later: non-zero means the run met the limit of the working memory)
+ * [11] violations of the step kernel's classification invariants, counted only by the checking build of the library
+ * (-DRS_DEVICE_ASSERT, libresco_sim_check.so); always 0 in the production build, which compiles the checks out */
+int rs_stats(rs_handle h, int64_t *host_out /* [n_envs][12] */);
 
 /* environment snapshots (device-resident copies of the SoA state) */
 int rs_snapshot(rs_handle h, void **snap);

@@ -175,4 +175,6 @@ class OracleEnv:
         lib().orc_stats(self._h, out)
         keys = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10',
                 'active', 'pending', 'active_ticks', 'ticks', 'cap_blocked']
-        return dict(zip(keys, [int(x) for x in out]))
+        d = dict(zip(keys, [int(x) for x in out]))
+        d['invariant'] = 0      # (resco_sim.h rs_stats [11]: the kernel's own classification invariants -- the oracle has no such notion)
+        return d

@@ -28,5 +28,21 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+CHECK_LIB = os.path.join(HERE, 'csrc', 'libresco_sim_check.so')
+
+
+def build_check_library(force=False):
+    """The CHECKING build: the step kernel's classification invariants (RS_ASSERT) counted on the device instead of compiled out
+    (rs_stats()[11]); one capacity (256 slots: cologne8, ingolstadt7, cologne3) so that it compiles in seconds.  Test infrastructure
+    of tests/test_gpu_parity.py::test_device_invariant_counter -- never loaded by the package."""
+    deps = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('resco_step.h', 'resco_tables.h', 'resco_policy.h')] + \
+           [os.path.join(ROOT, 'include', f) for f in ('resco_sim.h', 'resco_model.h')]
+    force = force or os.environ.get('GRAFT_FORCE_BUILD') == '1'
+    if not force and os.path.exists(CHECK_LIB) and all(os.path.getmtime(CHECK_LIB) >= os.path.getmtime(d) for d in deps):
+        return CHECK_LIB
+    subprocess.check_call([HIPCC] + FLAGS + ['-DRS_DEVICE_ASSERT', '-DRS_ONE_CAP=256', SRC, '-o', CHECK_LIB])
+    return CHECK_LIB
+
+
 if __name__ == '__main__':
     print(build_library(force=True, verbose=True))

@@ -80,6 +80,13 @@ __device__ unsigned long long *g_sec_prof;
 #define RS_SEC_BEGIN unsigned long long sec_t = wall_clock64();
 #define RS_SEC(id) { const unsigned long long sec_1 = wall_clock64(); if (g_sec_prof && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicAdd(&g_sec_prof[id], (sec_1 - sec_t) + (1ull << 40)); sec_t = wall_clock64(); }
 #endif
+#ifdef RS_DEVICE_ASSERT        // the CHECKING build (resco_amd/build.py: libresco_sim_check.so): the classification invariants of the step kernel -- a vehicle
+// without FL_H never needs the walk over the links, one without FL_MH never leaves its lane -- are counted per environment in
+// rs_stats()[11] instead of compiled out; tests/test_gpu_parity.py::test_device_invariant_counter holds the count at zero.  They rest
+// on classify() and the plan evaluating the same floating-point expressions to the same bits at different inline sites
+// (-ffp-contract=off): the one place where a compiler upgrade could silently skip a stop line.
+#define RS_ASSERT(c) if (!(c)) rs_atomic_add(&L.sc[SC_STATS + ST_INVARIANT], 1);     // (`L`: the working memory, in scope at every site)
+#endif
 #include "resco_step.h"
 #include "resco_policy.h"
 

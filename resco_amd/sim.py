@@ -24,7 +24,7 @@ OUTPUT_GROUPS = ('lane_agg', 'drq_norm', 'drq_norm_f16', 'lane_arrivals', 'mplig
 _NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64, np.uint32]
 _TYPESTR = ['<f4', '<i4', '<u2', '|u1', '<f2', '<i8', '<u4']
 STAT_KEYS = ['inserted', 'arrived', 'sum_duration', 'sum_depart_delay', 'sum_waiting', 'sum_time_loss_q10',
-             'active', 'pending', 'active_ticks', 'ticks', 'cap_blocked']
+             'active', 'pending', 'active_ticks', 'ticks', 'cap_blocked', 'invariant']
 TRIP_NONE = 0xFFFF
 
 # every symbol include/resco_sim.h declares

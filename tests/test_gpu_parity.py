@@ -1519,6 +1519,58 @@ def test_plain_bench_gpus_2_starts_two_ranks():
         assert r2.returncode != 0 and '{"metric"' not in r2.stdout
 
 
+def test_device_invariant_counter():
+    """The short paths of the plan and the move rest on two invariants of the classification (a vehicle without FL_H never needs the
+    walk over the links, one without FL_MH never leaves its lane), i.e. on classify() and the plan computing the same floating-point
+    expression to the same bits at different inline sites (-ffp-contract=off).  The host emulation asserts them; here the CHECKING
+    build of the very kernel (resco_amd/build.py: -DRS_DEVICE_ASSERT) counts violations ON THE DEVICE (rs_stats()[11]) over whole
+    episodes of two maps -- congested (random policy) and free-flowing (MAXPRESSURE) -- and the count must be zero; the same run
+    must still equal the oracle (the checks change nothing)."""
+    import subprocess
+    from resco_amd.build import CHECK_LIB, build_check_library
+    if not os.path.exists(CHECK_LIB):
+        build_check_library()
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import load_scenario
+from resco_amd.sim import BatchedSim
+from oracle.pyoracle import OracleEnv
+tot = 0
+for name, pol in (('cologne8', 'random'), ('ingolstadt7', 'maxpressure'), ('cologne3', 'random')):
+    sc = load_scenario(name)
+    sim = BatchedSim(sc, 64, seed=3)
+    o = OracleEnv(sc, env_index=5, seed=3, sigma=-1.0, speed_dev=1); o.observe()
+    for k in range(360):
+        if pol == 'random': sim.act_random(k)
+        else: sim.act_maxwave(1)
+        if k < 120:
+            sim.sync(); o.step(sim.read('actions')[5])
+        sim.step(None)
+        if k == 119:
+            v = o.vehicles(); live = v['lane'] != 0xFFFF
+            assert np.array_equal(sim.read('veh_lane')[5], v['lane']) and np.array_equal(sim.read('veh_pos')[5][live], v['pos'][live])
+    st = sim.stats()
+    assert st['ticks'].min() == 3600 and st['arrived'].min() > 0
+    print(name, pol, 'invariant violations', int(st['invariant'].sum()), 'vehicle-ticks', int(st['active_ticks'].sum()))
+    tot += int(st['invariant'].sum())
+    sim.close()
+print('TOTAL', tot)
+""" % (ROOT, os.path.join(ROOT, 'tests'))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, RESCO_SIM_LIB=CHECK_LIB), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    print(r.stdout)
+    assert r.stdout.strip().splitlines()[-1] == 'TOTAL 0'
+    # ... and the production build reports the slot as zero (the checks are compiled out)
+    from resco_amd.sim import BatchedSim
+    sim = BatchedSim(load_scenario('cologne1'), 4, seed=1)
+    for k in range(30):
+        sim.act_random(k)
+        sim.step(None)
+    assert (sim.stats()['invariant'] == 0).all() and 'cap_blocked' in sim.stats()
+    sim.close()
+
+
 def test_arrival_departure_counters_and_mplight_full_batched():
     """the batched outputs behind fma2c / mplight_full (RS_BUF_ARRIVALS / DEPARTURES / MPLIGHT_FULL) for N environments:
     equal to the oracle's for sampled environments, and consistent with the Signal views of environment 0"""
