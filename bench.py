@@ -86,7 +86,7 @@ def pmc_traffic(args, n_local, world):
     summary exists for this run's --steps / --warmup on the default workload AND was measured on the kernel sources that are
     running now (source hash); otherwise None, with the reason."""
     path = os.path.join(ROOT, 'profiles', 'r06_pmc_s%d_w%d.json' % (args.steps, args.warmup))
-    default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0 and args.pipes == DEFAULT_PIPES and args.tls_expiry == 0
+    default_workload = world == 1 and args.map == 'ingolstadt21' and n_local == 4096 and args.block == 0 and args.pipes == DEFAULT_PIPES and args.tls_expiry == 1
     if not default_workload or not os.path.exists(path):
         return None, ('HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_passes.sh); '
                       'there is no committed summary for this workload / window (%s)' % os.path.basename(path))
@@ -337,9 +337,10 @@ def main():
     ap.add_argument('--block', type=int, default=0, help='threads per workgroup (0 = library default)')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--tls-expiry', type=int, default=0, choices=(0, 1),
-                    help='rs_params.tls_expiry: 0 (default) a phase set through setPhase stays, 1 it expires after its programme duration '
-                         '(SUMO\'s documented setPhase); the headline figure is reported for both (profiles/r06_bench_both_modes.txt)')
+    ap.add_argument('--tls-expiry', type=int, default=1, choices=(0, 1),
+                    help='1 (default, rs_params.tls_hold = 0): a phase set through setPhase expires after its programme duration (SUMO\'s '
+                         'documented setPhase); 0: it stays until the next action (round 5\'s default: a heavier network, 469 instead of 421 '
+                         'vehicles per environment in the driver\'s window); the figure is reported for both (profiles/r06_bench_both_modes.txt)')
     ap.add_argument('--digest', action='store_true', help='add a digest of the final per-environment state (all ranks, global env order)')
     args = ap.parse_args()
 

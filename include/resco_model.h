@@ -67,7 +67,7 @@
 #define RM_SWAP_EVERY 4           /* ... looked for on every 4th tick only */
 #endif
 #define RM_BIGF 1.0e30f
-#define RM_TLS_HOLD_TICKS 0x3FFFFFFF   /* time left of a phase that does not expire (rs_params.tls_expiry = 0): more ticks than any run has */
+#define RM_TLS_HOLD_TICKS 0x3FFFFFFF   /* time left of a phase that does not expire (rs_params.tls_hold = 1): more ticks than any run has */
 #ifndef RM_OCC_FACTOR
 #define RM_OCC_FACTOR 1.0f        /* [SUMO-K] LC2013 JAM_FACTOR: weight of the target lane's occupation in the usable distance */
 #endif

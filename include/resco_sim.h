@@ -89,13 +89,18 @@ typedef struct rs_params {
                                * RESCO waiting rule still adds step_length per observe (traffic_signal.py:196).  0 or 1: one.
                                * A tick is always ONE second: a sub-second SUMO step length (what the reference uses step_ratio for)
                                * is not modelled -- k means k one-second ticks per step_sim() */
-    int32_t tls_expiry;       /* what trafficlight.setPhase (Signal.prep_phase / set_phase, traffic_signal.py:176-187) leaves behind:
-                               * 0 (default) the phase stays until the next setPhase; 1 it expires after its programme duration and the
-                               * programme continues with the next index, i -> i + 1 (mod P) -- what SUMO's setPhase is documented to do
-                               * [SUMO-K], under which a 6 s green chosen for a 10 s step hands its 7th second to the next phase of the list.
-                               * Neither is pinned against a SUMO binary; 0 is the default because it reproduces the reference-held
-                               * random-policy figures of five maps and 1 does not (profiles/r05_tls_expiry_bands.txt).
-                               * The net's own programme (fixed_program) and the phase installed at reset always run on their durations */
+    int32_t tls_hold;         /* what trafficlight.setPhase (Signal.prep_phase / set_phase, traffic_signal.py:176-187) leaves behind.
+                               * 0 (default): SUMO's setPhase -- the phase runs for its PROGRAMME DURATION and the programme then
+                               * continues with the next index, i -> i + 1 (mod P) (MSSimpleTrafficLightLogic::changeStepAndDuration
+                               * re-schedules the switch `duration` seconds ahead [SUMO-K]); the reference never resets a duration, so
+                               * a 6 s green chosen for a 10 s step hands its 7th second to the next phase of the list.
+                               * 1: the phase STAYS until the next setPhase -- round 5's calibration variant: it reproduces the
+                               * reference-held random-policy figures of five maps better (36 of 42 result cells inside +-35 % against
+                               * 29, profiles/r06_reference_bands_both_modes.txt), trained agents land on the same delays either way
+                               * (profiles/r06_heldout_both_modes.txt).  It was the default of round 5 (then: tls_expiry = 0); round 6
+                               * returns to the documented semantics.  Neither is pinned against a SUMO binary
+                               * (tools/sumo_runner.py diff decides it on a box that has SUMO).  The net's own programme
+                               * (fixed_program) and the phase installed at reset always run on their durations */
 } rs_params;
 
 typedef struct rs_sim *rs_handle;

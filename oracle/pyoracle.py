@@ -82,10 +82,10 @@ class OracleEnv:
     """One environment instance of the CPU oracle."""
 
     def __init__(self, scenario, env_index=0, seed=0, max_distance=200.0, sigma=0.0, speed_dev=0,
-                 fixed_program=0, step_length=10, yellow_length=None, trip_log=0, step_ratio=1, tls_expiry=0):
+                 fixed_program=0, step_length=10, yellow_length=None, trip_log=0, step_ratio=1, tls_expiry=1):
         self.sc = scenario
         self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
-        self._p = ParamsStruct(seed, max_distance, sigma, speed_dev, fixed_program, trip_log, step_ratio, int(tls_expiry))
+        self._p = ParamsStruct(seed, max_distance, sigma, speed_dev, fixed_program, trip_log, step_ratio, 0 if tls_expiry else 1)      # rs_params.tls_hold
         self._trip_log = trip_log
         self._h = lib().orc_create(C.byref(self._st), C.byref(self._p), env_index)
         self.S, self.O = scenario.n_signals, scenario.n_obs

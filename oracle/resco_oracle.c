@@ -352,9 +352,9 @@ void orc_set_phase(orc_env *e, int32_t sig, int32_t ph) {
     const orc_scenario *sc = e->sc;
     if (ph < 0 || ph >= sc->tls_nphase[sig]) return;
     e->phase[sig] = ph;
-    /* trafficlight.setPhase [SUMO-K, unpinned; see rs_params.tls_expiry]: with tls_expiry the phase runs for its programme duration and the
-     * programme then continues with the next index; without it (default) the phase stays until the next setPhase */
-    e->left[sig] = e->p.tls_expiry ? sc->tls_dur[sc->tls_dur_off[sig] + ph] : RM_TLS_HOLD_TICKS;
+    /* trafficlight.setPhase [SUMO-K, unpinned; see rs_params.tls_hold]: the phase runs for its programme duration and the programme then
+     * continues with the next index (default); with tls_hold the phase stays until the next setPhase */
+    e->left[sig] = e->p.tls_hold ? RM_TLS_HOLD_TICKS : sc->tls_dur[sc->tls_dur_off[sig] + ph];
 }
 
 /* ------------------------------------------------------------------ the tick */

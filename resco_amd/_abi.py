@@ -45,7 +45,7 @@ class ScenarioStruct(C.Structure):
 class ParamsStruct(C.Structure):
     _fields_ = [('seed', C.c_uint32), ('max_distance', C.c_float), ('sigma', C.c_float),
                 ('speed_dev', C.c_int32), ('fixed_program', C.c_int32), ('trip_log', C.c_int32), ('step_ratio', C.c_int32),
-                ('tls_expiry', C.c_int32)]
+                ('tls_hold', C.c_int32)]
 
 
 def pack_scenario(sc, step_length=10, yellow_length=None):

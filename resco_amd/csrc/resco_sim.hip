@@ -424,7 +424,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     const int lmax = PT.lmax;
 
     h->P.seed = p->seed; h->P.env_base = env_base; h->P.max_distance = p->max_distance; h->P.sigma = p->sigma;
-    h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.tls_expiry = p->tls_expiry != 0; h->P.n_envs = n_envs;
+    h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.tls_expiry = p->tls_hold == 0; h->P.n_envs = n_envs;
 
     const size_t N = (size_t)n_envs, NC = N * C, S = (size_t)sc->n_signals, NO = (size_t)sc->n_obs;
     State &G = h->G;

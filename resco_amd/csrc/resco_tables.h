@@ -146,7 +146,7 @@ struct KParams {
     int32_t env_base;
     float max_distance, sigma;
     int32_t speed_dev, fixed_program;
-    int32_t tls_expiry;     // rs_params.tls_expiry: 1 = a phase set through setPhase expires after its programme duration
+    int32_t tls_expiry;     // !rs_params.tls_hold: 1 = a phase set through setPhase expires after its programme duration (SUMO's setPhase, the default)
     int32_t n_ticks;        // ticks to simulate in this launch (0: observe only)
     int32_t do_fsm;         // apply prep_phase / set_phase around the ticks
     int32_t do_observe;     // 1: Signal.observe + states / rewards after the ticks; 0: only the state goes back (step_sim)

@@ -100,21 +100,21 @@ class MultiSignal(_EnvBase):
     """The reference's MultiSignal (resco_benchmark/multi_signal.py:10-216: same constructor, reset / step / close, attributes) on the
     HIP simulator; the keyword-only arguments after `gymma` are this package's.
 
-    **tls_expiry -- read this before comparing numbers with a SUMO run.**  What `trafficlight.setPhase` (Signal.prep_phase /
-    set_phase, traffic_signal.py:176-187) leaves behind is a PARAMETER of this simulator, and its default DEPARTS from what SUMO
-    documents: `tls_expiry=False` (default) keeps the phase an action selected until the next action; `tls_expiry=True` lets it run
-    for its programme duration and then continues with the next phase of the list -- SUMO's documented setPhase (the switch is
-    re-scheduled `duration` seconds ahead, MSSimpleTrafficLightLogic::changeStepAndDuration), under which a 6 s green chosen for a
-    10 s step hands its 7th second to the next index.  The default was chosen because it reproduces the reference-held random-policy
-    figures of five maps better (36 of 42 result cells inside +-35 % against 29, profiles/r06_reference_bands_both_modes.txt); it is
-    a calibration of this build's own traffic model, NOT a pin against a SUMO binary (`tools/sumo_runner.py diff` decides it on a box
-    that has SUMO).  Results, bench figures and the held-out IDQN check are reported for BOTH values (README).
+    **tls_expiry** -- what `trafficlight.setPhase` (Signal.prep_phase / set_phase, traffic_signal.py:176-187) leaves behind is a
+    parameter of this simulator (rs_params.tls_hold, inverted).  `tls_expiry=True` (default) is SUMO's documented setPhase: the phase
+    runs for its programme duration and the programme then continues with the next phase of the list (the switch is re-scheduled
+    `duration` seconds ahead, MSSimpleTrafficLightLogic::changeStepAndDuration), so a 6 s green chosen for a 10 s step hands its 7th
+    second to the next index.  `tls_expiry=False` keeps the selected phase until the next action: round 5's default, a calibration
+    of this build's own traffic model that reproduces the reference-held random-policy figures better (36 of 42 result cells inside
+    +-35 % against 29, profiles/r06_reference_bands_both_modes.txt) while trained agents reach the same delays either way
+    (profiles/r06_heldout_both_modes.txt).  Neither is pinned against a SUMO binary (`tools/sumo_runner.py diff` decides it on a box
+    that has SUMO); results, bench figures and the held-out IDQN check are reported for BOTH values (README).
     """
 
     def __init__(self, run_name, map_name, net, state_fn, reward_fn, route=None, gui=False, end_time=3600,
                  step_length=10, yellow_length=4, step_ratio=1, max_distance=200, lights=(), log_dir='/',
                  libsumo=False, warmup=0, gymma=False, *, device=0, seed=None, sigma=-1.0, speed_dev=1,
-                 fixed_program=False, scenario=None, use_fast_path=True, tripinfo=True, tls_expiry=False):
+                 fixed_program=False, scenario=None, use_fast_path=True, tripinfo=True, tls_expiry=True):
         if int(step_ratio) < 1:
             raise ValueError('step_ratio must be a positive integer')
         if int(step_ratio) > 1:
@@ -389,20 +389,20 @@ class VecMultiSignal:
     library-owned device buffers (the agent boundary), actions are an int32 [N, S] tensor or None (actions
     already written on device by act_random / act_maxwave).
 
-    **tls_expiry -- read this before comparing numbers with a SUMO run.**  What `trafficlight.setPhase` (Signal.prep_phase /
-    set_phase, traffic_signal.py:176-187) leaves behind is a PARAMETER of this simulator, and its default DEPARTS from what SUMO
-    documents: `tls_expiry=False` (default) keeps the phase an action selected until the next action; `tls_expiry=True` lets it run
-    for its programme duration and then continues with the next phase of the list -- SUMO's documented setPhase (the switch is
-    re-scheduled `duration` seconds ahead, MSSimpleTrafficLightLogic::changeStepAndDuration), under which a 6 s green chosen for a
-    10 s step hands its 7th second to the next index.  The default was chosen because it reproduces the reference-held random-policy
-    figures of five maps better (36 of 42 result cells inside +-35 % against 29, profiles/r06_reference_bands_both_modes.txt); it is
-    a calibration of this build's own traffic model, NOT a pin against a SUMO binary (`tools/sumo_runner.py diff` decides it on a box
-    that has SUMO).  Results, bench figures and the held-out IDQN check are reported for BOTH values (README).
+    **tls_expiry** -- what `trafficlight.setPhase` (Signal.prep_phase / set_phase, traffic_signal.py:176-187) leaves behind is a
+    parameter of this simulator (rs_params.tls_hold, inverted).  `tls_expiry=True` (default) is SUMO's documented setPhase: the phase
+    runs for its programme duration and the programme then continues with the next phase of the list (the switch is re-scheduled
+    `duration` seconds ahead, MSSimpleTrafficLightLogic::changeStepAndDuration), so a 6 s green chosen for a 10 s step hands its 7th
+    second to the next index.  `tls_expiry=False` keeps the selected phase until the next action: round 5's default, a calibration
+    of this build's own traffic model that reproduces the reference-held random-policy figures better (36 of 42 result cells inside
+    +-35 % against 29, profiles/r06_reference_bands_both_modes.txt) while trained agents reach the same delays either way
+    (profiles/r06_heldout_both_modes.txt).  Neither is pinned against a SUMO binary (`tools/sumo_runner.py diff` decides it on a box
+    that has SUMO); results, bench figures and the held-out IDQN check are reported for BOTH values (README).
     """
 
     def __init__(self, map_name, n_envs, states=('drq_norm',), rewards=('wait',), net=None, device=0, seed=0,
                  max_distance=200, step_length=10, yellow_length=3, sigma=-1.0, speed_dev=1, fixed_program=False,
-                 env_base=0, block_threads=0, scenario=None, outputs=None, step_ratio=1, tls_expiry=False):
+                 env_base=0, block_threads=0, scenario=None, outputs=None, step_ratio=1, tls_expiry=True):
         mc = map_configs.get(map_name, {})
         self.scenario = scenario if scenario is not None else load_scenario(map_name, net, mc.get('lights', ()),
                                                                             yellow_length)

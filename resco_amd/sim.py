@@ -189,7 +189,7 @@ class BatchedSim:
 
     def __init__(self, scenario, n_envs, device=0, seed=0, max_distance=200.0, sigma=-1.0, speed_dev=1,
                  fixed_program=0, env_base=0, step_length=10, yellow_length=None, block_threads=0, trip_log=0, step_ratio=1,
-                 tls_expiry=0, device_envs=None):
+                 tls_expiry=1, device_envs=None):
         """device_envs: how many environments share this GPU when the batch is split over several handles (pipes) -- the default
         workgroup shape (block_threads = 0) is chosen for the device's load, not for this handle's share (rs_default_block)"""
         self.sc = scenario
@@ -202,7 +202,7 @@ class BatchedSim:
             raise ValueError('scenario %s was compiled with yellow_length=%d (asked %d)' % (scenario.name, scenario.yellow_length, yellow_length))
         self._st, self._keep = pack_scenario(scenario, step_length, yellow_length)
         self._p = ParamsStruct(int(seed) & 0xFFFFFFFF, float(max_distance), float(sigma), int(speed_dev),
-                               int(fixed_program), int(trip_log), int(step_ratio), 1 if tls_expiry else 0)
+                               int(fixed_program), int(trip_log), int(step_ratio), 0 if tls_expiry else 1)     # rs_params.tls_hold
         self.step_ratio = max(1, int(step_ratio))
         self._h = C.c_void_p()
         if not block_threads and device_envs and int(device_envs) != self.n_envs and hasattr(self._lib, 'rs_default_block'):

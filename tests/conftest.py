@@ -16,7 +16,8 @@ WARM_CASES = ['ingolstadt21_d200_warm180', 'cologne8_d200_warm180']
 FULL_CASES = ['cologne1_d50_full']
 # MultiSignal(step_ratio=2): two simulation steps per step_sim() (multi_signal.py:102-105), driven by the reference's own loop
 RATIO_CASES = ['cologne8_d200_sr2']
-# rs_params.tls_expiry = 1 (a phase set through setPhase runs out after its programme duration; not the default)
+# tls_expiry = 1 (rs_params.tls_hold = 0: a phase set through setPhase runs out after its programme duration -- the library's default since
+# round 6; the cases WITHOUT the suffix were generated with tls_expiry = 0, round 5's default, and say so in their meta data)
 EXPIRY_CASES = ['cologne1_d200_exp', 'ingolstadt21_d200_exp', 'cologne8_d200_sr2_exp']
 ALL_CASES = HOT_CASES + WARM_CASES + FULL_CASES + RATIO_CASES + EXPIRY_CASES
 

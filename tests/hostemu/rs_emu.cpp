@@ -192,7 +192,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     K.horizon = sc->horizon; K.capacity = C; K.step_length = sc->step_length; K.yellow_length = sc->yellow_length * h->ratio; K.lmax = PT.lmax;
     K.n_arr = PT.n_arr; K.n_dep = PT.n_dep;
     h->P.seed = p->seed; h->P.env_base = env_base; h->P.max_distance = p->max_distance; h->P.sigma = p->sigma;
-    h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.tls_expiry = p->tls_expiry != 0; h->P.n_envs = n_envs;
+    h->P.speed_dev = p->speed_dev; h->P.fixed_program = p->fixed_program; h->P.tls_expiry = p->tls_hold == 0; h->P.n_envs = n_envs;
     const size_t N = (size_t)n_envs, NC = N * C, S = (size_t)sc->n_signals;
     h->G.nc = NC; h->slab.assign(State::bytes(NC), 0); h->G.base = h->slab.data();
     h->O.n = n_envs; h->O.o = sc->n_obs; h->O.s = sc->n_signals; h->O.lm = PT.lmax;

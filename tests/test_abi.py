@@ -57,7 +57,7 @@ def _struct_fields(text, name):
 
 
 def test_params_and_group_agent_layouts_match_header():
-    """rs_params (incl. tls_expiry, round 5) and rs_group_agent: the ctypes mirrors list the header's fields in header order, with
+    """rs_params (incl. tls_hold, round 6: the inverse of round 5's tls_expiry) and rs_group_agent: the ctypes mirrors list the header's fields in header order, with
     4-byte scalars and one pointer"""
     with open(os.path.join(ROOT, 'include', 'resco_sim.h')) as f:
         text = f.read()

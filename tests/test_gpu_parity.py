@@ -300,7 +300,7 @@ def test_device_agents_match_reference(tag):
     from resco_amd.sim import BatchedSim
     meta, g = load_golden(tag)
     sc = load_scenario(meta['map'])
-    sim = BatchedSim(sc, 3, seed=meta['seed'], max_distance=meta['max_distance'])
+    sim = BatchedSim(sc, 3, seed=meta['seed'], max_distance=meta['max_distance'], tls_expiry=meta.get('tls_expiry', 0))
     # env 0 is the golden environment; envs 1,2 differ (other RNG keys) and only have to stay in range
     for k in range(meta['steps'] + 1):
         sim.act_maxwave(1)
@@ -330,7 +330,7 @@ def test_fma2c_through_signal_views(tag):
     activate('FMA2C', meta['map'])
     env = MultiSignal('golden', meta['map'], mc['net'], states.fma2c, rewards.fma2c, yellow_length=3,
                       end_time=mc['end_time'], max_distance=meta['max_distance'], lights=mc['lights'],
-                      log_dir=tempfile.mkdtemp() + os.sep, seed=meta['base_seed'])
+                      log_dir=tempfile.mkdtemp() + os.sep, seed=meta['base_seed'], tls_expiry=bool(meta.get('tls_expiry', 0)))
     keys = meta['fma2c_keys']['fma2c']
     assert list(env.obs_shape.keys()) == keys and env.ts_order == keys
     assert len(env.action_space) == len(meta['all_ts_ids'])          # managers have no action space

@@ -169,8 +169,8 @@ def test_step_ratio_two_against_the_reference_s_own_loop():
     meta, g = load_golden('cologne8_d200_sr2')
     assert meta['step_ratio'] == 2
     sc = load_scenario('cologne8')
-    sim = EmuSim(sc, 1, order=2, seed=meta['seed'], max_distance=meta['max_distance'], step_ratio=2)
-    o = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1, step_ratio=2)
+    sim = EmuSim(sc, 1, order=2, seed=meta['seed'], max_distance=meta['max_distance'], step_ratio=2, tls_expiry=meta.get('tls_expiry', 0))
+    o = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1, step_ratio=2, tls_expiry=meta.get('tls_expiry', 0))
     o.observe()
     for k in range(meta['steps']):
         sim.step(g['actions'][k][None, :])
@@ -189,8 +189,8 @@ def test_warm_start_ticks_and_reinit_signals():
     the loaded-network golden of the reference's own Python at its first observe"""
     meta, g = load_golden('cologne8_d200_warm180')
     sc = load_scenario('cologne8')
-    sim = EmuSim(sc, 1, seed=meta['seed'], max_distance=meta['max_distance'])
-    o = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1)
+    sim = EmuSim(sc, 1, seed=meta['seed'], max_distance=meta['max_distance'], tls_expiry=meta.get('tls_expiry', 0))
+    o = OracleEnv(sc, env_index=0, seed=meta['seed'], max_distance=meta['max_distance'], sigma=-1.0, speed_dev=1, tls_expiry=meta.get('tls_expiry', 0))
     o.observe()
     for k in range(meta['preroll']):
         sim.act_random(k)

@@ -72,10 +72,10 @@ def test_parity_mode_is_deterministic_and_env_keyed():
 
 
 def test_fsm_duration_auto_advance():
-    """SURVEY 8(a) A7 [SUMO-K], rs_params.tls_expiry = 1: a 6 s green expires inside the 7 post-yellow ticks -> phase advances to
-    (a+1) % P."""
+    """SURVEY 8(a) A7 [SUMO-K], the default (rs_params.tls_hold = 0): a 6 s green expires inside the 7 post-yellow ticks -> phase advances
+    to (a+1) % P."""
     sc = load_scenario('cologne1')
-    e = OracleEnv(sc, sigma=0.0, tls_expiry=1)
+    e = OracleEnv(sc, sigma=0.0)
     e.observe()
     assert e.outputs()['phase'][0] == 0
     e.step(np.array([1], np.int32))                # green 1 has duration 6
@@ -90,12 +90,12 @@ def test_fsm_duration_auto_advance():
     assert e.outputs()['phase'][0] == 0
 
 
-def test_fsm_a_set_phase_stays_by_default():
-    """rs_params.tls_expiry = 0 (default): the phase entered through setPhase is the phase observed, whatever its programme
-    duration; the phase installed at reset still runs on its duration until the first setPhase, and so does the net's own
+def test_fsm_tls_hold_keeps_the_selected_phase():
+    """rs_params.tls_hold = 1 (tls_expiry=0, round 5's default): the phase entered through setPhase is the phase observed, whatever its
+    programme duration; the phase installed at reset still runs on its duration until the first setPhase, and so does the net's own
     programme (fixed_program)"""
     sc = load_scenario('cologne1')
-    e = OracleEnv(sc, sigma=0.0)
+    e = OracleEnv(sc, sigma=0.0, tls_expiry=0)
     e.observe()
     for a in (1, 3, 1, 0, 3, 3, 2):
         e.step(np.array([a], np.int32))

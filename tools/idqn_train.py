@@ -27,7 +27,7 @@ def delay(env):
     return float(env.sim.trip_delay().mean()), float(env.sim.stats()['arrived'].mean())
 
 
-def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1, use_graph=True, replay_steps=0, eps_end=0.0, evaluate=True, quiet=False, seed=0, tls_expiry=False):
+def main(map_name='cologne1', n=256, episodes=12, batch=256, updates=1, use_graph=True, replay_steps=0, eps_end=0.0, evaluate=True, quiet=False, seed=0, tls_expiry=True):
     rows = []
     env = VecMultiSignal(map_name, n, states=('drq_norm_f16',), rewards=('wait_norm',), seed=0, tls_expiry=tls_expiry)
     S, steps = env.n_signals, env.horizon_steps
