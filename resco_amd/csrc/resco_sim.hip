@@ -72,6 +72,11 @@ __device__ __forceinline__ float rs_int_as_float(int x) { return __int_as_float(
 __device__ __forceinline__ int rs_float_as_int(float x) { return __float_as_int(x); }
 __device__ __forceinline__ uint16_t rs_f2h(float x) { return __half_as_ushort(__float2half(x)); }
 
+// all four dwords of a Node are "used": the compiler reads them with one ds_read_b128 instead of narrowing the read to the fields a loop
+// body happens to need (resco_step.h: node_load)
+#ifndef RS_NARROW_NODE
+#define RS_KEEP4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#endif
 extern __shared__ __attribute__((aligned(16))) char rs_smem[];      // THE working memory of a workgroup (dynamic LDS)
 #define RS_SMEM rs_smem
 
@@ -91,13 +96,73 @@ __device__ unsigned long long *g_sec_prof;
 #include "resco_policy.h"
 
 // ------------------------------------------------------------------------------------------------ kernels
+// The tables / state / output descriptors live in ONE constant block in device memory (StepArgs): passed by value they
+// would pin ~70 SGPRs for the whole kernel (beyond ~100 the compiler spills SGPRs into VGPR lanes around every use);
+// behind a const __restrict__ pointer every field is a re-loadable scalar load.
+struct StepArgs { KTab T; State G; Out O; Lds L; };
+// the block is read through the CONSTANT address space: scalar loads, and the compiler takes pointers loaded from it for
+// global ones (global_load instead of flat_load, which would also tie up the LDS wait counter)
+typedef const __attribute__((address_space(4))) StepArgs *StepArgsPtr;
+
+// ---- the long code paths of a tick as FUNCTIONS (round 6).  Inlined into the tick loop, the walk over the links, the lane-change
+// searches and the hand-over keep ~190 scalars alive at once -- table bases, layout offsets, parameters -- and the 64-VGPR build
+// (80 SGPRs: eight waves per SIMD) spilled 124 of them into VGPR lanes, a v_readlane in front of every use.  A called function has a
+// register allocation of its own: it loads what it needs from the constant block when it is entered (once per chunk of 64 vehicles)
+// and nothing of the caller's is alive in it.  Arguments arrive in VGPRs (the calling convention knows nothing about uniform
+// values): the function makes them scalars again with v_readfirstlane -- a dozen instructions per call.
+#ifndef RS_INLINE_LONG
+#define RS_CALL_LONG 1
+#endif
+__device__ __forceinline__ int rs_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t rs_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ float rs_uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ StepArgsPtr rs_uni(StepArgsPtr p) {
+    const unsigned long long v = (unsigned long long)p;
+    return (StepArgsPtr)(((unsigned long long)rs_uni((uint32_t)(v >> 32)) << 32) | rs_uni((uint32_t)v));
+}
+// f(T, L, G) with the views a kernel of capacity CAP works with
+template <int CAP, class F> __device__ __forceinline__ void rs_with_tables(StepArgsPtr Ac, F f) {
+    const StepArgs *A = (const StepArgs *)Ac;
+    if constexpr (CAP != 0) { const LdsFix<CAP> Lf(A->L); f(A->T, Lf, A->G); }
+    else f(A->T, A->L, A->G);
+}
+// REGS only separates the instantiations by the register budget of the kernel that calls them (64 / 80 / 128 VGPRs)
+template <int CAP, int REGS> __device__ __attribute__((noinline)) void rs_fn_plan_long(StepArgsPtr Ac, uint32_t seed, float sigma, int genv, int env, int t, uint32_t tag, int s) {
+    Ac = rs_uni(Ac); seed = rs_uni(seed); sigma = rs_uni(sigma); genv = rs_uni(genv); env = rs_uni(env); t = rs_uni(t); tag = rs_uni(tag);
+    rs_with_tables<CAP>(Ac, [&](const KTab &T, const auto &L, const State &G) {
+        KParams P{};
+        P.seed = seed; P.sigma = sigma;
+        const int C = CAP ? CAP : T.capacity;
+        phase_plan<true>(T, L, Grid{(uint16_t *)L.grid, tag}, G, (size_t)env * C, P, genv, t, s);
+    });
+}
+template <int CAP, int REGS> __device__ __attribute__((noinline)) void rs_fn_lc_decide(StepArgsPtr Ac, int env, int t, uint32_t tag, int s) {
+    Ac = rs_uni(Ac); env = rs_uni(env); t = rs_uni(t); tag = rs_uni(tag);
+    rs_with_tables<CAP>(Ac, [&](const KTab &T, const auto &L, const State &G) {
+        const int C = CAP ? CAP : T.capacity;
+        lc_decide_and_flag(T, L, Grid{(uint16_t *)L.grid, tag}, G, (size_t)env * C, t, s);
+    });
+}
+template <int CAP, int REGS> __device__ __attribute__((noinline)) uint32_t rs_fn_move_long(StepArgsPtr Ac, uint32_t out_mask, int env, int t, uint32_t tag, int flags, int s) {
+    Ac = rs_uni(Ac); out_mask = rs_uni(out_mask); env = rs_uni(env); t = rs_uni(t); tag = rs_uni(tag); flags = rs_uni(flags);
+    int active = 0, halted = 0, top = 0;
+    rs_with_tables<CAP>(Ac, [&](const KTab &T, const auto &L, const State &G) {
+        KParams P{};
+        P.out_mask = out_mask;
+        const int C = CAP ? CAP : T.capacity;
+        phase_move<true>(T, L, Grid{(uint16_t *)L.grid, tag}, G, P, env, (size_t)env * C, t, (flags & 1) != 0, (flags & 2) != 0, s, active, halted, top);
+    });
+    return (uint32_t)active | ((uint32_t)halted << 1) | ((uint32_t)top << 2);
+}
+
 // grid = n_envs workgroups (one environment each); blockDim.x = 64 * waves (<= 1024), normally one thread per slot.
 // PROF: the build with the in-kernel timers (rs_phase_profile); the production kernels carry none of that code
-template <bool PROF> struct DevExec {
+template <bool PROF, int CAP, int REGS> struct DevExec {
     int B;
     int wave;                       // threadIdx.x / 64, wave-uniform: lives in a scalar register
     unsigned long long *prof;       // optional per-phase timers (rs_phase_profile)
     unsigned long long t0;
+    StepArgsPtr Ac;
     template <class F> __device__ __forceinline__ void phase(int id, F f) {
         // The thread index is RECOMPUTED per phase from the wave's index (a scalar) and the lane's position in the wave (two VALU
         // instructions): kept in a register across the kernel it costs a VGPR the 64-VGPR build does not have (it lived in scratch
@@ -133,38 +198,51 @@ template <bool PROF> struct DevExec {
 #endif
         if (PROF && prof && (threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicAdd(&prof[id], (wall_clock64() - start) + (1ull << 40));   // (every 16th environment: the sum stays below 2^40)
     }
+    // the long code paths: called (production kernels) or inlined (the profiling kernel, whose section timers live inside them)
+    template <class LT> __device__ __forceinline__ void plan_long(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, const KParams &P, int genv, int env, int t, int s) const {
+#ifdef RS_CALL_LONG
+        if constexpr (!PROF) { rs_fn_plan_long<CAP, REGS>(Ac, P.seed, P.sigma, genv, env, t, grid.tag, s); return; }
+#endif
+        phase_plan<true>(T, L, grid, G, eo, P, genv, t, s);
+    }
+    template <class LT> __device__ __forceinline__ void lc_decide(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, int env, int t, int s) const {
+#ifdef RS_CALL_LONG
+        if constexpr (!PROF) { rs_fn_lc_decide<CAP, REGS>(Ac, env, t, grid.tag, s); return; }
+#endif
+        lc_decide_and_flag(T, L, grid, G, eo, t, s);
+    }
+    template <class LT> __device__ __forceinline__ void move_long(const KTab &T, const LT &L, const Grid &gnew, const State &G, const KParams &P, int env, size_t eo, int t, bool last_tick,
+                                                                  bool more, int s, int &active, int &halted, int &top) const {
+#ifdef RS_CALL_LONG
+        if constexpr (!PROF) { move_unpack(rs_fn_move_long<CAP, REGS>(Ac, P.out_mask, env, t, gnew.tag, (last_tick ? 1 : 0) | (more ? 2 : 0), s), active, halted, top); return; }
+#endif
+        phase_move<true>(T, L, gnew, G, P, env, eo, t, last_tick, more, s, active, halted, top);
+    }
 };
 // Register budgets: 64 VGPRs (eight waves per SIMD: FOUR 512-thread workgroups per CU -- the default where the working memory of an
 // environment fits four times, round 6) and 80 VGPRs (three 512-thread workgroups per CU; `_v128` is the same code under a third
 // launch bound); CAP = the slot capacity as a compile-time constant (0: any).
-// The tables / state / output descriptors live in ONE constant block in device memory (StepArgs): passed by value they
-// would pin ~70 SGPRs for the whole kernel (beyond ~100 the compiler spills SGPRs into VGPR lanes around every use);
-// behind a const __restrict__ pointer every field is a re-loadable scalar load.
-struct StepArgs { KTab T; State G; Out O; Lds L; };
-// the block is read through the CONSTANT address space: scalar loads, and the compiler takes pointers loaded from it for
-// global ones (global_load instead of flat_load, which would also tie up the LDS wait counter)
-typedef const __attribute__((address_space(4))) StepArgs *StepArgsPtr;
-template <int CAP, bool PROF> __device__ __forceinline__ void rs_step_kernel_body(StepArgsPtr Ac, const KParams &P, const int32_t *__restrict__ actions) {
+template <int CAP, bool PROF, int REGS> __device__ __forceinline__ void rs_step_kernel_body(StepArgsPtr Ac, const KParams &P, const int32_t *__restrict__ actions) {
     if ((int)blockIdx.x >= P.n_envs) return;
     const StepArgs *A = (const StepArgs *)Ac;
 #ifdef RS_STUDY_SECTIONS
     if (threadIdx.x == 0) g_sec_prof = P.prof;
 #endif
-    DevExec<PROF> ex{(int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), PROF ? P.prof : nullptr, (PROF && P.prof) ? wall_clock64() : 0ull};
+    DevExec<PROF, CAP, REGS> ex{(int)blockDim.x, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), PROF ? P.prof : nullptr, (PROF && P.prof) ? wall_clock64() : 0ull, Ac};
     rs_step_body<CAP>(ex, A->L, A->T, A->G, A->O, P, actions, (int)blockIdx.x);
 }
 template <int CAP>
 __global__ void __launch_bounds__(1024, 8)
-rs_step_kernel_v64(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false>(Ac, P, actions); }
+rs_step_kernel_v64(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false, 64>(Ac, P, actions); }
 template <int CAP>
 __global__ void __launch_bounds__(768, 6)
-rs_step_kernel_v80(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false>(Ac, P, actions); }
+rs_step_kernel_v80(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false, 80>(Ac, P, actions); }
 template <int CAP>
 __global__ void __launch_bounds__(512, 4)
-rs_step_kernel_v128(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false>(Ac, P, actions); }
+rs_step_kernel_v128(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<CAP, false, 128>(Ac, P, actions); }
 // the profiling build (rs_phase_profile / RS_STUDY_SECTIONS): any capacity, 80 VGPRs
 __global__ void __launch_bounds__(768, 6)
-rs_step_kernel_prof(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<0, true>(Ac, P, actions); }
+rs_step_kernel_prof(StepArgsPtr Ac, KParams P, const int32_t *__restrict__ actions) { rs_step_kernel_body<0, true, 80>(Ac, P, actions); }
 
 // reset every environment: no vehicles, every backlog at its first trip, TLS programs freshly installed
 // (Signal.__init__, traffic_signal.py:93-100)

@@ -10,6 +10,8 @@
 //   ex.next_chunk(c, w, i, n)  the next work chunk of wave w (its i-th call in this phase, n waves): on the GPU ONE atomic on the LDS
 //                           counter c per wave (dynamic: whichever wave is free takes the next chunk), on the host i * n + w --
 //                           any assignment of chunks to waves gives the same result, a phase being order independent
+//   ex.plan_long / ex.lc_decide / ex.move_long   the long code paths of a tick for ONE slot (ExecInline below: inlined; the production
+//                           kernels call functions with a register allocation of their own)
 // On the GPU (resco_sim.hip) one workgroup = one environment; the state lives in LDS for the whole env-step and phase() is
 // `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same source for the host (tests/hostemu), where
 // phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never reads what another thread writes in the same
@@ -368,7 +370,9 @@ RS_CARVE float pick_cell_len(const rs_scenario *sc, int n_arr, int n_dep, int tl
 #define RS_SEC_BEGIN
 #define RS_SEC(id) {}
 #endif
+#ifdef RS_OLD_CHAINS
 RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
+#endif
 template <class LT> RS_DEV int lane_cells(const LT &L, const LaneRec &LR) { return (int)(LR.len * L.cell_inv) + 1; }
 template <class LT> RS_DEV int cell_of(const LT &L, float pos, int ncell) { const int c = (int)(pos * L.cell_inv); return c < ncell ? c : ncell - 1; }
 
@@ -458,6 +462,7 @@ RS_DEV bool cells_have_mover(const Grid &g, int c0, int nc) {
     }
     return false;
 }
+#ifdef RS_OLD_CHAINS        // (A/B: the chain walks of rounds 1-5)
 // rear-most vehicle of a cell chain (min pos, ties -> larger trip)
 template <class LT> RS_DEV int chain_rearmost(const LT &L, int head) {
     int best = NIL, bk = 0;
@@ -547,6 +552,136 @@ template <class LT> RS_DEV int at_or_behind_within(const LT &L, const Grid &grid
     return Fd;
 }
 
+#else
+// ---- the order of the vehicles of a lane as ONE integer: larger = further ahead.  ahead_of(pj, kj, pi, ki) -- the front position first,
+// the smaller trip id on a tie -- is `order_key(pj, kj) > order_key(pi, ki)`: positions are never negative (no -0.0 either: a position is a
+// sum of non-negative terms, a lane length, or what is left of a position beyond a lane's end), so the bit patterns of two positions
+// compare like the positions, and two vehicles never share a key (the trip ids differ).  One 64-bit compare and three selects per chain
+// element instead of a ladder of branches (round 6: the scalar pipe, not the VALU, is the nearer wall -- DESIGN.md section 4).
+RS_DEV unsigned long long order_key(float pos, int trip) { return ((unsigned long long)(uint32_t)rs_float_as_int(pos) << 16) | (uint32_t)(0xFFFF - trip); }
+RS_DEV float key_pos(unsigned long long key) { return rs_int_as_float((int)(uint32_t)(key >> 16)); }
+// a vehicle's Node with ONE 16-byte read (left to itself the compiler reads `nxt` first and the other fields it needs one by one,
+// behind the branch that uses them: two or three dependent LDS round trips per chain element)
+#ifndef RS_KEEP4
+#define RS_KEEP4(a, b, c, d)
+#endif
+template <class LT> RS_DEV Node node_load(const LT &L, int s) {
+    struct alignas(16) Raw { uint32_t a, b, c, d; } r;
+    __builtin_memcpy(&r, (const Node *)L.node + s, 16);
+    RS_KEEP4(r.a, r.b, r.c, r.d)
+    Node n;
+    n.pos = rs_int_as_float((int)r.a); n.speed = rs_int_as_float((int)r.b); n.trip = (uint16_t)(r.c & 0xFFFFu); n.nxt = (uint16_t)(r.c >> 16);
+    n.vt = (uint8_t)(r.d & 0xFFu); n.fl = (uint8_t)((r.d >> 8) & 0xFFu); n.sfq = (uint16_t)(r.d >> 16);
+    return n;
+}
+// rear-most vehicle of a cell chain (min pos, ties -> larger trip), its key in `bkey`
+template <class LT> RS_DEV int chain_rearmost(const LT &L, int head, unsigned long long &bkey) {
+    int best = NIL;
+    bkey = ~0ull;
+    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
+        const Node nd = node_load(L, s);
+        const unsigned long long key = order_key(nd.pos, nd.trip);
+        const bool take = key < bkey;
+        best = take ? s : best; bkey = take ? key : bkey;
+        s = nd.nxt;
+    }
+    return best;
+}
+// front-most vehicle of a cell chain (max pos, ties -> smaller trip)
+template <class LT> RS_DEV int chain_frontmost(const LT &L, int head, unsigned long long &bkey) {
+    int best = NIL;
+    bkey = 0ull;
+    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
+        const Node nd = node_load(L, s);
+        const unsigned long long key = order_key(nd.pos, nd.trip);
+        const bool take = key > bkey;
+        best = take ? s : best; bkey = take ? key : bkey;
+        s = nd.nxt;
+    }
+    return best;
+}
+// rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
+template <class LT> RS_DEV int rearmost_within(const LT &L, const Grid &grid, int cell0, int ncell, float win) {
+    if (win < 0.0f) return NIL;
+    const int c = scan_up(grid, cell0, cell0 + cell_of(L, win, ncell));
+    if (c < 0) return NIL;
+    unsigned long long key;
+    const int o = chain_rearmost(L, cell_head(grid, c), key);
+    return (o != NIL && key_pos(key) > win) ? NIL : o;
+}
+// nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front).  (pos, k) are `self`'s own everywhere this
+// is called (the plan; the lane-change searches on the neighbour lane, where `self` is not in the chains at all): its key equals
+// `mykey`, so the strict comparison leaves it out without a test of its own.
+template <class LT> RS_DEV int leader_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
+    const int c = cell_of(L, pos, ncell);
+    const unsigned long long mykey = order_key(pos, k);
+    int Ld = NIL;
+    unsigned long long Lkey = ~0ull;
+    // my own cell first.  A cell that holds ONE vehicle, me, needs no walk (the cell carries the number of its vehicles)
+    const uint32_t cw = grid.c[cell0 + c];
+    int s = ((cw ^ grid.tag) & CELL_TAG) ? (int)NIL : (int)(cw & NIL);
+    if (s == self && ((cw >> CELL_CNT_SHIFT) & CELL_CNT_MAX) == 1u) s = NIL;
+    while (s != NIL) { RS_CHAIN_GUARD
+        const Node nd = node_load(L, s);
+        const unsigned long long key = order_key(nd.pos, nd.trip);
+        RS_ASSERT(s != self || key == mykey)
+        const bool take = (key > mykey) & (key < Lkey);
+        Ld = take ? s : Ld; Lkey = take ? key : Lkey;
+        s = nd.nxt;
+    }
+    if (Ld == NIL && c + 1 < ncell) {
+        const int cc = scan_up(grid, cell0 + c + 1, cell0 + cell_of(L, pos + win, ncell));
+        if (cc >= 0) Ld = chain_rearmost(L, cell_head(grid, cc), Lkey);
+    }
+    if (Ld != NIL && key_pos(Lkey) - pos > win) Ld = NIL;
+    return Ld;
+}
+// nearest vehicle behind (pos, k) on the lane (not `self`: see leader_within), at most `win` metres away
+template <class LT> RS_DEV int follower_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
+    const int c = cell_of(L, pos, ncell);
+    const unsigned long long mykey = order_key(pos, k);
+    int Fd = NIL;
+    unsigned long long Fkey = 0ull;
+    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
+        const Node nd = node_load(L, s);
+        const unsigned long long key = order_key(nd.pos, nd.trip);
+        RS_ASSERT(s != self || key == mykey)
+        const bool take = (key < mykey) & (key > Fkey);
+        Fd = take ? s : Fd; Fkey = take ? key : Fkey;
+        s = nd.nxt;
+    }
+    if (Fd == NIL && c > 0) {
+        const float lo = pos - win;
+        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
+        if (cc >= 0) Fd = chain_frontmost(L, cell_head(grid, cc), Fkey);
+    }
+    if (Fd != NIL && pos - key_pos(Fkey) > win) Fd = NIL;
+    (void)self;
+    return Fd;
+}
+// nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
+template <class LT> RS_DEV int at_or_behind_within(const LT &L, const Grid &grid, int cell0, int ncell, float back, float win) {
+    if (back < 0.0f) return NIL;
+    const int c = cell_of(L, back, ncell);
+    int Fd = NIL;
+    unsigned long long Fkey = 0ull;
+    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
+        const Node nd = node_load(L, s);
+        const unsigned long long key = order_key(nd.pos, nd.trip);
+        const bool take = !(nd.pos > back) & (key > Fkey);
+        Fd = take ? s : Fd; Fkey = take ? key : Fkey;
+        s = nd.nxt;
+    }
+    if (Fd == NIL && c > 0) {
+        const float lo = back - win;
+        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
+        if (cc >= 0) Fd = chain_frontmost(L, cell_head(grid, cc), Fkey);
+    }
+    if (Fd != NIL && back - key_pos(Fkey) > win) Fd = NIL;
+    return Fd;
+}
+
+#endif
 // ------------------------------------------------------------------------------------------------ model helpers
 template <class LT> RS_DEV int tls_state(const KTab &T, const LT &L, int tls, int pos) {
     if (tls == 0xFF) return TLS_G;
@@ -1119,6 +1254,35 @@ template <class LT> RS_DEV int nth_free_slot(const LT &L, int C, int r) {      /
     return -1;
 }
 
+// the lane-change decision of the vehicle in slot s, queued for the move when it changes lanes (what a lane-change chunk does per entry)
+template <class LT> RS_DEV void lc_decide_and_flag(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, int t, int s) {
+    const Aux ax = L.aux[s];
+    if (ax.lane == LANE_NONE) return;
+    const int code = phase_lc_decide(T, L, grid, G, eo, t, s, ax, L.node[s]);
+    if (code) flag_mover(L, s, t, code);
+}
+// what phase_move adds to its thread's counters, as one word (a function that is CALLED returns it in a register): bit 0 the vehicle is
+// still on the network, bit 1 it stands, bits 2.. its slot + 1 (0: it has arrived)
+RS_DEV void move_unpack(uint32_t r, int &active, int &halted, int &top) {
+    active += (int)(r & 1u); halted += (int)((r >> 1) & 1u);
+    if ((int)(r >> 2) > top) top = (int)(r >> 2);
+}
+// The LONG code paths of a tick as the execution interface sees them (ex.plan_long / ex.lc_decide / ex.move_long): this default inlines
+// them where they are used (host emulation, profiling kernel); the production kernels CALL them (resco_sim.hip: functions with a
+// register allocation of their own -- the tick loop with all three inlined keeps ~190 scalars alive and spills 110-125 of them).
+struct ExecInline {
+    template <class LT> RS_MEM static void plan_long(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, const KParams &P, int genv, int, int t, int s) {
+        phase_plan<true>(T, L, grid, G, eo, P, genv, t, s);
+    }
+    template <class LT> RS_MEM static void lc_decide(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, int, int t, int s) {
+        lc_decide_and_flag(T, L, grid, G, eo, t, s);
+    }
+    template <class LT> RS_MEM static void move_long(const KTab &T, const LT &L, const Grid &gnew, const State &G, const KParams &P, int env, size_t eo, int t, bool last_tick, bool more,
+                                                     int s, int &active, int &halted, int &top) {
+        phase_move<true>(T, L, gnew, G, P, env, eo, t, last_tick, more, s, active, halted, top);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ the step
 // CAP: the slot capacity as a compile-time constant (0: read it from the tables at run time)
 template <int CAP, class Exec, class LT>
@@ -1232,12 +1396,8 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
                 for (int pass = 0; pass < 2; ++pass)
                     for (int w = tid; w < hw; w += B) {
                         if (pass && !(L.node[w].fl & FL_LC)) continue;
-                        if (pass) {
-                            const Aux ax = L.aux[w];
-                            if (ax.lane == LANE_NONE) continue;
-                            const int code = phase_lc_decide(T, L, gold, G, eo, t, w, ax, L.node[w]);
-                            if (code) flag_mover(L, w, t, code);
-                        } else phase_plan<true>(T, L, gold, G, eo, P, genv, t, w);
+                        if (pass) ex.lc_decide(T, L, gold, G, eo, env, t, w);
+                        else ex.plan_long(T, L, gold, G, eo, P, genv, env, t, w);
                     }
             } else {
                 // The work of the phase in chunks, longest code path first: the look-ahead list (RS_LIST_CHUNK entries per chunk), the
@@ -1251,18 +1411,11 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
                     if (c < hch) {                                  // plan of a vehicle that looks beyond its lane
                         role = 1;
                         const int w = c * RS_H_CHUNK + ln;
-                        if (ln < RS_H_CHUNK && w < nh) phase_plan<true>(T, L, gold, G, eo, P, genv, t, L.ls_h[w]);
+                        if (ln < RS_H_CHUNK && w < nh) ex.plan_long(T, L, gold, G, eo, P, genv, env, t, L.ls_h[w]);
                     } else if (c < hch + lch) {                     // lane-change decision
                         role = 2;
                         const int w = (c - hch) * RS_LIST_CHUNK + ln;
-                        if (ln < RS_LIST_CHUNK && w < nlc) {
-                            const int s = L.ls_lc[w];
-                            const Aux ax = L.aux[s];
-                            if (ax.lane != LANE_NONE) {
-                                const int code = phase_lc_decide(T, L, gold, G, eo, t, s, ax, L.node[s]);
-                                if (code) flag_mover(L, s, t, code);
-                            }
-                        }
+                        if (ln < RS_LIST_CHUNK && w < nlc) ex.lc_decide(T, L, gold, G, eo, env, t, L.ls_lc[w]);
                     } else {                                        // plan on the short path
                         const int w = (c - hch - lch) * 64 + ln;
                         if (w < hw && !(L.node[w].fl & FL_H)) phase_plan<false>(T, L, gold, G, eo, P, genv, t, w);
@@ -1316,7 +1469,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
                 if (c < mch) {
                     list = true;
                     const int w = c * RS_LIST_CHUNK + ln;
-                    if (ln < RS_LIST_CHUNK && w < nmh) phase_move<true>(T, L, gnew, G, P, env, eo, t, !more, more, L.ls_mh[w], active, halted, top);
+                    if (ln < RS_LIST_CHUNK && w < nmh) ex.move_long(T, L, gnew, G, P, env, eo, t, !more, more, L.ls_mh[w], active, halted, top);
                 } else if (c < mch + ich) {
                     // the winners of the departure lanes take the slots that were free at the beginning of the tick, lower lane first
                     for (int d = 63 - ln; d < T.n_dep; d += 64) {
@@ -1360,7 +1513,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
                     const int w = (c - mch - ich) * 64 + ln;
                     // (the vehicles of the list have FL_MH of this tick's parity set: their chunk moves them)
                     if (w < hw && (L.alive0[w >> 5] & (1u << (w & 31)))) {
-                        if (all) phase_move<true>(T, L, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
+                        if (all) ex.move_long(T, L, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
                         else if (!(L.node[w].fl & fl_mh(t))) phase_move<false>(T, L, gnew, G, P, env, eo, t, !more, more, w, active, halted, top);
                     }
                 }

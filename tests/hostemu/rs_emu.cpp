@@ -72,7 +72,7 @@ static long rs_dbg_chain = 0;         // chain-walk steps of the current phase (
 #endif
 #include "resco_step.h"
 
-struct HostExec {
+struct HostExec : ExecInline {
     unsigned long long role_begin() const { return 0ull; }
     void role_end(int, unsigned long long) const {}
     int wave_of(int tid) const { return tid >> 6; }
@@ -139,7 +139,8 @@ static void run_step(rs_sim *h, int n_ticks, int do_fsm, int do_observe = 1) {
     for (int env = 0; env < h->n_envs; ++env) {
         std::fill(h->smem.begin(), h->smem.end(), (char)0xA5);      // LDS is not zero on the GPU either
         g_smem = h->smem.data();
-        HostExec ex{h->block, h->order};
+        HostExec ex;
+        ex.B = h->block; ex.order = h->order;
         ex.rng = 777u + (uint32_t)env;
         switch (h->K.capacity) {
             case 128: rs_step_body<128>(ex, h->L, h->K, h->G, h->O, P, h->actions.data(), env); break;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: every reference-held result cell under BOTH answers to "what does trafficlight.setPhase leave behind"
-(rs_params.tls_expiry: 0 = the phase stays until the next setPhase, 1 = it expires after its programme duration and the programme
-continues -- what SUMO's MSSimpleTrafficLightLogic::changeStepAndDuration does).  64 environments x one whole episode per cell, the
+(tls_expiry 0 = rs_params.tls_hold 1: the phase stays until the next setPhase -- round 5's calibration variant; tls_expiry 1 = the library's
+default: it expires after its programme duration and the programme continues -- what SUMO's MSSimpleTrafficLightLogic::changeStepAndDuration does).  64 environments x one whole episode per cell, the
 median over the environments / the reference's figure (tests/golden/ref_bands.json).  FIXED does not depend on the parameter (the
 net's own programme always runs on its durations) and is printed once.
 
@@ -51,7 +51,7 @@ def main():
     a = ap.parse_args()
     with open(os.path.join(ROOT, 'tests', 'golden', 'ref_bands.json')) as f:
         ref = json.load(f)
-    print('# map policy metric | reference | phase stays (tls_expiry 0, default): value (ratio) | phase expires (tls_expiry 1, SUMO\'s documented setPhase): value (ratio)')
+    print('# map policy metric | reference | phase stays (tls_expiry 0: round 5\'s default): value (ratio) | phase expires (tls_expiry 1, SUMO\'s documented setPhase: the default): value (ratio)   [cap!: insertions were refused because all vehicle slots were taken]')
     err = {0: [], 1: []}
     inband = {0: 0, 1: 0}
     ncell = 0
