@@ -104,15 +104,15 @@ struct StepArgs { KTab T; State G; Out O; Lds L; };
 // global ones (global_load instead of flat_load, which would also tie up the LDS wait counter)
 typedef const __attribute__((address_space(4))) StepArgs *StepArgsPtr;
 
-// ---- the long code paths of a tick as FUNCTIONS (round 6).  Inlined into the tick loop, the walk over the links, the lane-change
-// searches and the hand-over keep ~190 scalars alive at once -- table bases, layout offsets, parameters -- and the 64-VGPR build
-// (80 SGPRs: eight waves per SIMD) spilled 124 of them into VGPR lanes, a v_readlane in front of every use.  A called function has a
-// register allocation of its own: it loads what it needs from the constant block when it is entered (once per chunk of 64 vehicles)
-// and nothing of the caller's is alive in it.  Arguments arrive in VGPRs (the calling convention knows nothing about uniform
-// values): the function makes them scalars again with v_readfirstlane -- a dozen instructions per call.
-#ifndef RS_INLINE_LONG
-#define RS_CALL_LONG 1
-#endif
+// ---- the long code paths of a tick as FUNCTIONS: measured in round 6 and NOT adopted (build with -DRS_CALL_LONG to get it).  Inlined
+// into the tick loop, the walk over the links, the lane-change searches and the hand-over keep ~190 scalars alive at once -- table
+// bases, layout offsets, parameters -- and the 64-VGPR build (80 SGPRs: eight waves per SIMD) spills ~110 of them into VGPR lanes, a
+// v_readlane in front of every use.  A called function has a register allocation of its own (41 / 59 / 41 VGPRs, 70-78 SGPRs, no
+// SGPR spills inside) and loads what it needs from the constant block when it is entered; its arguments arrive in VGPRs (the calling
+// convention knows nothing about uniform values) and are made scalars again with v_readfirstlane.  Bit-exact, but 1-2 % SLOWER
+// (profiles/r06_ab_call.txt: ingolstadt21 x 4096 3.105 against 3.137 M env-steps/s, cologne1 x 1024 5.70 / 5.77, cologne8 x 2048 7.37 /
+// 7.51): the kernel itself still spills 102 scalars (the short paths, C and the observe phases hold as many), the calls add 48 bytes
+// of scratch per lane for the callee-saved registers, and a v_readlane is cheap next to what a spill costs elsewhere.
 __device__ __forceinline__ int rs_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ uint32_t rs_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ float rs_uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }

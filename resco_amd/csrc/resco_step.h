@@ -10,8 +10,8 @@
 //   ex.next_chunk(c, w, i, n)  the next work chunk of wave w (its i-th call in this phase, n waves): on the GPU ONE atomic on the LDS
 //                           counter c per wave (dynamic: whichever wave is free takes the next chunk), on the host i * n + w --
 //                           any assignment of chunks to waves gives the same result, a phase being order independent
-//   ex.plan_long / ex.lc_decide / ex.move_long   the long code paths of a tick for ONE slot (ExecInline below: inlined; the production
-//                           kernels call functions with a register allocation of their own)
+//   ex.plan_long / ex.lc_decide / ex.move_long   the long code paths of a tick for ONE slot (ExecInline below: inlined; -DRS_CALL_LONG: called as functions
+//                           with a register allocation of their own -- measured, not adopted)
 // On the GPU (resco_sim.hip) one workgroup = one environment; the state lives in LDS for the whole env-step and phase() is
 // `f(threadIdx.x); __syncthreads()`.  The CPU tests compile the very same source for the host (tests/hostemu), where
 // phase() calls f for tid = 0 .. B-1 in turn (in any order: a phase never reads what another thread writes in the same
@@ -1268,8 +1268,8 @@ RS_DEV void move_unpack(uint32_t r, int &active, int &halted, int &top) {
     if ((int)(r >> 2) > top) top = (int)(r >> 2);
 }
 // The LONG code paths of a tick as the execution interface sees them (ex.plan_long / ex.lc_decide / ex.move_long): this default inlines
-// them where they are used (host emulation, profiling kernel); the production kernels CALL them (resco_sim.hip: functions with a
-// register allocation of their own -- the tick loop with all three inlined keeps ~190 scalars alive and spills 110-125 of them).
+// them where they are used; a build with -DRS_CALL_LONG calls them as functions with a register allocation of their own (resco_sim.hip:
+// measured in round 6, 1-2 % slower, not adopted).
 struct ExecInline {
     template <class LT> RS_MEM static void plan_long(const KTab &T, const LT &L, const Grid &grid, const State &G, size_t eo, const KParams &P, int genv, int, int t, int s) {
         phase_plan<true>(T, L, grid, G, eo, P, genv, t, s);
