@@ -370,9 +370,6 @@ RS_CARVE float pick_cell_len(const rs_scenario *sc, int n_arr, int n_dep, int tl
 #define RS_SEC_BEGIN
 #define RS_SEC(id) {}
 #endif
-#ifdef RS_OLD_CHAINS
-RS_DEV bool ahead_of(float pj, int kj, float pi, int ki) { return pj > pi || (pj == pi && kj < ki); }
-#endif
 template <class LT> RS_DEV int lane_cells(const LT &L, const LaneRec &LR) { return (int)(LR.len * L.cell_inv) + 1; }
 template <class LT> RS_DEV int cell_of(const LT &L, float pos, int ncell) { const int c = (int)(pos * L.cell_inv); return c < ncell ? c : ncell - 1; }
 
@@ -462,98 +459,7 @@ RS_DEV bool cells_have_mover(const Grid &g, int c0, int nc) {
     }
     return false;
 }
-#ifdef RS_OLD_CHAINS        // (A/B: the chain walks of rounds 1-5)
-// rear-most vehicle of a cell chain (min pos, ties -> larger trip)
-template <class LT> RS_DEV int chain_rearmost(const LT &L, int head) {
-    int best = NIL, bk = 0;
-    float bp = 0.0f;
-    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = L.node[s];
-        if (best == NIL || nd.pos < bp || (nd.pos == bp && (int)nd.trip > bk)) { best = s; bk = nd.trip; bp = nd.pos; }
-        s = nd.nxt;
-    }
-    return best;
-}
-// front-most vehicle of a cell chain (max pos, ties -> smaller trip)
-template <class LT> RS_DEV int chain_frontmost(const LT &L, int head) {
-    int best = NIL, bk = 0;
-    float bp = 0.0f;
-    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = L.node[s];
-        if (best == NIL || ahead_of(nd.pos, nd.trip, bp, bk)) { best = s; bk = nd.trip; bp = nd.pos; }
-        s = nd.nxt;
-    }
-    return best;
-}
-// rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
-template <class LT> RS_DEV int rearmost_within(const LT &L, const Grid &grid, int cell0, int ncell, float win) {
-    if (win < 0.0f) return NIL;
-    const int c = scan_up(grid, cell0, cell0 + cell_of(L, win, ncell));
-    if (c < 0) return NIL;
-    const int o = chain_rearmost(L, cell_head(grid, c));
-    return (o != NIL && L.node[o].pos > win) ? NIL : o;
-}
-// nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front)
-template <class LT> RS_DEV int leader_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
-    const int c = cell_of(L, pos, ncell);
-    int Ld = NIL, Lk = 0;
-    float Lp = 0.0f;
-    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD        // my own cell first
-        const Node nd = L.node[s];
-        const int cur = s;
-        s = nd.nxt;
-        if (cur == self) continue;
-        if (ahead_of(nd.pos, nd.trip, pos, k) && (Ld == NIL || ahead_of(Lp, Lk, nd.pos, nd.trip))) { Ld = cur; Lk = nd.trip; Lp = nd.pos; }
-    }
-    if (Ld == NIL && c + 1 < ncell) {
-        const int cc = scan_up(grid, cell0 + c + 1, cell0 + cell_of(L, pos + win, ncell));
-        if (cc >= 0) { Ld = chain_rearmost(L, cell_head(grid, cc)); Lp = L.node[Ld].pos; }
-    }
-    if (Ld != NIL && Lp - pos > win) Ld = NIL;
-    return Ld;
-}
-// nearest vehicle behind (pos, k) on the lane (not `self`), at most `win` metres away
-template <class LT> RS_DEV int follower_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
-    const int c = cell_of(L, pos, ncell);
-    int Fd = NIL, Fk = 0;
-    float Fp = 0.0f;
-    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = L.node[s];
-        const int cur = s;
-        s = nd.nxt;
-        if (cur == self) continue;
-        if (!ahead_of(nd.pos, nd.trip, pos, k) && (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk))) { Fd = cur; Fk = nd.trip; Fp = nd.pos; }
-    }
-    if (Fd == NIL && c > 0) {
-        const float lo = pos - win;
-        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) { Fd = chain_frontmost(L, cell_head(grid, cc)); Fp = L.node[Fd].pos; }
-    }
-    if (Fd != NIL && pos - Fp > win) Fd = NIL;
-    return Fd;
-}
-// nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
-template <class LT> RS_DEV int at_or_behind_within(const LT &L, const Grid &grid, int cell0, int ncell, float back, float win) {
-    if (back < 0.0f) return NIL;
-    const int c = cell_of(L, back, ncell);
-    int Fd = NIL, Fk = 0;
-    float Fp = 0.0f;
-    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = L.node[s];
-        if (!(nd.pos > back) && (Fd == NIL || ahead_of(nd.pos, nd.trip, Fp, Fk))) { Fd = s; Fk = nd.trip; Fp = nd.pos; }
-        s = nd.nxt;
-    }
-    if (Fd == NIL && c > 0) {
-        const float lo = back - win;
-        const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) { Fd = chain_frontmost(L, cell_head(grid, cc)); Fp = L.node[Fd].pos; }
-    }
-    if (Fd != NIL && back - Fp > win) Fd = NIL;
-    return Fd;
-}
-
-#else
-// ---- the order of the vehicles of a lane as ONE integer: larger = further ahead.  ahead_of(pj, kj, pi, ki) -- the front position first,
+// ---- the order of the vehicles of a lane as ONE integer: larger = further ahead.  "j is ahead of i" (oracle: ahead_of) -- the front position first,
 // the smaller trip id on a tie -- is `order_key(pj, kj) > order_key(pi, ki)`: positions are never negative (no -0.0 either: a position is a
 // sum of non-negative terms, a lane length, or what is left of a position beyond a lane's end), so the bit patterns of two positions
 // compare like the positions, and two vehicles never share a key (the trip ids differ).  One 64-bit compare and three selects per chain
@@ -574,114 +480,109 @@ template <class LT> RS_DEV Node node_load(const LT &L, int s) {
     n.vt = (uint8_t)(r.d & 0xFFu); n.fl = (uint8_t)((r.d >> 8) & 0xFFu); n.sfq = (uint16_t)(r.d >> 16);
     return n;
 }
-// rear-most vehicle of a cell chain (min pos, ties -> larger trip), its key in `bkey`
-template <class LT> RS_DEV int chain_rearmost(const LT &L, int head, unsigned long long &bkey) {
-    int best = NIL;
-    bkey = ~0ull;
-    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = node_load(L, s);
-        const unsigned long long key = order_key(nd.pos, nd.trip);
-        const bool take = key < bkey;
-        best = take ? s : best; bkey = take ? key : bkey;
-        s = nd.nxt;
+// the winner of a search over chains: its slot (NIL: none), its order key (-> position) and the rest of its Node that a plan wants
+// (speed, vType) -- carried along by the selects, so that nobody has to read the winner's Node again (one LDS round trip less on the
+// critical path of every plan; where they are not used the compiler drops the selects)
+struct Found {
+    int slot;
+    unsigned long long key;
+    uint32_t speed_bits, vtw;
+    RS_MEM float pos() const { return key_pos(key); }
+    RS_MEM float speed() const { return rs_int_as_float((int)speed_bits); }
+    RS_MEM int vt() const { return (int)(vtw & 0xFFu); }
+};
+// one step of a chain walk: the Node of slot s (returned: the next slot of the chain); `take` decides from its key whether it replaces f
+#define RS_CHAIN_STEP(f, s, COND)                                                                          \
+    {                                                                                                      \
+        RS_CHAIN_GUARD                                                                                     \
+        const Node nd_ = node_load(L, s);                                                                  \
+        const unsigned long long key = order_key(nd_.pos, nd_.trip);                                       \
+        const bool take_ = (COND);                                                                         \
+        (f).slot = take_ ? (s) : (f).slot; (f).key = take_ ? key : (f).key;                                \
+        (f).speed_bits = take_ ? (uint32_t)rs_float_as_int(nd_.speed) : (f).speed_bits;                    \
+        (f).vtw = take_ ? (uint32_t)nd_.vt : (f).vtw;                                                      \
+        s = nd_.nxt;                                                                                       \
     }
-    return best;
+// rear-most vehicle of a cell chain (min pos, ties -> larger trip)
+template <class LT> RS_DEV Found chain_rearmost(const LT &L, int head) {
+    Found f{(int)NIL, ~0ull, 0u, 0u};
+    for (int s = head & NIL; s != NIL;) RS_CHAIN_STEP(f, s, key < f.key)
+    return f;
 }
 // front-most vehicle of a cell chain (max pos, ties -> smaller trip)
-template <class LT> RS_DEV int chain_frontmost(const LT &L, int head, unsigned long long &bkey) {
-    int best = NIL;
-    bkey = 0ull;
-    for (int s = head & NIL; s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = node_load(L, s);
-        const unsigned long long key = order_key(nd.pos, nd.trip);
-        const bool take = key > bkey;
-        best = take ? s : best; bkey = take ? key : bkey;
-        s = nd.nxt;
-    }
-    return best;
+template <class LT> RS_DEV Found chain_frontmost(const LT &L, int head) {
+    Found f{(int)NIL, 0ull, 0u, 0u};
+    for (int s = head & NIL; s != NIL;) RS_CHAIN_STEP(f, s, key > f.key)
+    return f;
 }
 // rear-most vehicle of the lane with cells [cell0, cell0 + ncell) whose front is within `win` metres of the lane start
-template <class LT> RS_DEV int rearmost_within(const LT &L, const Grid &grid, int cell0, int ncell, float win) {
-    if (win < 0.0f) return NIL;
+template <class LT> RS_DEV Found rearmost_within(const LT &L, const Grid &grid, int cell0, int ncell, float win) {
+    Found f{(int)NIL, ~0ull, 0u, 0u};
+    if (win < 0.0f) return f;
     const int c = scan_up(grid, cell0, cell0 + cell_of(L, win, ncell));
-    if (c < 0) return NIL;
-    unsigned long long key;
-    const int o = chain_rearmost(L, cell_head(grid, c), key);
-    return (o != NIL && key_pos(key) > win) ? NIL : o;
+    if (c < 0) return f;
+    f = chain_rearmost(L, cell_head(grid, c));
+    if (f.slot != NIL && f.pos() > win) f.slot = NIL;
+    return f;
 }
 // nearest vehicle ahead of (pos, k) on the lane, at most `win` metres away (front to front).  (pos, k) are `self`'s own everywhere this
 // is called (the plan; the lane-change searches on the neighbour lane, where `self` is not in the chains at all): its key equals
 // `mykey`, so the strict comparison leaves it out without a test of its own.
-template <class LT> RS_DEV int leader_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
+template <class LT> RS_DEV Found leader_found(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(L, pos, ncell);
     const unsigned long long mykey = order_key(pos, k);
-    int Ld = NIL;
-    unsigned long long Lkey = ~0ull;
+    Found f{(int)NIL, ~0ull, 0u, 0u};
     // my own cell first.  A cell that holds ONE vehicle, me, needs no walk (the cell carries the number of its vehicles)
     const uint32_t cw = grid.c[cell0 + c];
     int s = ((cw ^ grid.tag) & CELL_TAG) ? (int)NIL : (int)(cw & NIL);
     if (s == self && ((cw >> CELL_CNT_SHIFT) & CELL_CNT_MAX) == 1u) s = NIL;
-    while (s != NIL) { RS_CHAIN_GUARD
-        const Node nd = node_load(L, s);
-        const unsigned long long key = order_key(nd.pos, nd.trip);
-        RS_ASSERT(s != self || key == mykey)
-        const bool take = (key > mykey) & (key < Lkey);
-        Ld = take ? s : Ld; Lkey = take ? key : Lkey;
-        s = nd.nxt;
+    while (s != NIL) {
+        RS_ASSERT(s != self || order_key(L.node[s].pos, L.node[s].trip) == mykey)
+        RS_CHAIN_STEP(f, s, (key > mykey) & (key < f.key))
     }
-    if (Ld == NIL && c + 1 < ncell) {
+    if (f.slot == NIL && c + 1 < ncell) {
         const int cc = scan_up(grid, cell0 + c + 1, cell0 + cell_of(L, pos + win, ncell));
-        if (cc >= 0) Ld = chain_rearmost(L, cell_head(grid, cc), Lkey);
+        if (cc >= 0) f = chain_rearmost(L, cell_head(grid, cc));
     }
-    if (Ld != NIL && key_pos(Lkey) - pos > win) Ld = NIL;
-    return Ld;
+    if (f.slot != NIL && f.pos() - pos > win) f.slot = NIL;
+    return f;
 }
-// nearest vehicle behind (pos, k) on the lane (not `self`: see leader_within), at most `win` metres away
+template <class LT> RS_DEV int leader_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
+    return leader_found(L, grid, cell0, ncell, pos, k, self, win).slot;
+}
+// nearest vehicle behind (pos, k) on the lane (not `self`: see leader_found), at most `win` metres away
 template <class LT> RS_DEV int follower_within(const LT &L, const Grid &grid, int cell0, int ncell, float pos, int k, int self, float win) {
     const int c = cell_of(L, pos, ncell);
     const unsigned long long mykey = order_key(pos, k);
-    int Fd = NIL;
-    unsigned long long Fkey = 0ull;
-    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = node_load(L, s);
-        const unsigned long long key = order_key(nd.pos, nd.trip);
-        RS_ASSERT(s != self || key == mykey)
-        const bool take = (key < mykey) & (key > Fkey);
-        Fd = take ? s : Fd; Fkey = take ? key : Fkey;
-        s = nd.nxt;
+    Found f{(int)NIL, 0ull, 0u, 0u};
+    for (int s = cell_head(grid, cell0 + c); s != NIL;) {
+        RS_ASSERT(s != self || order_key(L.node[s].pos, L.node[s].trip) == mykey)
+        RS_CHAIN_STEP(f, s, (key < mykey) & (key > f.key))
     }
-    if (Fd == NIL && c > 0) {
+    if (f.slot == NIL && c > 0) {
         const float lo = pos - win;
         const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) Fd = chain_frontmost(L, cell_head(grid, cc), Fkey);
+        if (cc >= 0) f = chain_frontmost(L, cell_head(grid, cc));
     }
-    if (Fd != NIL && pos - key_pos(Fkey) > win) Fd = NIL;
+    if (f.slot != NIL && pos - f.pos() > win) f.slot = NIL;
     (void)self;
-    return Fd;
+    return f.slot;
 }
 // nearest vehicle of the lane whose front is at or behind `back`, at most `win` metres behind it
 template <class LT> RS_DEV int at_or_behind_within(const LT &L, const Grid &grid, int cell0, int ncell, float back, float win) {
     if (back < 0.0f) return NIL;
     const int c = cell_of(L, back, ncell);
-    int Fd = NIL;
-    unsigned long long Fkey = 0ull;
-    for (int s = cell_head(grid, cell0 + c); s != NIL;) { RS_CHAIN_GUARD
-        const Node nd = node_load(L, s);
-        const unsigned long long key = order_key(nd.pos, nd.trip);
-        const bool take = !(nd.pos > back) & (key > Fkey);
-        Fd = take ? s : Fd; Fkey = take ? key : Fkey;
-        s = nd.nxt;
-    }
-    if (Fd == NIL && c > 0) {
+    Found f{(int)NIL, 0ull, 0u, 0u};
+    for (int s = cell_head(grid, cell0 + c); s != NIL;) RS_CHAIN_STEP(f, s, !(nd_.pos > back) & (key > f.key))
+    if (f.slot == NIL && c > 0) {
         const float lo = back - win;
         const int cc = scan_down(grid, cell0 + (lo > 0.0f ? cell_of(L, lo, ncell) : 0), cell0 + c - 1);
-        if (cc >= 0) Fd = chain_frontmost(L, cell_head(grid, cc), Fkey);
+        if (cc >= 0) f = chain_frontmost(L, cell_head(grid, cc));
     }
-    if (Fd != NIL && back - key_pos(Fkey) > win) Fd = NIL;
-    return Fd;
+    if (f.slot != NIL && back - f.pos() > win) f.slot = NIL;
+    return f.slot;
 }
 
-#endif
 // ------------------------------------------------------------------------------------------------ model helpers
 template <class LT> RS_DEV int tls_state(const KTab &T, const LT &L, int tls, int pos) {
     if (tls == 0xFF) return TLS_G;
@@ -889,22 +790,22 @@ template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L
     const uint32_t c2 = G.cooplead((t + 1) & 1)[eo + s];
     const LaneRec LR0 = T.lanes()[lane];
     LaneRec LR = LR0;
-    const float vfree = plan_vfree(vt, v, LR.vmax, sf);
     float vsafe = RM_BIGF;
     // The look-ahead only FINDS what limits the vehicle (a leader, or a stop line = a standing leader of zero length):
     // the Krauss safe speed is evaluated once, by all lanes together, after the walk.
     float tgap = 0.0f, tvl = 0.0f, tbl = b;
     bool have = false;
-    const float look = plan_look(vt, vfree);
     if (LONG) RS_SEC(7)
-    const int lead = leader_within(L, grid, LR.cell0, lane_cells(L, LR), x, k, s, look + T.maxlen);
+    const float vfree = plan_vfree(vt, v, LR.vmax, sf);
+    const float look = plan_look(vt, vfree);
+    const Found ld = leader_found(L, grid, LR.cell0, lane_cells(L, LR), x, k, s, look + T.maxlen);
+    const int lead = ld.slot;
     if (LONG) RS_SEC(8)
     bool found = false;
     if (lead != NIL) {
-        const Node ld = L.node[lead];
-        const float *vo = L.vtp + ld.vt * VT_COLS;
-        tgap = ld.pos - vo[VT_LENGTH] - x - mingap;
-        tvl = ld.speed; tbl = vo[VT_DECEL];
+        const float *vo = L.vtp + ld.vt() * VT_COLS;
+        tgap = ld.pos() - vo[VT_LENGTH] - x - mingap;
+        tvl = ld.speed(); tbl = vo[VT_DECEL];
         have = true; found = true;
     }
     {   // cooperation: requests of the last lane-change phase
@@ -954,12 +855,11 @@ template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L
                     if (vs < vsafe) vsafe = vs;
                 }
             }
-            const int o = rearmost_within(L, grid, LR.cell0, lane_cells(L, LR), look - seen + T.maxlen);
-            if (o != NIL) {
-                const Node od = L.node[o];
-                const float *vo = L.vtp + od.vt * VT_COLS;
-                tgap = seen + od.pos - vo[VT_LENGTH] - mingap;
-                tvl = od.speed; tbl = vo[VT_DECEL];
+            const Found od = rearmost_within(L, grid, LR.cell0, lane_cells(L, LR), look - seen + T.maxlen);
+            if (od.slot != NIL) {
+                const float *vo = L.vtp + od.vt() * VT_COLS;
+                tgap = seen + od.pos() - vo[VT_LENGTH] - mingap;
+                tvl = od.speed(); tbl = vo[VT_DECEL];
                 have = true;
                 break;
             }
