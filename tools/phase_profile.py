@@ -16,6 +16,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 n_envs = n
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 sc = Scenario.load(os.path.join(ROOT, 'resco_amd', 'scenarios', name + '.npz'))
+if os.environ.get('RS_CAPACITY'):
+    sc.capacity = int(os.environ['RS_CAPACITY'])
 sim = BatchedSim(sc, n, seed=0, sigma=-1.0, speed_dev=1, block_threads=block)
 for k in range(100):
     sim.act_random(k); sim.step(None)
