@@ -11,7 +11,9 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -disable-machine-licm: the step kernel's tick loop is long and register-starved (80 VGPRs for three workgroups per CU); with
 #   machine LICM every 32-bit literal of the loop body is hoisted into a VGPR of its own and five values end up in scratch,
 #   written per thread and tick: 110 MB of HBM writes per launch at 4096 environments and 2.5 % of the time (profiles/r03_*)
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-mllvm', '-disable-machine-licm', '-fPIC', '-shared',
+# -fno-honor-nans: no NaN exists in the model; with the flag the `x < y ? x : y` selects become v_min_f32 / v_max_f32 instead of v_cmp +
+#   v_cndmask pairs (and the s_nop the pair needs on gfx950): +0.6-0.9 % (profiles/r06_ab_linkrec_nnan.txt); results bit-identical
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-honor-nans', '-mllvm', '-disable-machine-licm', '-fPIC', '-shared',
          '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(HERE, 'csrc')]
 
 
