@@ -72,6 +72,18 @@ __device__ __forceinline__ float rs_int_as_float(int x) { return __int_as_float(
 __device__ __forceinline__ int rs_float_as_int(float x) { return __float_as_int(x); }
 __device__ __forceinline__ uint16_t rs_f2h(float x) { return __half_as_ushort(__float2half(x)); }
 
+// a / b by the hardware's Newton sequence without the range scaling (resco_step.h: RS_DIV).  Identical to `/` -- the same v_rcp_f32 and the same
+// seven operations -- for finite non-zero b, a = 0 or 2^-100 < |a|, |a / b| and |1 / b| normal: every division of the step kernel
+#ifndef RS_IEEE_DIV
+__device__ __forceinline__ float rs_div_unscaled(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
+    const float q0 = a * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-b, q1, a), r1, q1);
+}
+#define RS_DIV(a, b) rs_div_unscaled((a), (b))
+#endif
 // all four dwords of a Node are "used": the compiler reads them with one ds_read_b128 instead of narrowing the read to the fields a loop
 // body happens to need (resco_step.h: node_load)
 #ifndef RS_NARROW_NODE

@@ -95,31 +95,39 @@ RS_DEV uint32_t d_hash(uint32_t seed, uint32_t env, uint32_t trip, uint32_t tick
 }
 RS_DEV float d_u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
 
+// a / b, correctly rounded.  The including file may define RS_DIV: the device build uses the hardware's own Newton sequence (v_rcp_f32 + seven
+// fma / mul, what the compiler emits for `/`) WITHOUT the range scaling around it (v_div_scale x 2, v_div_fmas, v_div_fixup and the wait states
+// their condition codes need): every quotient of the model has a finite, non-zero denominator and operands far from the ends of the
+// exponent range, where the scaled and the unscaled sequence are the same operations -- bit-identical, 3-5 issue slots less per division,
+// and a plan + move execute seven of them per vehicle and tick.
+#ifndef RS_DIV
+#define RS_DIV(a, b) ((a) / (b))
+#endif
 // Krauss (SUMO MSCFModel, Euler update, dt = 1 s) [SUMO-K]
 RS_DEV float d_brake_gap(float v, float b) {
-    const int steps = (int)(v / b);
+    const int steps = (int)RS_DIV(v, b);
     const float fs = (float)steps;
     return fs * v - b * fs * (fs + 1.0f) * 0.5f;
 }
 RS_DEV float d_stop_speed(float gap, float b, float tau) {
     const float g = gap - 0.001f;
     if (g < 0.0f) return 0.0f;
-    const float q = 1.0f + 4.0f * ((2.0f * g / b - tau) + tau * tau);
+    const float q = 1.0f + 4.0f * ((RS_DIV(2.0f * g, b) - tau) + tau * tau);
     const float n = floorf(0.5f - (tau + sqrtf(q) * -0.5f));
     const float h = 0.5f * n * (n - 1.0f) * b + n * b * tau;
-    const float r = (g - h) / (n + tau);
+    const float r = RS_DIV(g - h, n + tau);
     return n * b + r;
 }
 RS_DEV float d_free_speed(float dist, float target, float b) {
     if (dist < target) return target;
     const float t2 = b + 2.0f * target;
-    float y = ((sqrtf(t2 * t2 + 8.0f * b * dist) - b) * 0.5f - target) / b;
+    float y = RS_DIV((sqrtf(t2 * t2 + 8.0f * b * dist) - b) * 0.5f - target, b);
     if (y < 0.0f) y = 0.0f;
     const float yf = floorf(y);
     const float exact = (yf * yf + yf) * 0.5f * b + yf * target + (y > yf ? target : 0.0f);
     float rest = dist - exact;
     if (rest < 0.0f) rest = 0.0f;
-    return rest / (yf + 1.0f) + yf * b + target;
+    return RS_DIV(rest, yf + 1.0f) + yf * b + target;
 }
 RS_DEV float d_follow_speed(float gap, float vl, float b, float bl, float tau) {
     const float bm = b > bl ? b : bl;
@@ -689,7 +697,7 @@ template <class LT> RS_DEV void register_approach_w(const KTab &T, const LT &L, 
     if (st == TLS_R) return;
     const float dist = lane_len - pos;
     if (st == TLS_Y && dist >= d_brake_gap(v, L.vtp[vt * VT_COLS + VT_DECEL])) return;
-    const float ta = dist / (v > 1.0f ? v : 1.0f);
+    const float ta = RS_DIV(dist, v > 1.0f ? v : 1.0f);
     const int q = ta * 10.0f >= 65000.0f ? 65000 : (int)(ta * 10.0f);
     rs_atomic_min(&L.arr[(int16_t)(kw & 0xFFFFu)], q);
 }
@@ -950,7 +958,7 @@ template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L
         halted += 1;
         if (G.trip_log) { const int wt = G.wtot()[eo + s]; if (wt < 65535) G.wtot()[eo + s] = (uint16_t)(wt + 1); }
     } else swn = 0;
-    if (vref > 0.0f && vn < vref) { tl += (vref - vn) / vref; G.tloss()[eo + s] = tl; }
+    if (vref > 0.0f && vn < vref) { tl += RS_DIV(vref - vn, vref); G.tloss()[eo + s] = tl; }
     float x = me.pos + vn;
     bool arrived = false;
     if (LONG) for (int it = 0; it < 16; ++it) {
