@@ -1148,13 +1148,15 @@ def test_reference_result_known_gaps(cell):
 
 
 def test_tls_expiry_evidence():
-    """What does trafficlight.setPhase leave behind (rs_params.tls_expiry)?  SUMO documents that the phase runs for its programme
-    duration and the programme then continues [SUMO-K]; the reference never resets a duration (traffic_signal.py:176-187), so a 6 s
-    green chosen for a 10 s step would hand its 7th second to the next phase of the list.  No SUMO binary is at hand, but the
-    reference holds 20 figures that depend on it: delay / duration / waitingTime / queue of a uniformly random policy on five maps
-    with 6 s greens (episode 1 of its IDQN runs, epsilon >= 0.9875).  Both answers on the device, 64 environments x one episode
-    each; the table goes to profiles/r05_tls_expiry_bands.txt.  Asserted: WITHOUT expiry (the default) at least 15 of the 20 figures
-    are closer to the reference's than with it, and |log ratio| summed over the 20 is at most 70 % of what expiry gives."""
+    """What does trafficlight.setPhase leave behind (rs_params.tls_hold; tls_expiry in the Python layer)?  SUMO documents that the phase
+    runs for its programme duration and the programme then continues [SUMO-K]: the library's default since round 6.  The reference never
+    resets a duration (traffic_signal.py:176-187), so a 6 s green chosen for a 10 s step hands its 7th second to the next phase of the
+    list.  No SUMO binary is at hand, but the reference holds 20 figures that depend on the rule: delay / duration / waitingTime / queue
+    of a uniformly random policy on five maps with 6 s greens (episode 1 of its IDQN runs, epsilon >= 0.9875).  Both answers on the
+    device, 64 environments x one episode each (table: profiles/r06_tls_expiry_bands.txt).  RECORDED, as what it is -- a property of
+    this build's own traffic model, not a pin: WITHOUT expiry (round 5's default, the calibration variant tls_hold = 1) at least 15 of
+    the 20 figures are closer to the reference's than with it, and |log ratio| summed over the 20 is at most 70 % of what expiry
+    gives.  A model change that closes the gap of the documented rule shows up here as a failure -- and is welcome."""
     ref = _ref_bands()
     lines, closer, err = [], 0, [0.0, 0.0]
     for name in ('cologne1', 'cologne8', 'ingolstadt1', 'ingolstadt7', 'ingolstadt21'):

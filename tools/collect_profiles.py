@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 PIPES = 2          # bench.py's default: launches per step
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')
@@ -26,7 +26,8 @@ for a, b in (('bench_default.json', 'bench_default.json'), ('bench_driver_window
              ('bench_under_rocprof.json', 'bench_under_rocprof.json'), ('phase_profile.txt', 'phase_profile.txt'),
              ('phase_profile_one_workgroup_per_cu.txt', 'phase_profile_one_workgroup_per_cu.txt'),
              ('pipes_ab.jsonl', 'pipes_ab.jsonl'), ('heldout_idqn.txt', 'heldout_idqn.txt'), ('bench_configs.jsonl', 'bench_configs.jsonl'),
-             ('reference_bands.txt', 'reference_bands.txt'), ('idqn_rollout.jsonl', 'idqn_rollout.jsonl'), ('prof/%s_kernel_stats.csv' % tag, 'kernel_stats.csv'),
+             ('reference_bands.txt', 'reference_bands.txt'), ('tls_expiry_bands.txt', 'tls_expiry_bands.txt'), ('reference_bands_both_modes.txt', 'reference_bands_both_modes.txt'),
+             ('heldout_both_modes.txt', 'heldout_both_modes.txt'), ('bench_default_hold.json', 'bench_default_hold.json'), ('bench_driver_window_hold.json', 'bench_driver_window_hold.json'), ('idqn_rollout.jsonl', 'idqn_rollout.jsonl'), ('prof/%s_kernel_stats.csv' % tag, 'kernel_stats.csv'),
              ('prof_dw/%s_dw_kernel_stats.csv' % tag, 'driver_window_kernel_stats.csv'),
              ('pmc_s300_w60/pmc_summary.json', 'pmc_s300_w60.json'), ('pmc_s20_w5/pmc_summary.json', 'pmc_s20_w5.json'),
              ('pmcdiag/diag_summary.json', 'pmc_diag.json')):
