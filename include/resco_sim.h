@@ -216,6 +216,9 @@ enum rs_buffer {
                             * (the fringe arrivals of rewards.fma2c, rewards.py:94-97) */
     RS_BUF_VEH_COOP_ODD,   /* u32 [N][C]  the mailboxes are double-buffered by tick parity: requests written in odd ticks ... */
     RS_BUF_VEH_COOPLEAD_ODD, /* u32 [N][C] ... (RS_BUF_VEH_COOP / _COOPLEAD hold those of even ticks) */
+    RS_BUF_VEH_MAIL,       /* u32 [N][ceil(C/32)]  one bit per slot: "a cooperation request written in the last tick is waiting in this slot's
+                            * mailboxes" (round 6).  Inside a launch the bit travels in the vehicle's working-memory record and a plan reads
+                            * its mailboxes only when it is set; the bitmap carries it from one launch to the next */
     RS_BUF_COUNT
 };
 enum rs_dtype { RS_F32 = 0, RS_I32 = 1, RS_U16 = 2, RS_U8 = 3, RS_F16 = 4, RS_I64 = 5, RS_U32 = 6 };

@@ -86,6 +86,7 @@ __device__ __forceinline__ float rs_div_unscaled(float a, float b) {
 #endif
 // all four dwords of a Node are "used": the compiler reads them with one ds_read_b128 instead of narrowing the read to the fields a loop
 // body happens to need (resco_step.h: node_load)
+#define RS_OPAQUE_S(x) asm volatile("" : "+s"(x));
 #ifndef RS_NARROW_NODE
 #define RS_KEEP4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 #endif
@@ -275,6 +276,7 @@ __global__ void rs_reset_kernel(KTab T, State G, KParams P) {
         G.tls[(env * S + s) * TLS_W + 0] = ph; G.tls[(env * S + s) * TLS_W + 1] = left; G.tls[(env * S + s) * TLS_W + 2] = 0; G.tls[(env * S + s) * TLS_W + 3] = 0;
     }
     for (int d = threadIdx.x; d < T.n_dep; d += blockDim.x) G.dep_next[(size_t)env * T.n_dep + d] = T.cold.dep_first[d];
+    for (int i = threadIdx.x; i < (C + 31) / 32; i += blockDim.x) G.mail[(size_t)env * ((C + 31) / 32) + i] = 0u;
     if (threadIdx.x < 4) G.env[env * 4 + threadIdx.x] = 0;
     if (threadIdx.x < ST_N) G.stats[(size_t)env * ST_N + threadIdx.x] = 0;
     if (G.trip_log)
@@ -525,7 +527,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         O.n = n_envs; O.o = sc->n_obs; O.s = sc->n_signals; O.lm = lmax;
         if ((rc = dev_alloc(h, &slab, State::bytes(NC))) || (rc = dev_alloc(h, &outb, O.bytes())) ||
             (rc = dev_alloc(h, &G.env, N * 4)) || (rc = dev_alloc(h, &G.tls, N * S * TLS_W)) || (rc = dev_alloc(h, &G.stats, N * ST_N)) ||
-            (rc = dev_alloc(h, &G.dep_next, N * (size_t)h->K.n_dep)) ||
+            (rc = dev_alloc(h, &G.dep_next, N * (size_t)h->K.n_dep)) || (rc = dev_alloc(h, &G.mail, N * (size_t)((C + 31) / 32))) ||
             (rc = dev_alloc(h, &h->actions, N * S)))
             return fail(rc);
         G.base = slab; O.base = outb;
@@ -571,6 +573,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
     set_buf(h, RS_BUF_MPLIGHT_FULL, O.mplight_full(), RS_F32, 3, n, s, 49);
     set_buf(h, RS_BUF_LANE_ARRIVALS, O.lane_arr(), RS_I32, 2, n, sc->n_obs);
     set_buf(h, RS_BUF_VEH_COOP_ODD, G.coop(1), RS_U32, 2, n, c); set_buf(h, RS_BUF_VEH_COOPLEAD_ODD, G.cooplead(1), RS_U32, 2, n, c);
+    set_buf(h, RS_BUF_VEH_MAIL, G.mail, RS_U32, 2, n, (C + 31) / 32);
 
     h->lds = lds_carve(nullptr, C, h->K.n_cells, h->K.n_arr, h->K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, h->K.tls_maxl);
     if (const char *pad = getenv("RESCO_STUDY_LDS_PAD")) h->lds += (size_t)atoi(pad);      // study knob: unused bytes, to hold the residency fixed in an A/B
@@ -826,7 +829,7 @@ static const int kSnapBufs[] = {RS_BUF_LANE_AGG, RS_BUF_DRQ_NORM, RS_BUF_PHASE, 
                                 RS_BUF_VEH_LANE, RS_BUF_VEH_TRIP, RS_BUF_VEH_CURSOR, RS_BUF_VEH_SWAIT, RS_BUF_VEH_RWAIT,
                                 RS_BUF_VEH_DEPART, RS_BUF_VEH_OWNER, RS_BUF_VEH_SF, RS_BUF_VEH_WTOT, RS_BUF_TRIP_LOG, RS_BUF_STATS,
                                 RS_BUF_DEP_NEXT, RS_BUF_VEH_COOP, RS_BUF_VEH_COOPLEAD, RS_BUF_ARRIVALS, RS_BUF_DEPARTURES, RS_BUF_MPLIGHT_FULL,
-                                RS_BUF_LANE_ARRIVALS, RS_BUF_VEH_COOP_ODD, RS_BUF_VEH_COOPLEAD_ODD};
+                                RS_BUF_LANE_ARRIVALS, RS_BUF_VEH_COOP_ODD, RS_BUF_VEH_COOPLEAD_ODD, RS_BUF_VEH_MAIL};
 extern "C" int rs_snapshot(rs_handle h, void **snap) {
     if (!h || !snap) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));

@@ -35,6 +35,7 @@ struct State {      // env-major SoA in HBM: field[env][slot]
     int32_t *tls;       // [N][S][TLS_W] phase, left, next_phase, departures since the last observe
     long long *stats;   // [N][10]
     uint16_t *dep_next; // [N][n_dep] head of every departure lane's backlog (TRIP_NONE: exhausted)
+    uint32_t *mail;     // [N][ceil(C/32)] bit per slot: a cooperation request of the last tick waits in its mailboxes (see SFQ_MAIL)
     RS_HD float *pos() const { return (float *)base; }
     RS_HD float *speed() const { return RS_G((float *)(base + 4 * nc)); }
     RS_HD float *accel() const { return RS_G((float *)(base + 8 * nc)); }
@@ -147,7 +148,15 @@ RS_DEV int speed_factor_q(const KParams &P, int env, int trip, const float *vt) 
     if (f > 2.0f) f = 2.0f;
     return (int)(f * RM_SF_QUANT + 0.5f);
 }
-RS_DEV float sf_of(int q) { return (float)q * (1.0f / RM_SF_QUANT); }
+// Node.sfq: bits 0..13 the speed factor (at most 2.0 * RM_SF_QUANT = 8192), bits 14 / 15 the MAIL FLAGS of the two tick parities: "a
+// cooperation request written in a tick of parity p addresses this vehicle".  The lane-change decision that writes a request sets the
+// flag (atomic OR on the record's last dword), the plan of the next tick reads its two mailboxes -- global memory -- only when it is set
+// and clears it: 95 % of the plans issue no mailbox load at all, and the mailbox lines of an environment are no longer fetched once
+// per launch for nothing ("Bytes per env-step").  Between launches the flags of the last tick live in State.mail.
+#define SFQ_MASK 0x3FFFu
+#define SFQ_MAIL(par) (0x4000u << (par))
+RS_DEV float sf_of(int q) { return (float)(q & (int)SFQ_MASK) * (1.0f / RM_SF_QUANT); }
+
 
 // ------------------------------------------------------------------------------------------------ working memory (LDS)
 struct __attribute__((aligned(16))) Node {      // everything a NEIGHBOUR wants to know about a vehicle: one 16-byte read
@@ -197,6 +206,7 @@ struct Lds {
     LPtr<int32_t> arr;          // link approach registers
     LPtr<uint16_t> dep, dep_t;  // head trip of every departure lane's backlog, and its departure second (0xFFFF: none)
     LPtr<uint32_t> alive, alive0, insm;     // bit per slot: occupied (now / at the beginning of the tick); bit per departure lane: inserts this tick
+    LPtr<uint32_t> mailw;                   // bit per slot: the mail flags of the last tick, collected when the slab goes back (-> State.mail)
     LPtr<int32_t> agg_q, agg_a, agg_w, agg_m, agg_n;
     LPtr<uint32_t> agg_s;
     LPtr<int32_t> sig_arr, sig_dep;
@@ -265,6 +275,7 @@ RS_CARVE size_t lds_carve(Lds *L, int C, int n_cells, int n_arr, int n_dep, int 
     CARVE(grid, (size_t)((n_cells + 8 + 7) & ~7) * 2)
     // ---- scenario-dependent
     CARVE(insm, (size_t)((n_dep + 31) / 32) * 4)
+    CARVE(mailw, (size_t)((C + 31) / 32) * 4)
     CARVE(vtp, (size_t)n_vt * VT_COLS * 4)
     CARVE(phase, (size_t)S * 4) CARVE(left, (size_t)S * 4) CARVE(nextp, (size_t)S * 4)
     CARVE(sig_arr, (size_t)S * 4) CARVE(sig_dep, (size_t)S * 4)
@@ -321,14 +332,14 @@ template <int C> struct LdsFix {
     const uint32_t &gstride;
     const LPtr<int32_t> &arr;
     const LPtr<uint16_t> &dep, &dep_t;
-    const LPtr<uint32_t> &insm;
+    const LPtr<uint32_t> &insm, &mailw;
     const LPtr<int32_t> &agg_q, &agg_a, &agg_w, &agg_m, &agg_n;
     const LPtr<uint32_t> &agg_s;
     const LPtr<int32_t> &sig_arr, &sig_dep, &phase, &left, &nextp;
     const LPtr<uint8_t> &tstate;
     const float &cell_inv;
     RS_MEM explicit LdsFix(const Lds &T)
-        : vtp(T.vtp), gstride(T.gstride), arr(T.arr), dep(T.dep), dep_t(T.dep_t), insm(T.insm), agg_q(T.agg_q), agg_a(T.agg_a), agg_w(T.agg_w),
+        : vtp(T.vtp), gstride(T.gstride), arr(T.arr), dep(T.dep), dep_t(T.dep_t), insm(T.insm), mailw(T.mailw), agg_q(T.agg_q), agg_a(T.agg_a), agg_w(T.agg_w),
           agg_m(T.agg_m), agg_n(T.agg_n), agg_s(T.agg_s), sig_arr(T.sig_arr), sig_dep(T.sig_dep), phase(T.phase), left(T.left), nextp(T.nextp),
           tstate(T.tstate), cell_inv(T.cell_inv) {}
     // does the host's table put the arrays where this view expects them?  (rs_create checks it: a mismatch is a build error)
@@ -478,6 +489,9 @@ RS_DEV float key_pos(unsigned long long key) { return rs_int_as_float((int)(uint
 // behind the branch that uses them: two or three dependent LDS round trips per chain element)
 #ifndef RS_KEEP4
 #define RS_KEEP4(a, b, c, d)
+#endif
+#ifndef RS_OPAQUE_S         // "the compiler knows nothing about this (wave-uniform) value from here on" (device build: an empty asm)
+#define RS_OPAQUE_S(x)
 #endif
 template <class LT> RS_DEV Node node_load(const LT &L, int s) {
     struct alignas(16) Raw { uint32_t a, b, c, d; } r;
@@ -728,6 +742,9 @@ template <class LT> RS_DEV void follow_neighbour(const KTab &T, const LT &L, uin
     (void)lane;
 }
 
+// the mail flag of tick parity `par` in the record of slot s (see SFQ_MAIL): atomic, other threads may mark the same vehicle
+template <class LT> RS_DEV void mail_flag_set(const LT &L, int s, int par) { rs_atomic_or((uint32_t *)((Node *)L.node + s) + 3, SFQ_MAIL(par) << 16); }
+template <class LT> RS_DEV void mail_flag_clear(const LT &L, int s, int par) { rs_atomic_and((uint32_t *)((Node *)L.node + s) + 3, ~(SFQ_MAIL(par) << 16)); }
 // mark slot s as one whose move of tick t is a long one and queue it (the plan's thread and the lane-change thread of a
 // vehicle may both do it, at the same time: an atomic OR on the dword that holds Node.fl decides who queues it)
 template <class LT, class LP> RS_DEV void list_push(const LT &L, const LP &list, int counter, int s);
@@ -795,7 +812,6 @@ template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L
     const float a = vt[VT_ACCEL], b = vt[VT_DECEL], tau = vt[VT_TAU], mingap = vt[VT_MINGAP];
     const float v = me.speed, x = me.pos;
     const float sf = sf_of(me.sfq);
-    const uint32_t c2 = G.cooplead((t + 1) & 1)[eo + s];
     const LaneRec LR0 = T.lanes()[lane];
     LaneRec LR = LR0;
     float vsafe = RM_BIGF;
@@ -816,11 +832,16 @@ template <bool LONG, class LT> RS_DEV void phase_plan(const KTab &T, const LT &L
         tvl = ld.speed(); tbl = vo[VT_DECEL];
         have = true; found = true;
     }
-    {   // cooperation: requests of the last lane-change phase
-        const uint32_t c1 = G.coop((t + 1) & 1)[eo + s];  // (in HBM: written rarely, by other threads, with a global atomic)
-        if (c1 != COOP_NONE) { G.coop((t + 1) & 1)[eo + s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
-        if (c2 != COOP_NONE) { G.cooplead((t + 1) & 1)[eo + s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
+    if (me.sfq & SFQ_MAIL((t + 1) & 1)) {   // cooperation: requests of the last lane-change phase (the mailboxes are in HBM: read only when flagged)
+        const int q = (t + 1) & 1;
+        const uint32_t c1 = G.coop(q)[eo + s], c2 = G.cooplead(q)[eo + s];
+        if (c1 != COOP_NONE) { G.coop(q)[eo + s] = COOP_NONE; follow_neighbour(T, L, c1, false, LR, lane, x, v, b, tau, mingap, vsafe); }
+        if (c2 != COOP_NONE) { G.cooplead(q)[eo + s] = COOP_NONE; follow_neighbour(T, L, c2, true, LR, lane, x, v, b, tau, mingap, vsafe); }
+        mail_flag_clear(L, s, q);
     }
+#ifdef RS_EMU_CHECK_MAIL      // (host emulation: no request may wait in an unflagged vehicle's mailboxes)
+    else { RS_ASSERT(G.coop((t + 1) & 1)[eo + s] == COOP_NONE && G.cooplead((t + 1) & 1)[eo + s] == COOP_NONE) }
+#endif
     if (LONG) RS_SEC(9)
     float seen = LR.len - x;
     RS_ASSERT(LONG || found || !(seen < look))
@@ -1101,9 +1122,9 @@ template <class LT> RS_DEV int phase_lc_decide(const KTab &T, const LT &L, const
             } else if (want == 2) {
                 // blocked: fall in behind the target-lane leader, and ask the nearest vehicle completely behind me on the
                 // target lane to let me in
-                if (lead_t != NIL) G.cooplead(t & 1)[eo + s] = ((uint32_t)L.node[lead_t].trip << 16) | (uint32_t)lead_t;
+                if (lead_t != NIL) { G.cooplead(t & 1)[eo + s] = ((uint32_t)L.node[lead_t].trip << 16) | (uint32_t)lead_t; mail_flag_set(L, s, t & 1); }
                 const int R = at_or_behind_within(L, grid, tcell0, nc, x - vt[VT_LENGTH], RM_COOP_RANGE);
-                if (R != NIL) rs_atomic_min(&G.coop(t & 1)[eo + R], ((uint32_t)k << 16) | (uint32_t)s);
+                if (R != NIL) { rs_atomic_min(&G.coop(t & 1)[eo + R], ((uint32_t)k << 16) | (uint32_t)s); mail_flag_set(L, R, t & 1); }
             }
         }
     }
@@ -1210,7 +1231,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
         for (int i = tid; i < T.n_vtypes * VT_COLS; i += B) L.vtp[i] = T.cold.vtype_params[i];
         for (int i = tid; i < (int)(L.gstride >> 1); i += B) ((uint32_t *)grid0)[i] = 0x07FF07FFu;      // every cell empty (tag 0)
         for (int i = tid; i < T.n_arr; i += B) L.arr[i] = ARR_NONE;
-        for (int i = tid; i < (C + 31) / 32; i += B) L.alive[i] = 0u;
+        for (int i = tid; i < (C + 31) / 32; i += B) { L.alive[i] = 0u; L.mailw[i] = 0u; }
         for (int i = tid; i < (T.n_dep + 31) / 32; i += B) L.insm[i] = 0u;
         for (int i = tid; i < T.n_dep; i += B) {
             const int k = G.dep_next[(size_t)env * T.n_dep + i];
@@ -1246,6 +1267,8 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
             // the speed factor is a function of (seed, environment, trip): recomputed here (four hashes per vehicle and ENV-STEP) instead of
             // read back -- 4 B per slot and step less from HBM; RS_BUF_VEH_SF is written at the insertion, for whoever reads it
             nn.fl = 0; nn.sfq = (uint16_t)speed_factor_q(P, genv, tr, L.vtp + nn.vt * VT_COLS);
+            // a request of the last tick before this launch waits in the mailboxes: the first plan reads those of parity (t + 1) & 1
+            if ((G.mail[(size_t)env * ((C + 31) / 32) + (s >> 5)] >> (s & 31)) & 1u) nn.sfq |= (uint16_t)SFQ_MAIL((L.sc[SC_T] + 1) & 1);
             nn.nxt = grid_push(Grid{grid0, 0u}, LR0.cell0 + cell_of(L, x, lane_cells(L, LR0)), s, sp > RM_HALT_SPEED);
             if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, sf_of(nn.sfq), L.sc[SC_T]);
             L.node[s] = nn;
@@ -1339,7 +1362,12 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
             // the cells that still carry the tag the move phase is about to push with hold what was valid a tick ago (nobody read
             // them in this tick): they are emptied now, so that every cell of that tag the move meets is one it has filled itself.
             // (Readers of this phase are not disturbed: the cells of their tag are written back as they are.)
-            for (int i = tid; i < (int)(L.gstride >> 2); i += B) {
+            // (the stride is made opaque per tick: seen through, the compiler keeps `8 * B` in a vector register across the whole tick loop --
+            //  in the 64-VGPR build that register lived in scratch, written once and re-loaded in every iteration of this loop: 8 MB of HBM
+            //  writes per launch of 2048 environments, profiles/r06_pmc_scratch_mailflags.txt)
+            int Bs = B;
+            RS_OPAQUE_S(Bs)
+            for (int i = tid; i < (int)(L.gstride >> 2); i += Bs) {
                 unsigned long long *q = (unsigned long long *)grid0 + i;
                 const unsigned long long w = *q;
                 const unsigned long long st = ((w ^ grid_tag4(gold)) >> 15) & 0x0001000100010001ull;    // 1: the cell carries the other tag
@@ -1451,6 +1479,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
             G.lane()[eo + s] = (uint16_t)lane; G.trip()[eo + s] = L.node[s].trip;
             if (lane == (int)LANE_NONE) continue;
             hi = s + 1;
+            if (L.node[s].sfq & SFQ_MAIL((L.sc[SC_T] + 1) & 1)) rs_atomic_or(&L.mailw[s >> 5], 1u << (s & 31));      // (what the next launch's first plan reads)
             // store the slab back (once per env-step)
             const int rq = L.aux[s].rq;
             G.pos()[eo + s] = L.node[s].pos; G.speed()[eo + s] = L.node[s].speed; G.swait()[eo + s] = L.aux[s].swait;
@@ -1564,6 +1593,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
             G.tls[(env * S + sg) * TLS_W + 3] = obs ? 0 : L.sig_dep[sg];
         }
         for (int i = tid; i < T.n_dep; i += B) G.dep_next[(size_t)env * T.n_dep + i] = L.dep[i];
+        for (int i = tid; i < (C + 31) / 32; i += B) G.mail[(size_t)env * ((C + 31) / 32) + i] = L.mailw[i];
     });
     ex.phase(14, [&](int tid) {
         if (tid == 0) {

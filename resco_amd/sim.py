@@ -18,7 +18,7 @@ BUFFERS = ['lane_agg', 'drq_norm', 'phase', 'mplight', 'wave', 'wait', 'wait_nor
            'queue_max', 'actions', 'env', 'tls', 'veh_pos', 'veh_speed', 'veh_accel', 'veh_tloss', 'veh_lane',
            'veh_trip', 'veh_cursor', 'veh_swait', 'veh_rwait', 'veh_depart', 'veh_owner', 'stats', 'drq_norm_f16',
            'veh_sf', 'veh_wtot', 'trip_log', 'dep_next', 'veh_coop', 'veh_cooplead', 'arrivals', 'departures',
-           'mplight_full', 'lane_arrivals', 'veh_coop_odd', 'veh_cooplead_odd']
+           'mplight_full', 'lane_arrivals', 'veh_coop_odd', 'veh_cooplead_odd', 'veh_mail']
 BUF_ID = {n: i for i, n in enumerate(BUFFERS)}
 OUTPUT_GROUPS = ('lane_agg', 'drq_norm', 'drq_norm_f16', 'lane_arrivals', 'mplight', 'wave', 'mplight_full', 'veh_accel')
 _NP_DTYPES = [np.float32, np.int32, np.uint16, np.uint8, np.float16, np.int64, np.uint32]

@@ -22,6 +22,7 @@
 static char *g_smem = nullptr;
 #define RS_SMEM g_smem
 // an invariant of the kernel source the emulation checks (the device build compiles it out)
+#define RS_EMU_CHECK_MAIL 1
 #define RS_ASSERT(c) if (!(c)) { fprintf(stderr, "rs_emu: invariant violated: %s (resco_step.h:%d)\n", #c, __LINE__); abort(); }
 static inline void rs_atomic_min(int32_t *p, int32_t v) { if (v < *p) *p = v; }
 static inline void rs_atomic_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
@@ -112,6 +113,7 @@ struct rs_sim {
     uint32_t out_mask = OUT_ALL;
     std::vector<long long> stats;
     std::vector<uint16_t> dep_next;
+    std::vector<uint32_t> mail;
     std::vector<float> route_cont, vtype_params;
     std::vector<std::vector<int32_t>> keep;
     struct Buf { void *ptr; int64_t shape[4]; int ndim; int dtype; size_t bytes; };
@@ -200,7 +202,8 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->outb.assign(h->O.bytes(), 0); h->O.base = h->outb.data();
     h->env.assign(N * 4, 0); h->tls.assign(N * S * TLS_W, 0); h->stats.assign(N * ST_N, 0); h->actions.assign(N * S, 0);
     h->dep_next.assign(N * K.n_dep, 0);
-    h->G.env = h->env.data(); h->G.tls = h->tls.data(); h->G.stats = h->stats.data(); h->G.dep_next = h->dep_next.data();
+    h->mail.assign(N * (size_t)((C + 31) / 32), 0u);
+    h->G.env = h->env.data(); h->G.tls = h->tls.data(); h->G.stats = h->stats.data(); h->G.dep_next = h->dep_next.data(); h->G.mail = h->mail.data();
     h->G.trip_log = nullptr;
     if (p->trip_log) { h->trip_log.assign(N * (size_t)sc->n_trips * 4, 0); h->G.trip_log = h->trip_log.data(); }
     h->lds = lds_carve(&h->L, C, K.n_cells, K.n_arr, K.n_dep, sc->n_obs, sc->n_signals, sc->n_vtypes, K.tls_maxl);
@@ -231,6 +234,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     set_buf(h, RS_BUF_MPLIGHT_FULL, O.mplight_full(), RS_F32, 3, n, s, 49);
     set_buf(h, RS_BUF_LANE_ARRIVALS, O.lane_arr(), RS_I32, 2, n, sc->n_obs);
     set_buf(h, RS_BUF_VEH_COOP_ODD, G.coop(1), RS_U32, 2, n, cc); set_buf(h, RS_BUF_VEH_COOPLEAD_ODD, G.cooplead(1), RS_U32, 2, n, cc);
+    set_buf(h, RS_BUF_VEH_MAIL, G.mail, RS_U32, 2, n, (cc + 31) / 32);
     *out = h;
     return rs_reset(h, nullptr);
 }
@@ -254,6 +258,7 @@ int rs_reset(rs_handle h, void *) {
             G.tls[(env * S + s) * TLS_W + 0] = ph; G.tls[(env * S + s) * TLS_W + 1] = left; G.tls[(env * S + s) * TLS_W + 2] = 0; G.tls[(env * S + s) * TLS_W + 3] = 0;
         }
         for (int d = 0; d < T.n_dep; ++d) G.dep_next[(size_t)env * T.n_dep + d] = T.cold.dep_first[d];
+        for (int i = 0; i < (C + 31) / 32; ++i) G.mail[(size_t)env * ((C + 31) / 32) + i] = 0u;
         for (int i = 0; i < 4; ++i) G.env[env * 4 + i] = 0;
         for (int i = 0; i < ST_N; ++i) G.stats[(size_t)env * ST_N + i] = 0;
         if (G.trip_log) for (int i = 0; i < T.n_trips * 4; ++i) G.trip_log[(size_t)env * T.n_trips * 4 + i] = 0;
