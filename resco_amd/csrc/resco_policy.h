@@ -262,7 +262,10 @@ idqn_forward_body(PolicySmem &sm, const PolicyTab &W, const __half *__restrict__
 
 // One workgroup = one signal: the body is chosen by the signal's own head size (a workgroup-uniform switch).  W.hp_sig[s] == W.hp
 // for every signal until rs_idqn_set_lanes has told the library the networks' real input sizes.
-__global__ void __launch_bounds__(256)
+#ifndef POL_MINBLOCKS
+#define POL_MINBLOCKS 1      // workgroups per CU the register allocation leaves room for (study switch: 4 = 128 registers per lane)
+#endif
+__global__ void __launch_bounds__(256, POL_MINBLOCKS)
 rs_idqn_forward_kernel(PolicyTab W, const __half *__restrict__ obs, int n_envs, int env_base, int mode, float eps, uint32_t seed, uint32_t step_key,
                        const uint32_t *__restrict__ dyn, int32_t *__restrict__ actions, float *__restrict__ q_out) {
     // dyn != NULL: epsilon (float bits) and step key come from device memory, so that a captured HIP graph of the
