@@ -9,16 +9,18 @@ the other derived buffers are switched off with rs_set_outputs).
 One "step" = one MultiSignal.step() of every environment = 10 one-second simulation ticks, fused in ONE
 kernel launch per PIPE: the batch of a GPU is split into --pipes (default 2) handles of envs / pipes environments, each
 stepping on a HIP stream of its own (the global environment index keys the RNG, so the union is the same batch whatever the
-split).  The launches of different pipes overlap, which fills the tail of a launch -- 4096 workgroups on 768 resident slots
-are 5.33 rounds -- and the gaps between dependent launches: +8.6 % on one MI355X (profiles/r04_pipes_ab.jsonl).  The timed window is placed in the BULK of the 360-step episode whatever --steps / --warmup are: an
+split).  The launches of different pipes overlap, which fills the tail of a launch -- 4096 workgroups on 1024 resident slots
+are 4 rounds that do not end together -- and the gaps between dependent launches: +10 % on one MI355X (profiles/r06_pipes_ab.jsonl).  The timed window is placed in the BULK of the 360-step episode whatever --steps / --warmup are: an
 untimed fast-forward first rolls the batch to step 180 - K/2 - W (the demand ramps up over the hour, so the first steps
 of an episode are a nearly empty network); then W untimed warm-up steps, then exactly K timed steps.  The defaults
 (W = 60, K = 300) time steps 60..360; the driver's short run (W = 5, K = 20) times steps 170..190, whose load is within
 a few per cent of the episode mean.  When an episode ends inside the timed region the reset is part of the timed work.
 
   python bench.py                               # 1 GPU
+  python bench.py --gpus N                      # N GPUs of this node: starts N ranks itself (one per device, RCCL rendezvous on 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W # N GPUs: env-batch split, no collective on the data path
+         bench.py --gpus N --steps K --warmup W # the same under a launcher; a launcher whose world differs from --gpus is refused
+                                                # (env-batch split, no collective on the data path; `rccl_ranks` = the world RCCL reports)
 
 Rank 0 prints ONE JSON line.  `roofline` prices the step kernel against HBM (this path has no dense
 contraction, MFMA is irrelevant); `cpu_baseline` is the C oracle (oracle/, test infrastructure) timed on the
@@ -56,12 +58,12 @@ def algorithmic_bytes_per_env_step(sc, mean_active):
 
 def designed_bytes_per_env_step(sc, mean_active):
     """what the kernel moves per env-step BY DESIGN: the slab fields it loads / stores once, the
-    HBM-resident private fields it touches every tick (the two mailboxes, tloss), every output buffer"""
+    HBM-resident private field it touches every tick (tloss; L2 hits after the first), every output buffer"""
     S, O = sc.n_signals, sc.n_obs
     lmax = int((sc.sig_obs_start[1:] - sc.sig_obs_start[:-1]).max())
-    # slab fields in and out once (pos, speed, lane, trip, cursor, waiting time) + speed factor at the load; every tick:
-    # both cooperation mailboxes (read), time loss (read + write)
-    per_vehicle = (4 + 4 + 2 + 2 + 2 + 2) * 2 + 4 + 10 * (4 + 4 + 4 * 2)
+    # slab fields in and out once (pos, speed, lane, trip, cursor, waiting time); every tick: time loss (read + write).  (Round 6: the
+    # cooperation mailboxes are read only by the ~5 % of the plans whose record is flagged; the speed factor is recomputed at the load.)
+    per_vehicle = (4 + 4 + 2 + 2 + 2 + 2) * 2 + 10 * (4 + 4)
     per_signal = 4 + 16 + 16 + 4 * (1 + 13 + 1 + 1 + 1 + 1 + 1 + 2)          # action, FSM in / out, mplight + the per-signal scalars
     return mean_active * per_vehicle + S * per_signal + O * 20 + 24 + 80     # + the drq_norm rows
 
