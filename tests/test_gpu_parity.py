@@ -1246,6 +1246,58 @@ def test_step_sim_and_output_mask_on_the_device():
     sim.close()
 
 
+def test_mail_flags_survive_every_launch_boundary():
+    """Round 6: a plan reads its cooperation mailboxes only when its record is flagged; between launches the flags travel in
+    RS_BUF_VEH_MAIL.  The same congested episode (ingolstadt21, the net's own programme) cut into launches of ONE tick each must end
+    in the state of ten-tick launches, both equal to the oracle (which knows no flags); snapshot / restore carries the bitmap."""
+    from resco_amd.sim import BatchedSim
+    from oracle.pyoracle import OracleEnv
+    sc = load_scenario('ingolstadt21')
+    n = 3
+    a = BatchedSim(sc, n, seed=4, fixed_program=1)
+    b = BatchedSim(sc, n, seed=4, fixed_program=1)
+    orcs = [OracleEnv(sc, env_index=e, seed=4, sigma=-1.0, speed_dev=1, fixed_program=1) for e in range(n)]
+    for o in orcs:
+        o.observe()
+    mails, snap = 0, None
+    for step in range(45):
+        a.step(None)
+        for i in range(10):
+            b.step_sim(1)
+            mails += int(np.unpackbits(b.read('veh_mail').view(np.uint8)).sum())
+            if step == 30 and i == 4:
+                snap = b.snapshot()                  # in the middle of an env-step, requests pending
+        for o in orcs:
+            for _ in range(10):
+                o.tick()
+    assert mails > 100, mails
+
+    def same(x, y):
+        lane = x.read('veh_lane')
+        np.testing.assert_array_equal(lane, y.read('veh_lane'))
+        live = lane != 0xFFFF
+        for name in ('veh_pos', 'veh_speed', 'veh_cursor', 'veh_swait', 'veh_tloss', 'veh_coop', 'veh_cooplead', 'veh_coop_odd', 'veh_cooplead_odd'):
+            np.testing.assert_array_equal(x.read(name)[live], y.read(name)[live], err_msg=name)
+        np.testing.assert_array_equal(x.read('veh_mail'), y.read('veh_mail'))
+        np.testing.assert_array_equal(x.read('env'), y.read('env'))
+
+    same(a, b)
+    for e, o in enumerate(orcs):
+        v = o.vehicles()
+        live = v['lane'] != 0xFFFF
+        np.testing.assert_array_equal(a.read('veh_lane')[e], v['lane'])
+        np.testing.assert_array_equal(a.read('veh_pos')[e][live], v['pos'][live])
+    # back to the snapshot (tick 305 of the episode) and forward again in other launch sizes: the same end state
+    b.restore(snap)
+    b.step_sim(5)
+    for step in range(31, 45):
+        b.step_sim(7)
+        b.step_sim(3)
+    same(a, b)
+    b.free_snapshot(snap)
+    a.close(); b.close()
+
+
 def test_edge_cases_capacity_invalid_actions_and_create_errors():
     """Through the C ABI: (1) the network full -- due trips wait in their lane's backlog, never dropped, bit-identical to the
     oracle; (2) action entries that are no phase index leave the signal alone; actions as a HOST array, a DEVICE tensor and the

@@ -421,3 +421,35 @@ def test_group_step_equals_the_calls_it_replaces():
             np.testing.assert_array_equal(whole.read(name), np.concatenate([p.read(name) for p in pipes]))
     with pytest.raises(RuntimeError):
         grp.step('idqn')                        # the policy network is device code: the emulation refuses
+
+
+def test_mail_flags_survive_every_launch_boundary():
+    """Round 6: a plan reads its cooperation mailboxes only when its record is flagged, and between launches the flags travel in
+    RS_BUF_VEH_MAIL.  The same congested episode (ingolstadt21 under the net's own programme: blocked lane changers every tick) cut
+    into launches of ONE tick each must end in the state of ten-tick launches -- every cooperation request written in the last tick
+    of a launch is honoured by the first plan of the next one -- and both equal the oracle, which knows no flags."""
+    sc = load_scenario('ingolstadt21')
+    kw = dict(seed=4, fixed_program=1)
+    a = EmuSim(sc, 1, order=2, **kw)
+    b = EmuSim(sc, 1, order=1, **kw)
+    o = OracleEnv(sc, env_index=0, seed=4, sigma=-1.0, speed_dev=1, fixed_program=1)
+    o.observe()
+    mails = 0
+    for step in range(45):
+        a.step(None)
+        for _ in range(10):
+            b.step_sim(1)
+            mails += int(np.unpackbits(b.read('veh_mail').view(np.uint8)).sum())
+        for _ in range(10):
+            o.tick()
+    assert mails > 50, mails                 # the boundary was crossed with requests pending, many times
+    v = o.vehicles()
+    live = v['lane'] != 0xFFFF
+    np.testing.assert_array_equal(a.read('veh_lane'), b.read('veh_lane'))
+    for name in ('veh_pos', 'veh_speed', 'veh_cursor', 'veh_swait', 'veh_tloss', 'veh_coop', 'veh_cooplead', 'veh_coop_odd', 'veh_cooplead_odd'):
+        np.testing.assert_array_equal(a.read(name)[0][live], b.read(name)[0][live], err_msg=name)        # (a free slot keeps what its last tenant left)
+    for name in ('veh_mail', 'env'):
+        np.testing.assert_array_equal(a.read(name), b.read(name), err_msg=name)
+    np.testing.assert_array_equal(a.read('veh_lane')[0], v['lane'])
+    np.testing.assert_array_equal(a.read('veh_pos')[0][live], v['pos'][live])
+    a.close(); b.close()
