@@ -684,15 +684,22 @@ RS_DEV float cont_of(const ContRow &R, int j) {
 // are computed with while the next tick's grid is still being built.
 #define OCC_NONE (Grid{(uint16_t *)0, 0u})
 #define OCC_FULL (Grid{(uint16_t *)1, 0u})
+// The table carries "lane k is NOT one of the best lanes of its route step" in the SIGN of the continuation length (PackedTables::build:
+// the comparison `c >= best - RM_CONT_EPS` over the lanes of the step's edge is a property of the table, not of the vehicle): whoever
+// wants the length takes the magnitude, and neither the maximum over the lanes nor the comparisons are evaluated per vehicle and tick.
+RS_DEV bool cont_notbest(float c) { return rs_float_as_int(c) < 0; }
+RS_DEV float cont_len(float c) { return rs_int_as_float(rs_float_as_int(c) & 0x7FFFFFFF); }
 RS_DEV int strategic_dir(const ContRow &R, int kk, int n, float x, float v, int extra, float &rem, const Grid &grid, int cell0, int nc, float occ_unit) {
-    float best = 0.0f;
-    for (int j = 0; j < n; ++j) { const float c = cont_of(R, j); if (c > best) best = c; }
     const float mine = cont_of(R, kk);
-    rem = mine - x;
-    if (mine >= best - RM_CONT_EPS) return 0;
+    rem = cont_len(mine) - x;
+#ifdef RS_EMU_CHECK_MAIL      // (host emulation: the sign is what the comparison over the lanes of THIS edge gives)
+    { float best = 0.0f; for (int j = 0; j < n; ++j) { const float c = cont_len(cont_of(R, j)); if (c > best) best = c; }
+      for (int j = 0; j < n; ++j) RS_ASSERT(cont_notbest(cont_of(R, j)) == !(cont_len(cont_of(R, j)) >= best - RM_CONT_EPS)) }
+#endif
+    if (!cont_notbest(mine)) return 0;
     int dl = 1000, dr = 1000;
-    for (int j = kk + 1; j < n; ++j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dl = j - kk; break; }
-    for (int j = kk - 1; j >= 0; --j) if (cont_of(R, j) >= best - RM_CONT_EPS) { dr = kk - j; break; }
+    for (int j = kk + 1; j < n; ++j) if (!cont_notbest(cont_of(R, j))) { dl = j - kk; break; }
+    for (int j = kk - 1; j >= 0; --j) if (!cont_notbest(cont_of(R, j))) { dr = kk - j; break; }
     const int dir = (dr <= dl) ? -1 : +1;
     if (grid.c == (uint16_t *)1) return dir;
     const int off = (dr <= dl ? dr : dl) + extra;

@@ -180,6 +180,7 @@ struct PackedTables {
     std::vector<int32_t> tls_off_p, fix_off_p;      // byte offset of signal s's first row in tls8 / fix8 (rows padded to tls_maxl bytes)
     std::vector<int16_t> lane_obs16;
     std::vector<int32_t> obs_sig;
+    std::vector<float> route_cont;          // sc->route_cont with the sign bit set where the lane is not one of the best of its route step (resco_step.h: cont_notbest)
     int n_cells = 0, n_arr = 1, n_dep = 1, kmax = 1, lmax = 1, tls_maxl = 1;
     float maxlen = 0.0f, occ_unit = 0.0f;
     float cell_len = 30.0f, cell_inv = 1.0f / 30.0f;       // grid cell length of this build of the tables (pick_cell_len)
@@ -319,6 +320,23 @@ struct PackedTables {
             memset(R.pad, 0, sizeof(R.pad));
         }
         kmax = sc->kmax;
+        {   // continuation lengths, signed: lane k of route step q is "not a best lane" iff !(c_k >= max_j c_j - RM_CONT_EPS) over the lanes of
+            // the step's edge -- the very comparison the oracle's strategic_dir_at makes per vehicle and tick
+            const size_t nq = (size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1);
+            route_cont.assign(nq * kmax, 0.0f);
+            for (int q = 0; q < sc->n_route_steps; ++q) {
+                const float *c = sc->route_cont + (size_t)q * kmax;
+                const int n = sc->edge_nlanes[sc->route_edge[q]];
+                float best = 0.0f;
+                for (int j = 0; j < n && j < kmax; ++j) if (c[j] > best) best = c[j];
+                for (int j = 0; j < kmax; ++j) {
+                    float v = c[j];
+                    if (!(v >= 0.0f)) { err = "negative continuation length"; return false; }
+                    if (j < n && !(v >= best - RM_CONT_EPS)) { uint32_t b; memcpy(&b, &v, 4); b |= 0x80000000u; memcpy(&v, &b, 4); }
+                    route_cont[(size_t)q * kmax + j] = v;
+                }
+            }
+        }
         rsteps.resize((size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1));
         routes.resize((size_t)sc->n_routes);
         next_link.assign((size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1) * kmax * 2, (uint16_t)NLINK_NONE);

@@ -168,7 +168,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->order = device_id;           // the emulation has no device: the argument carries the thread order
     h->block = block_threads > 0 ? block_threads : (C > 1024 ? 1024 : C);
     h->n_envs = n_envs;
-    h->route_cont.assign(sc->route_cont, sc->route_cont + (size_t)sc->n_route_steps * sc->kmax);
+    h->route_cont = PT.route_cont;
     h->vtype_params.assign(sc->vtype_params, sc->vtype_params + (size_t)sc->n_vtypes * VT_COLS);
     KTab &K = h->K; KCold &c = K.cold;
     K.lanes_ = PT.lanes.data(); K.links_ = PT.links.data(); K.foes_ = PT.foes.data(); K.rsteps_ = PT.rsteps.data();
