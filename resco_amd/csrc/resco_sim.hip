@@ -484,7 +484,7 @@ extern "C" int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_en
         UP(K.foes_, FoeRec, PT.foes.data(), PT.foes.size()) UP(K.rsteps_, RStep, PT.rsteps.data(), PT.rsteps.size())
         UP(K.routes_, RouteRec, PT.routes.data(), PT.routes.size()) UP(K.next_link_, uint16_t, PT.next_link.data(), PT.next_link.size())
         UP(K.trip_route_, uint16_t, PT.trip_route.data(), PT.trip_route.size()) UP(K.trip_vtype_, uint8_t, PT.trip_vtype.data(), PT.trip_vtype.size())
-        UP(K.route_cont_, float, PT.route_cont.data(), PT.route_cont.size())
+        UP(K.route_cont_, float, PT.route_cont.data(), PT.route_cont.size()) UP(K.notbest_, uint16_t, PT.notbest.data(), PT.notbest.size())
         UP(cold.trip_depart, int32_t, sc->trip_depart, sc->n_trips) UP(cold.trip_next, uint16_t, PT.trip_next.data(), PT.trip_next.size())
         UP(cold.dep_lane, uint16_t, PT.dep_lane.data(), PT.dep_lane.size()) UP(cold.dep_info, DepInfo, PT.dep_info.data(), PT.dep_info.size()) UP(cold.dep_first, uint16_t, PT.dep_first.data(), PT.dep_first.size())
         UP(cold.vtype_params, float, sc->vtype_params, sc->n_vtypes * VT_COLS)

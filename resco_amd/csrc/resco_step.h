@@ -786,7 +786,7 @@ RS_DEV bool looks_beyond(const float *vt, float v, float x, float lane_len, floa
 // can the lane-change decision of tick t have an effect for a vehicle in this state?  (a superset, computed before the
 // grid of tick t is complete: it is on a lane that is not a best one -- whether the need has arisen depends on the queue
 // beside it --, or it is its turn to look for speed gain on a neighbour lane that may be good enough)
-RS_DEV bool may_change_lanes(const ContRow &R, const LaneRec &LR, int lane, int k, float x, float v, int t) {
+RS_DEV bool may_change_lanes_row(const ContRow &R, const LaneRec &LR, int lane, int k, float x, float v, int t) {
     const int n = LR.flags >> 2;
     if ((LR.flags & LF_INTERNAL) || n < 2) return false;
     const int kk = lane - (int)LR.edge_lane0;
@@ -796,11 +796,32 @@ RS_DEV bool may_change_lanes(const ContRow &R, const LaneRec &LR, int lane, int 
     const int tk = kk + ((t & 1) ? -1 : +1);
     return tk >= 0 && tk < n && strategic_dir(R, tk, n, x, v, RM_SG_EXTRA_LANES, rem, OCC_NONE, 0, 0, 0.0f) == 0;
 }
+// the same from the not-best MASK of the route step (KTab::notbest: bit k = lane k is not one of the step's best lanes -- the signs of the
+// continuation row as one 16-bit word): the move classifies every vehicle every tick, and all it needs of the row is two of these bits.
+// The lengths themselves are fetched only when the neighbour lane of a speed-gain candidate is not a best lane either (rare).
+RS_DEV bool may_change_lanes(const KTab &T, int rq, uint32_t nb, const LaneRec &LR, int lane, int k, float x, float v, int t) {
+    const int n = LR.flags >> 2;
+    if ((LR.flags & LF_INTERNAL) || n < 2) return false;
+    const int kk = lane - (int)LR.edge_lane0;
+    bool r;
+    if ((nb >> kk) & 1u) r = true;
+    else if ((((uint32_t)t >> 1) + (uint32_t)k) & 3u) r = false;
+    else {
+        const int tk = kk + ((t & 1) ? -1 : +1);
+        if (tk < 0 || tk >= n) r = false;
+        else if (!((nb >> tk) & 1u)) r = true;
+        else { float rem; r = strategic_dir(cont_row(T, rq), tk, n, x, v, RM_SG_EXTRA_LANES, rem, OCC_NONE, 0, 0, 0.0f) == 0; }
+    }
+#ifdef RS_EMU_CHECK_MAIL      // (host emulation)
+    RS_ASSERT(r == may_change_lanes_row(cont_row(T, rq), LR, lane, k, x, v, t))
+#endif
+    return r;
+}
 // The work of tick t for the vehicle in slot s (state as of the beginning of that tick): its flags, and it is queued
-template <class LT> RS_DEV int classify(const LT &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, const ContRow &R, int k, float sf, int t) {
+template <class LT> RS_DEV int classify(const KTab &T, const LT &L, int s, const float *vt, float v, float x, const LaneRec &LR, int lane, int rq, uint32_t nb, int k, float sf, int t) {
     int fl = 0;
     if (looks_beyond(vt, v, x, LR.len, LR.vmax, sf)) { fl |= FL_H; list_push(L, L.ls_h, SC_NH, s); }
-    if (may_change_lanes(R, LR, lane, k, x, v, t)) { fl |= FL_LC; list_push(L, L.ls_lc, SC_NLC, s); }
+    if (may_change_lanes(T, rq, nb, LR, lane, k, x, v, t)) { fl |= FL_LC; list_push(L, L.ls_lc, SC_NLC, s); }
     return fl;
 }
 
@@ -952,7 +973,7 @@ template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L
 #endif
     LaneRec LR = T.lanes()[lane];
     // what the end of the move needs from the tables is requested now (the common case: the vehicle stays on its lane)
-    ContRow R = cont_row(T, ax.rq);
+    uint32_t nb = T.notbest()[ax.rq];       // (which lanes of my route step are not its best ones: what classify() needs of the continuation row)
     uint32_t kw = 0;
     if (more && (ax.nlink & NLINK_ARR)) kw = link_reg_word(T, ax.nlink);
     const float sfv = sf_of(me.sfq);
@@ -1039,8 +1060,8 @@ template <bool LONG, class LT> RS_DEV void phase_move(const KTab &T, const LT &L
     nn.pos = x; nn.speed = vn; nn.fl = (uint8_t)(me.fl & fl_mh(t));
     nn.nxt = grid_push(gnew, LR.cell0 + cell_of(L, x, lane_cells(L, LR)), s, vn > RM_HALT_SPEED);
     if (more) {
-        if (LONG && relink) { R = cont_row(T, rq); if (na.nlink & NLINK_ARR) kw = link_reg_word(T, na.nlink); }
-        nn.fl |= classify(L, s, L.vtp + me.vt * VT_COLS, vn, x, LR, lane, R, k, sfv, t + 1);
+        if (LONG && relink) { nb = T.notbest()[rq]; if (na.nlink & NLINK_ARR) kw = link_reg_word(T, na.nlink); }
+        nn.fl |= classify(T, L, s, L.vtp + me.vt * VT_COLS, vn, x, LR, lane, rq, nb, k, sfv, t + 1);
         L.node[s] = nn;
         if ((na.nlink & NLINK_ARR) && vn > RM_HALT_SPEED) register_approach_w(T, L, kw, vn, x, LR.len, me.vt);
     } else L.node[s] = nn;
@@ -1277,7 +1298,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
             // a request of the last tick before this launch waits in the mailboxes: the first plan reads those of parity (t + 1) & 1
             if ((G.mail[(size_t)env * ((C + 31) / 32) + (s >> 5)] >> (s & 31)) & 1u) nn.sfq |= (uint16_t)SFQ_MAIL((L.sc[SC_T] + 1) & 1);
             nn.nxt = grid_push(Grid{grid0, 0u}, LR0.cell0 + cell_of(L, x, lane_cells(L, LR0)), s, sp > RM_HALT_SPEED);
-            if (n_ticks > 0) nn.fl = (uint8_t)classify(L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, cont_row(T, rq), tr, sf_of(nn.sfq), L.sc[SC_T]);
+            if (n_ticks > 0) nn.fl = (uint8_t)classify(T, L, s, L.vtp + nn.vt * VT_COLS, sp, x, LR0, ln, rq, T.notbest()[rq], tr, sf_of(nn.sfq), L.sc[SC_T]);
             L.node[s] = nn;
             rs_atomic_or(&L.alive[s >> 5], 1u << (s & 31));
         }
@@ -1432,7 +1453,7 @@ RS_DEV void rs_step_body_on(Exec &ex, const LT &L, const KTab &T, const State &G
                         Node nn; nn.pos = vt[VT_LENGTH] < RR.depart_len ? vt[VT_LENGTH] : RR.depart_len;
                         nn.speed = 0.0f; nn.trip = (uint16_t)k; nn.vt = (uint8_t)v; nn.fl = 0; nn.sfq = (uint16_t)sfq;
                         nn.nxt = grid_push(gnew, LRd.cell0 + cell_of(L, nn.pos, lane_cells(L, LRd)), s, false);
-                        if (more) nn.fl = (uint8_t)classify(L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, cont_row(T, (int)RR.start), k, sfn, t + 1);
+                        if (more) nn.fl = (uint8_t)classify(T, L, s, vt, 0.0f, nn.pos, LRd, RR.depart_lane, (int)RR.start, T.notbest()[RR.start], k, sfn, t + 1);
                         L.node[s] = nn;
                         Aux na; na.lane = RR.depart_lane; na.rq = (uint16_t)RR.start; na.swait = 0;
                         na.nlink = cache_link(T, LRd, RR.depart_lane, (int)RR.start, k);

@@ -122,6 +122,7 @@ struct KTab {
     const RStep *rsteps_;
     const float *route_cont_;       // [n_route_steps][kmax]
     const uint16_t *next_link_;     // [n_route_steps][kmax][2]: choose_link() of a normal lane for even / odd trips, NLINK_NONE: none
+    const uint16_t *notbest_;       // [n_route_steps] bit k: lane k of the step's edge is not one of its best lanes (= the signs of route_cont's row)
     const RouteRec *routes_;
     const uint16_t *trip_route_;
     const uint8_t *trip_vtype_;
@@ -136,6 +137,7 @@ struct KTab {
     RS_MEM const RStep *rsteps() const { return RS_G(rsteps_); }
     RS_MEM const float *route_cont() const { return RS_G(route_cont_); }
     RS_MEM const uint16_t *next_link() const { return RS_G(next_link_); }
+    RS_MEM const uint16_t *notbest() const { return RS_G(notbest_); }
     RS_MEM const RouteRec *routes() const { return RS_G(routes_); }
     RS_MEM const uint16_t *trip_route() const { return RS_G(trip_route_); }
     RS_MEM const uint8_t *trip_vtype() const { return RS_G(trip_vtype_); }
@@ -174,7 +176,7 @@ struct PackedTables {
     std::vector<FoeRec> foes;
     std::vector<RStep> rsteps;
     std::vector<RouteRec> routes;
-    std::vector<uint16_t> next_link, trip_route, trip_next, dep_lane, dep_first;
+    std::vector<uint16_t> next_link, trip_route, trip_next, dep_lane, dep_first, notbest;
     std::vector<uint8_t> trip_vtype, tls8, fix8;
     std::vector<DepInfo> dep_info;
     std::vector<int32_t> tls_off_p, fix_off_p;      // byte offset of signal s's first row in tls8 / fix8 (rows padded to tls_maxl bytes)
@@ -324,6 +326,7 @@ struct PackedTables {
             // the step's edge -- the very comparison the oracle's strategic_dir_at makes per vehicle and tick
             const size_t nq = (size_t)(sc->n_route_steps > 0 ? sc->n_route_steps : 1);
             route_cont.assign(nq * kmax, 0.0f);
+            notbest.assign(nq, 0);
             for (int q = 0; q < sc->n_route_steps; ++q) {
                 const float *c = sc->route_cont + (size_t)q * kmax;
                 const int n = sc->edge_nlanes[sc->route_edge[q]];
@@ -332,7 +335,7 @@ struct PackedTables {
                 for (int j = 0; j < kmax; ++j) {
                     float v = c[j];
                     if (!(v >= 0.0f)) { err = "negative continuation length"; return false; }
-                    if (j < n && !(v >= best - RM_CONT_EPS)) { uint32_t b; memcpy(&b, &v, 4); b |= 0x80000000u; memcpy(&v, &b, 4); }
+                    if (j < n && !(v >= best - RM_CONT_EPS)) { uint32_t b; memcpy(&b, &v, 4); b |= 0x80000000u; memcpy(&v, &b, 4); notbest[(size_t)q] |= (uint16_t)(1u << j); }
                     route_cont[(size_t)q * kmax + j] = v;
                 }
             }

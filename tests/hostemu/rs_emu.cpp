@@ -172,7 +172,7 @@ int rs_create(const rs_scenario *sc, const rs_params *p, int32_t n_envs, int32_t
     h->vtype_params.assign(sc->vtype_params, sc->vtype_params + (size_t)sc->n_vtypes * VT_COLS);
     KTab &K = h->K; KCold &c = K.cold;
     K.lanes_ = PT.lanes.data(); K.links_ = PT.links.data(); K.foes_ = PT.foes.data(); K.rsteps_ = PT.rsteps.data();
-    K.route_cont_ = h->route_cont.data(); K.next_link_ = PT.next_link.data(); K.routes_ = PT.routes.data();
+    K.route_cont_ = h->route_cont.data(); K.next_link_ = PT.next_link.data(); K.notbest_ = PT.notbest.data(); K.routes_ = PT.routes.data();
     K.trip_route_ = PT.trip_route.data(); K.trip_vtype_ = PT.trip_vtype.data();
     c.trip_depart = keep_i32(h, sc->trip_depart, sc->n_trips); c.trip_next = PT.trip_next.data(); c.dep_lane = PT.dep_lane.data(); c.dep_info = PT.dep_info.data(); c.dep_first = PT.dep_first.data();
     c.vtype_params = h->vtype_params.data(); c.tls8 = PT.tls8.data(); c.fix8 = PT.fix8.data();
