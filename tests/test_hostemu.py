@@ -453,3 +453,15 @@ def test_mail_flags_survive_every_launch_boundary():
     np.testing.assert_array_equal(a.read('veh_lane')[0], v['lane'])
     np.testing.assert_array_equal(a.read('veh_pos')[0][live], v['pos'][live])
     a.close(); b.close()
+
+
+def test_working_memory_of_the_headline_map_fits_a_cu_four_times():
+    """Round 6: four 512-thread workgroups per CU on ingolstadt21 (+12.5 % env-steps/s) need <= 40 960 B of LDS per environment (32
+    granules of 1280 B).  The layout is computed by host code the emulation shares with rs_create (lds_carve): a field added to the
+    working memory that pushes the headline map over the limit costs a workgroup per CU silently -- this makes it loud."""
+    sc = load_scenario('ingolstadt21')
+    sim = EmuSim(sc, 1, seed=0)
+    info = sim.info()
+    sim.close()
+    assert sc.capacity == 896
+    assert info['lds_bytes'] <= 40960, info
